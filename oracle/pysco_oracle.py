@@ -1,0 +1,492 @@
+"""CPU oracle for PySCo's per-step PM path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+A restatement (C kernels in pm_oracle.c + numpy for the k-space tables and the FFT) of the
+reference's algorithm.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module; the product (pysco_amd/) never does.
+
+Parity status: PINNED -- every function here is checked in tests/test_oracle_golden.py against
+golden vectors captured by oracle/gen_golden.py from the reference source itself (executed in the
+build container; the reference has no tests or fixtures of its own).
+
+Citations are relative to /root/reference/pysco/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+from typing import List, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_f32 = np.float32
+_fp = C.POINTER(C.c_float)
+
+
+def build(force: bool = False) -> None:
+    """Compile the C restatement (gcc, a second or two)."""
+    out = os.path.join(_HERE, "_build", "libpm_oracle.so")
+    src = os.path.join(_HERE, "pm_oracle.c")
+    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+_libs = {}
+
+
+def _lib(omp: bool = False):
+    key = "omp" if omp else "seq"
+    if key not in _libs:
+        build()
+        name = "libpm_oracle_omp.so" if omp else "libpm_oracle.so"
+        lib = C.CDLL(os.path.join(_HERE, "_build", name))
+        lib.pmo_max_abs.restype = C.c_float
+        lib.pmo_num_threads.restype = C.c_int
+        _libs[key] = lib
+    return _libs[key]
+
+
+_use_omp = False
+
+
+def use_openmp(flag: bool) -> None:
+    """bench.py's cpu_baseline leg switches to the OpenMP build; parity tests use the serial one."""
+    global _use_omp
+    _use_omp = bool(flag)
+
+
+def num_threads() -> int:
+    return int(_lib(_use_omp).pmo_num_threads())
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ------------------------------------------------------------------ mesh.py
+
+
+def NGP(position, ncells_1d: int) -> np.ndarray:  # mesh.py:2240
+    pos = _c32(position)
+    rho = np.empty((ncells_1d,) * 3, dtype=np.float32)
+    _lib(_use_omp).pmo_ngp(_p(pos), C.c_int64(pos.shape[0]), C.c_int(ncells_1d), _p(rho))
+    return rho
+
+
+def CIC(position, ncells_1d: int) -> np.ndarray:  # mesh.py:2284
+    pos = _c32(position)
+    rho = np.empty((ncells_1d,) * 3, dtype=np.float32)
+    _lib(_use_omp).pmo_cic(_p(pos), C.c_int64(pos.shape[0]), C.c_int(ncells_1d), _p(rho))
+    return rho
+
+
+def TSC(position, ncells_1d: int) -> np.ndarray:  # mesh.py:2363 / 2468
+    pos = _c32(position)
+    rho = np.empty((ncells_1d,) * 3, dtype=np.float32)
+    _lib(_use_omp).pmo_tsc(_p(pos), C.c_int64(pos.shape[0]), C.c_int(ncells_1d), _p(rho))
+    return rho
+
+
+TSC_seq = TSC
+
+
+def invNGP_vec(grid, position) -> np.ndarray:  # mesh.py:2639
+    g, pos = _c32(grid), _c32(position)
+    out = np.empty_like(pos)
+    _lib(_use_omp).pmo_inv_ngp_vec(_p(g), C.c_int(g.shape[0]), _p(pos), C.c_int64(pos.shape[0]), _p(out))
+    return out
+
+
+def invCIC_vec(grid, position) -> np.ndarray:  # mesh.py:2752
+    g, pos = _c32(grid), _c32(position)
+    out = np.empty_like(pos)
+    _lib(_use_omp).pmo_inv_cic_vec(_p(g), C.c_int(g.shape[0]), _p(pos), C.c_int64(pos.shape[0]), _p(out))
+    return out
+
+
+def invTSC_vec(grid, position) -> np.ndarray:  # mesh.py:2960
+    g, pos = _c32(grid), _c32(position)
+    out = np.empty_like(pos)
+    _lib(_use_omp).pmo_inv_tsc(_p(g), C.c_int(g.shape[0]), C.c_int(3), _p(pos), C.c_int64(pos.shape[0]), _p(out))
+    return out
+
+
+def invTSC(grid, position) -> np.ndarray:  # mesh.py:2827
+    g, pos = _c32(grid), _c32(position)
+    out = np.empty(pos.shape[0], dtype=np.float32)
+    _lib(_use_omp).pmo_inv_tsc(_p(g), C.c_int(g.shape[0]), C.c_int(1), _p(pos), C.c_int64(pos.shape[0]), _p(out))
+    return out
+
+
+def derivative(a, order: int) -> np.ndarray:  # mesh.py:2072 -> 639/681/725/782
+    if order not in (2, 3, 5, 7):
+        raise ValueError(f"gradient_order={order}, should be 2, 3, 5 or 7")
+    a = _c32(a)
+    n = a.shape[0]
+    out = np.empty((n, n, n, 3), dtype=np.float32)
+    _lib(_use_omp).pmo_derivative(_p(a), None, C.c_float(0), C.c_int(0), C.c_int(n), C.c_int(order), _p(out))
+    return out
+
+
+def derivative_fR(a, b, f, fR_n: int, order: int) -> np.ndarray:  # mesh.py:2112
+    if order not in (2, 3, 5, 7):
+        raise ValueError(f"gradient_order={order}, should be 2, 3, 5 or 7")
+    if fR_n not in (1, 2):
+        raise NotImplementedError(f"Only f(R) with n = 1 and 2, currently fR_n={fR_n}")
+    a, b = _c32(a), _c32(b)
+    n = a.shape[0]
+    out = np.empty((n, n, n, 3), dtype=np.float32)
+    _lib(_use_omp).pmo_derivative(_p(a), _p(b), C.c_float(f), C.c_int(fR_n), C.c_int(n), C.c_int(order), _p(out))
+    return out
+
+
+# ------------------------------------------------------------------ utils.py
+
+
+def add_vector_scalar_inplace(y, x, a) -> None:  # utils.py:264
+    assert y.dtype == np.float32 and y.flags.c_contiguous
+    x = _c32(x)
+    _lib(_use_omp).pmo_axpy(_p(y), _p(x), C.c_float(a), C.c_int64(y.size))
+
+
+def prod_vector_scalar_inplace(y, a) -> None:  # utils.py:410
+    assert y.dtype == np.float32 and y.flags.c_contiguous
+    _lib(_use_omp).pmo_scale(_p(y), C.c_float(a), C.c_int64(y.size))
+
+
+def linear_operator(x, f1, f2) -> np.ndarray:  # utils.py:644
+    x = _c32(x)
+    out = np.empty_like(x)
+    _lib(_use_omp).pmo_linear_operator(_p(x), C.c_float(f1), C.c_float(f2), _p(out), C.c_int64(x.size))
+    return out
+
+
+def linear_operator_inplace(x, f1, f2) -> None:  # utils.py:684
+    assert x.dtype == np.float32 and x.flags.c_contiguous
+    _lib(_use_omp).pmo_linear_operator(_p(x), C.c_float(f1), C.c_float(f2), _p(x), C.c_int64(x.size))
+
+
+def linear_operator_vectors_inplace(x, f1, y, f2) -> None:  # utils.py:721
+    assert x.dtype == np.float32 and x.flags.c_contiguous
+    y = _c32(y)
+    _lib(_use_omp).pmo_linear_operator_vectors(_p(x), C.c_float(f1), _p(y), C.c_float(f2), C.c_int64(x.size))
+
+
+def max_abs(x) -> np.float32:  # utils.py:220
+    x = _c32(x)
+    return np.float32(_lib(_use_omp).pmo_max_abs(_p(x), C.c_int64(x.size)))
+
+
+def periodic_wrap(position) -> None:  # utils.py:1120
+    assert position.dtype == np.float32 and position.flags.c_contiguous
+    _lib(_use_omp).pmo_periodic_wrap(_p(position), C.c_int64(position.size))
+
+
+def positions_to_keys(position) -> np.ndarray:  # morton.py:113
+    pos = _c32(position)
+    keys = np.empty(pos.shape[0], dtype=np.int64)
+    _lib(_use_omp).pmo_morton_keys(_p(pos), C.c_int64(pos.shape[0]), _p(keys))
+    return keys
+
+
+def reorder_particles(position, velocity=None, acceleration=None):  # utils.py:1019 (nthreads == 1)
+    arg = np.argsort(positions_to_keys(position), kind="stable")
+    if acceleration is not None:
+        return position[arg], velocity[arg], acceleration[arg]
+    if velocity is not None:
+        return position[arg], velocity[arg]
+    return position[arg]
+
+
+def set_units(param) -> None:  # utils.py:167-192 (G, pc: CODATA 2018 as astropy.constants)
+    G, pc = 6.6743e-11, 3.0856775814913674e16
+    mpc_to_km = 1e3 * pc
+    g = G * 1e-9
+    H0 = param["H0"] / mpc_to_km
+    rhoc = 3.0 * H0**2 / (8.0 * np.pi * g)
+    param["unit_l"] = param["aexp"] * param["boxlen"] * 100.0 / H0
+    param["unit_t"] = param["aexp"] ** 2 / H0
+    param["unit_d"] = param["Om_m"] * rhoc / param["aexp"] ** 3
+    param["mpart"] = param["unit_d"] * param["unit_l"] ** 3 / param["npart"]
+
+
+# ------------------------------------------------------------------ fourier.py
+
+
+def fft_3D_real(x, threads: int = 1) -> np.ndarray:  # fourier.py:104 (NumPy fallback :129-130)
+    return np.ascontiguousarray(np.fft.rfftn(x).astype(np.complex64))
+
+
+def ifft_3D_real(x, threads: int = 1) -> np.ndarray:  # fourier.py:251 (NumPy fallback :276-277)
+    return np.ascontiguousarray(np.fft.irfftn(x).astype(np.float32))
+
+
+def _kfreq(n: int) -> np.ndarray:
+    """kx = i - n if i >= n//2 else i, as fp32 (fourier.py:523-527)."""
+    i = np.arange(n)
+    return np.where(i >= n // 2, i - n, i).astype(np.float32)
+
+
+def _apply_greens(x: np.ndarray, kind: int, p: int, k2: np.ndarray, s: np.ndarray, c0: float) -> None:
+    assert x.dtype == np.complex64 and x.flags.c_contiguous
+    n = x.shape[0]
+    k2, s = _c32(k2), _c32(s)
+    _lib(_use_omp).pmo_greens(_p(x), C.c_int(n), C.c_int(kind), C.c_int(p), _p(k2), _p(s), C.c_double(c0))
+
+
+def inverse_laplacian(x) -> None:  # fourier.py:460-491
+    n = x.shape[0]
+    i = np.arange(n)
+    k = np.where(i > n // 2, n - i, i).astype(np.float32)  # note: '>' here, '>=' in the others
+    c0 = float(np.float32(-0.25 / np.pi**2))
+    _apply_greens(x, 0, 0, k**2, np.ones(n, np.float32), c0)
+
+
+def inverse_laplacian_compensated(x, p: int) -> None:  # fourier.py:502-544
+    n = x.shape[0]
+    k = _kfreq(n)
+    h = np.float32(1.0 / n)
+    c0 = float(np.float32(-0.25 / np.pi**2))
+    _apply_greens(x, 1, int(p), k**2, np.sinc(k * h).astype(np.float32), c0)
+
+
+def inverse_laplacian_7pt(x) -> None:  # fourier.py:555-595
+    n = x.shape[0]
+    k = _kfreq(n)
+    pi_h = np.float32(np.pi / n)
+    h = np.float32(1.0 / n)
+    minus_h2_inv4 = float(-(np.float32(0.25) * h**2))
+    # Numba types math.sin(f4) as f4: the table, its sums and the quotient are all fp32.
+    f = (np.sin(pi_h * k) ** 2).astype(np.float32)
+    _apply_greens(x, 2, 0, np.zeros(n, np.float32), f, minus_h2_inv4)
+
+
+def fourier_grid_to_Pk(density_k, p: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:  # fourier.py:22-100
+    assert density_k.dtype == np.complex64 and density_k.flags.c_contiguous
+    n = density_k.shape[0]
+    k = _kfreq(n)
+    prefactor = np.float32(1.0 / n)
+    sincs = np.sinc(k * prefactor).astype(np.float32)
+    ks = np.zeros(n, np.float32)
+    ps = np.zeros(n, np.float32)
+    nm = np.zeros(n, np.float32)
+    _lib(False).pmo_pk(_p(density_k), C.c_int(n), C.c_int(int(p)), _p(sincs), _p(ks), _p(ps), _p(nm))
+    kmax = int(2 * (n // 2) / 3)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return ks[1:kmax] / nm[1:kmax], ps[1:kmax] / nm[1:kmax], nm[1:kmax]
+
+
+# ------------------------------------------------------------------ solver.py (Newtonian FFT path)
+
+
+def rhs_poisson(density, additional_field, param) -> None:  # solver.py:381-449 (linear branch)
+    f1 = np.float32(1.5 * param["aexp"] * param["Om_m"] * param["parametrized_mu_z"])
+    linear_operator_inplace(density, f1, -f1)
+
+
+def fft(rhs, param, pk_out: list | None = None) -> np.ndarray:  # solver.py:453-522
+    MAS_index = param["MAS_index"]
+    rhs_fourier = fft_3D_real(rhs)
+    solver = param["linear_newton_solver"].casefold()
+    if param.get("save_pk", False):
+        k, Pk, Nmodes = fourier_grid_to_Pk(rhs_fourier, MAS_index)
+        Pk = Pk * np.float32(
+            (param["boxlen"] / len(rhs) ** 2) ** 3
+            / (1.5 * param["aexp"] * param["Om_m"]) ** 2
+            / param["parametrized_mu_z"] ** 2
+        )
+        k = k * np.float32(2 * np.pi / param["boxlen"])
+        if pk_out is not None:
+            pk_out.append((k, Pk, Nmodes))
+    if solver == "fft":
+        if MAS_index == 0:
+            inverse_laplacian(rhs_fourier)
+        else:
+            inverse_laplacian_compensated(rhs_fourier, MAS_index)
+    elif solver == "fft_7pt":
+        inverse_laplacian_7pt(rhs_fourier)
+    else:
+        raise NotImplementedError(f"{solver=}, should be 'fft' or 'fft_7pt'")
+    return ifft_3D_real(rhs_fourier)
+
+
+# ------------------------------------------------------------------ solver.pm / integration (oracle side)
+
+
+def pm(position, param, potential=None, additional_field=None, tables=(), pk_out: list | None = None):
+    """solver.py:30-215.  `param` is any mutable mapping (dict or pd.Series)."""
+    empty = np.empty(0, dtype=np.float32)
+    potential = empty if potential is None else potential
+    additional_field = empty if additional_field is None else additional_field
+    n = 2 ** int(param["ncoarse"])
+    scheme = param["mass_scheme"].casefold()
+    theory = param["theory"].casefold()
+    if scheme == "cic":
+        param["MAS_index"] = 2
+        density = CIC(position, n)
+    elif scheme == "tsc":
+        param["MAS_index"] = 3
+        density = TSC(position, n)
+    else:
+        raise NotImplementedError(f"{param['mass_scheme']=}, should be 'CIC' or 'TSC'")
+
+    if theory == "parametrized":  # solver.py:95-110
+        evo = param["aexp"] ** (-3 * (1 + param["w0"] + param["wa"])) * np.exp(-3 * param["wa"] * (1 - param["aexp"]))
+        oml = param["Om_lambda"] * evo / (
+            param["Om_m"] * param["aexp"] ** (-3) + param["Om_r"] * param["aexp"] ** (-4) + param["Om_lambda"] * evo
+        )
+        param["parametrized_mu_z"] = np.float32(1 + param["parametrized_mu0"] * oml / param["Om_lambda"])
+    else:
+        param["parametrized_mu_z"] = np.float32(1)
+
+    if n**3 != param["npart"]:
+        prod_vector_scalar_inplace(density, np.float32(n**3 / param["npart"]))
+
+    save = param["save_power_spectrum"].casefold()
+    if save == "yes":
+        param["save_pk"] = True
+    elif save == "z_out":
+        param["save_pk"] = bool(param["write_snapshot"])
+    elif save == "no":
+        param["save_pk"] = False
+    else:
+        raise NotImplementedError(f"SAVE_POWER_SPECTRUM={save!r}, should be 'yes', 'z_out' or 'no'")
+
+    solver = param["linear_newton_solver"].casefold()
+    if param["save_pk"] and solver == "multigrid":  # solver.py:134-140
+        dk = fft_3D_real(density)
+        k, Pk, Nmodes = fourier_grid_to_Pk(dk, param["MAS_index"])
+        Pk = Pk * np.float32((param["boxlen"] / len(density) ** 2) ** 3)
+        k = k * np.float32(2 * np.pi / param["boxlen"])
+        if pk_out is not None:
+            pk_out.append((k, Pk, Nmodes))
+
+    param["compute_additional_field"] = True
+    additional_field = get_additional_field(additional_field, density, param, tables)
+    param["compute_additional_field"] = False
+    rhs_poisson_full(density, additional_field, param)
+    rhs = density
+
+    if solver == "multigrid":
+        potential = initialise_potential(potential, rhs, param, tables)
+        potential = mg_linear(potential, rhs, param)
+    elif solver in ("fft", "fft_7pt"):
+        potential = fft(rhs, param, pk_out)
+    elif solver == "full_fft":
+        # the reference's full_fft branch calls fft_force with 3 args (solver.py:181,200) -> TypeError
+        raise TypeError("fft_force() takes 2 positional arguments but 3 were given")
+    else:
+        raise NotImplementedError(f"{param['linear_newton_solver']=}, should be multigrid, fft, fft_7pt or full_fft")
+
+    if theory == "fr":
+        half_c2 = fr_half_c2(param)
+        force = derivative_fR(potential, additional_field, half_c2, param["fR_n"], param["gradient_stencil_order"])
+    else:
+        force = derivative(potential, param["gradient_stencil_order"])
+
+    acc = invCIC_vec(force, position) if scheme == "cic" else invTSC_vec(force, position)
+    return acc, potential, additional_field
+
+
+def get_additional_field(additional_field, density, param, tables):  # solver.py:285-378
+    theory = param["theory"].casefold()
+    if theory in ("newton", "parametrized"):
+        return np.empty(0, dtype=np.float32)
+    if theory == "fr":
+        return _fr_additional_field(additional_field, density, param, tables)
+    if theory == "mond":
+        return _mond_additional_field(additional_field, density, param, tables)
+    raise NotImplementedError(f"{param['theory']=}, should be 'newton', 'fr', 'parametrized' or 'mond'")
+
+
+def rhs_poisson_full(density, additional_field, param) -> None:  # solver.py:381-449
+    if param["compute_additional_field"] is False and param["theory"].casefold() == "mond":
+        _mond_rhs(density, additional_field, param)
+    else:
+        rhs_poisson(density, additional_field, param)
+
+
+def _fr_additional_field(*a):  # filled in below once the multigrid oracle exists
+    raise NotImplementedError("f(R) oracle not built yet")
+
+
+def _mond_additional_field(*a):
+    raise NotImplementedError("MOND oracle not built yet")
+
+
+def _mond_rhs(*a):
+    raise NotImplementedError("MOND oracle not built yet")
+
+
+def initialise_potential(*a):
+    raise NotImplementedError("multigrid oracle not built yet")
+
+
+def mg_linear(*a):
+    raise NotImplementedError("multigrid oracle not built yet")
+
+
+def fr_half_c2(param):  # solver.py:167-179
+    c = 299792458.0
+    Rbar = 3 * param["Om_m"] * param["aexp"] ** (-3) + 12 * param["Om_lambda"]
+    Rbar0 = 3 * param["Om_m"] + 12 * param["Om_lambda"]
+    fR_a = -param["aexp"] ** 2 * ((Rbar0 / Rbar) ** (param["fR_n"] + 1)) * 10.0 ** (-param["fR_logfR0"])
+    return np.float32(0.5 * (-fR_a) * (c * 1e-3 * param["unit_t"] / (param["unit_l"] * param["aexp"])) ** 2)
+
+
+def dt_CFL_maxacc(acceleration, param):  # integration.py:267-295
+    dx = np.float32(0.5 ** param["ncoarse"])
+    return np.float32(param["Courant_factor"]) * np.sqrt(dx / max_abs(acceleration))
+
+
+def dt_CFL_maxvel(velocity, param):  # integration.py:298-326
+    dx = np.float32(0.5 ** param["ncoarse"])
+    return np.float32(param["Courant_factor"]) * dx / max_abs(velocity)
+
+
+def dt_weak_variation(func_t_a, param):  # integration.py:329-358
+    aexp_factor = 1.0 + 0.01 * param["max_aexp_stepping"]
+    return np.float32(func_t_a(np.log(aexp_factor * param["aexp"])) - func_t_a(np.log(param["aexp"])))
+
+
+def integrate(position, velocity, acceleration, potential, additional_field, tables, param,
+              t_snap_next=np.float32(0)):  # integration.py:17-118
+    dt1 = dt_CFL_maxacc(acceleration, param)
+    dt2 = dt_CFL_maxvel(velocity, param)
+    dt3 = dt_weak_variation(tables[1], param)
+    dt = np.min([dt1, dt2, dt3])
+    if (param["t"] + dt) > t_snap_next:
+        dt = t_snap_next - param["t"]
+        param["write_snapshot"] = True
+    else:
+        param["write_snapshot"] = False
+    integ = param["integrator"].casefold()
+    if integ == "leapfrog":  # integration.py:192-264
+        half_dt = np.float32(0.5 * dt)
+        add_vector_scalar_inplace(velocity, acceleration, -half_dt)
+        add_vector_scalar_inplace(position, velocity, dt)
+        param["t"] += dt
+        param["aexp_old"] = param["aexp"]
+        param["aexp"] = np.exp(tables[0](param["t"]))
+        set_units(param)
+        periodic_wrap(position)
+        acceleration, potential, additional_field = pm(position, param, potential, additional_field, tables)
+        add_vector_scalar_inplace(velocity, acceleration, -half_dt)
+    elif integ == "euler":  # integration.py:121-189
+        add_vector_scalar_inplace(position, velocity, dt)
+        param["t"] += dt
+        param["aexp_old"] = param["aexp"]
+        param["aexp"] = np.exp(tables[0](param["t"]))
+        set_units(param)
+        periodic_wrap(position)
+        add_vector_scalar_inplace(velocity, acceleration, -dt)
+        acceleration, potential, additional_field = pm(position, param, potential, additional_field, tables)
+    else:
+        raise NotImplementedError("ERROR: Integrator must be 'leapfrog' or 'euler'")
+    return position, velocity, acceleration, potential, additional_field

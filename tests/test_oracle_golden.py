@@ -1,0 +1,158 @@
+"""Pins the CPU oracle (oracle/) against golden vectors captured from the reference source
+(oracle/gen_golden.py).  CPU-only; runs everywhere."""
+import numpy as np
+import pytest
+
+from oracle import pysco_oracle as orc
+
+DEPOSIT_SETS = ["uniform_n16", "lattice_n16", "edge_n16", "cluster_n16", "uniform_n32", "lattice_n32"]
+
+
+@pytest.mark.parametrize("tag", DEPOSIT_SETS)
+def test_deposit_bit_exact(golden, tag):
+    g = golden("deposit_" + tag)
+    pos, n = g["pos"], int(g["n"])
+    # interpreted TSC == TSC_seq (same summation order when run serially)
+    np.testing.assert_array_equal(g["tsc"], g["tsc_seq"])
+    # CIC/NGP: bit-exact.  TSC: the interpreter evaluates `dx**2` through numpy's scalar powf, which
+    # differs from dx*dx (what Numba/LLVM compiles, and what the oracle does) by 1 ulp in ~0.2 % of
+    # cases -> a few-ulp tolerance on the weights, far below any index/weight error (>= 1e-2).
+    np.testing.assert_allclose(orc.TSC(pos, n), g["tsc"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(orc.CIC(pos, n), g["cic"])
+    np.testing.assert_array_equal(orc.NGP(pos, n), g["ngp"])
+    assert abs(float(orc.TSC(pos, n).sum(dtype=np.float64)) - pos.shape[0]) < 1e-3 * pos.shape[0]
+
+
+@pytest.mark.parametrize("tag", DEPOSIT_SETS)
+def test_gather_bit_exact(golden, tag):
+    g = golden("deposit_" + tag)
+    pos, F, S = g["pos"], g["F"], g["S"]
+    np.testing.assert_allclose(orc.invTSC_vec(F, pos), g["inv_tsc_vec"], rtol=0, atol=2e-6)  # `**2`, see above
+    np.testing.assert_array_equal(orc.invCIC_vec(F, pos), g["inv_cic_vec"])
+    np.testing.assert_array_equal(orc.invNGP_vec(F, pos), g["inv_ngp_vec"])
+    np.testing.assert_allclose(orc.invTSC(S, pos), g["inv_tsc"], rtol=0, atol=2e-6)
+
+
+def test_gradient_bit_exact(golden):
+    g = golden("gradient_n16")
+    a, b, f = g["a"], g["b"], np.float32(g["f"])
+    for order in (2, 3, 5, 7):
+        np.testing.assert_array_equal(orc.derivative(a, order), g[f"d{order}"])
+        # b**2 / b**3 go through numpy's scalar powf in the interpreter (1-ulp differences)
+        np.testing.assert_allclose(orc.derivative_fR(a, b, f, 1, order), g[f"d{order}_fr1"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(orc.derivative_fR(a, b, f, 2, order), g[f"d{order}_fr2"], rtol=0, atol=2e-5)
+    with pytest.raises(ValueError):
+        orc.derivative(a, 4)
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_kspace(golden, n):
+    g = golden(f"kspace_n{n}")
+    xk = g["xk"]
+    np.testing.assert_array_equal(orc.fft_3D_real(g["x"]), xk)
+    np.testing.assert_array_equal(orc.ifft_3D_real(xk.copy()), g["ifft_xk"])
+    for name, fn in (("plain", orc.inverse_laplacian),
+                     ("comp2", lambda a: orc.inverse_laplacian_compensated(a, 2)),
+                     ("comp3", lambda a: orc.inverse_laplacian_compensated(a, 3)),
+                     ("sevenpt", orc.inverse_laplacian_7pt)):
+        a = xk.copy()
+        fn(a)
+        ref = g["green_" + name]
+        assert a[0, 0, 0] == 0 and ref[0, 0, 0] == 0
+        # fp32 sinc/sin/pow differ by a few ulp between libm and numpy's SIMD loops
+        np.testing.assert_allclose(a, ref, rtol=3e-6, atol=0)
+    for p in (0, 2, 3):
+        a = xk.copy()
+        k, pk, nm = orc.fourier_grid_to_Pk(a, p)
+        assert a[0, 0, 0] == 0
+        np.testing.assert_array_equal(nm, g[f"pk{p}_nmodes"])
+        np.testing.assert_allclose(k, g[f"pk{p}_k"], rtol=2e-6)
+        np.testing.assert_allclose(pk, g[f"pk{p}_pk"], rtol=1e-5)
+
+
+def test_utils(golden):
+    g = golden("utils")
+    x, y0 = g["x"], g["y0"]
+    for tag in ("p1", "m1", "gen"):
+        y = y0.copy()
+        orc.add_vector_scalar_inplace(y, x, np.float32(g["axpy_" + tag + "_a"]))
+        np.testing.assert_array_equal(y, g["axpy_" + tag])
+    y = y0.copy()
+    orc.prod_vector_scalar_inplace(y, np.float32(1.7))
+    np.testing.assert_array_equal(y, g["scale"])
+    np.testing.assert_array_equal(orc.linear_operator(x, np.float32(0.193), np.float32(-0.193)), g["linop"])
+    y = y0.copy()
+    orc.linear_operator_vectors_inplace(y, np.float32(0.3), x, np.float32(-1.2))
+    np.testing.assert_array_equal(y, g["linop_vec"])
+    assert orc.max_abs(x) == g["max_abs"]
+    w = g["wrap_in"].copy()
+    orc.periodic_wrap(w)
+    np.testing.assert_array_equal(w, g["wrap_out"])
+    assert (w >= 0).all() and (w < 1).all()
+    np.testing.assert_array_equal(orc.positions_to_keys(g["morton_pos"]), g["morton_keys"])
+    p2, v2 = orc.reorder_particles(g["morton_pos"], g["morton_vel"])
+    # np.argsort's default quicksort is not stable: compare sorted keys and the (key,pos,vel) multiset
+    k_ref = orc.positions_to_keys(g["reorder_pos"])
+    assert (np.diff(k_ref) >= 0).all()
+    np.testing.assert_array_equal(orc.positions_to_keys(p2), k_ref)
+    if len(np.unique(k_ref)) == len(k_ref):
+        np.testing.assert_array_equal(p2, g["reorder_pos"])
+        np.testing.assert_array_equal(v2, g["reorder_vel"])
+
+
+PM_NEWTON = ["fft_tsc_o5", "fft_cic_o3", "fft7pt_tsc_o2", "fft_tsc_o7", "fft_tsc_o5_np5000_n16"]
+
+
+def _scale(x):
+    return float(np.abs(x).max())
+
+
+@pytest.mark.parametrize("tag", PM_NEWTON)
+def test_pm_newton(golden, tag):
+    from tests.helpers import param_from_json, synth_tables
+
+    g = golden("pm_newton_" + tag)
+    param = param_from_json(g["param_json"])
+    acc, pot, extra = orc.pm(g["pos"], param, tables=synth_tables())
+    assert extra.size == 0 and g["extra"].size == 0
+    np.testing.assert_allclose(pot, g["pot"], rtol=0, atol=2e-6 * _scale(g["pot"]))
+    np.testing.assert_allclose(acc, g["acc"], rtol=0, atol=1e-5 * _scale(g["acc"]))
+    for key in ("MAS_index", "save_pk", "compute_additional_field"):
+        assert param[key] == param_from_json(g["param_json"])[key]
+
+
+def test_pm_pk(golden):
+    from tests.helpers import param_from_json, synth_tables
+
+    g = golden("pm_newton_pk")
+    param = param_from_json(g["param_json"])
+    out = []
+    orc.pm(g["pos"], param, tables=synth_tables(), pk_out=out)
+    k, pk, nm = out[0]
+    ref = g["pk_table"]
+    np.testing.assert_allclose(k, ref[:, 0], rtol=2e-6)
+    np.testing.assert_allclose(pk, ref[:, 1], rtol=1e-4)  # BASELINE.md parity bar for P(k)
+    np.testing.assert_array_equal(nm, ref[:, 2])
+
+
+@pytest.mark.parametrize("integ,nsteps", [("leapfrog", 10), ("euler", 3)])
+def test_integrate(golden, integ, nsteps):
+    from tests.helpers import param_from_json, synth_tables
+
+    g = golden("integrate_" + integ)
+    tables = synth_tables()
+    param = param_from_json(g["param0_json"])
+    p, v = g["pos0"].copy(), g["vel0"].copy()
+    acc, pot, extra = orc.pm(p, dict(param), tables=tables)
+    np.testing.assert_allclose(acc, g["acc0"], rtol=0, atol=1e-5 * _scale(g["acc0"]))
+    t_next = np.float32(g["t_snap_next"])
+    for s in range(nsteps):
+        p, v, acc, pot, extra = orc.integrate(p, v, acc, pot, extra, tables, param, t_next)
+        assert abs(param["t"] - g["t"][s]) < 1e-6
+        assert abs(param["aexp"] - g["aexp"][s]) < 1e-6
+        assert bool(param["write_snapshot"]) == bool(g["write_snapshot"][s])
+        if s in (0, nsteps - 1):
+            d = np.abs(p - g[f"pos_{s+1}"])
+            d = np.minimum(d, 1 - d)
+            assert d.max() <= 1e-5  # positions after 10 steps max |dx| <= 1e-5 box units
+            np.testing.assert_allclose(v, g[f"vel_{s+1}"], rtol=0, atol=1e-5 * _scale(g[f"vel_{s+1}"]))
