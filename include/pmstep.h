@@ -1,0 +1,110 @@
+/*
+ * pmstep.h -- C ABI of libpmstep.so, the MI355X (gfx950) particle-mesh stepper.
+ *
+ * Drop-in boundary for PySCo's per-step hot path.  PySCo has no FFI of its own: its "native"
+ * layer is Numba-jitted Python, so each entry point below names the Python function
+ * (file:line under pysco/) whose body it replaces.  INTEGRATION.md shows the ctypes stubs a
+ * PySCo maintainer would add to call these from mesh.py / fourier.py / utils.py / solver.py.
+ *
+ * Conventions
+ *  - every pointer named d_* is a DEVICE pointer (hipMalloc'd by the caller, e.g. a torch tensor's
+ *    data_ptr()); h_* are host pointers.  No ownership is transferred; nothing is retained
+ *    after the call returns except inside pm_ctx.
+ *  - all grids are C-contiguous fp32 [n,n,n] (k fastest), vector grids [n,n,n,3] (AoS, as
+ *    mesh.derivative returns), particle arrays [np,3] fp32, half-spectra [n,n,n/2+1] complex64.
+ *  - n is a power of two >= 4 (2**ncoarse, solver.py:75); cell indices fit int16 in the reference
+ *    (mesh.py:2506) so n <= 16384 here.
+ *  - launches are asynchronous on the context's stream unless the function returns a host value.
+ *  - return value: 0 on success, negative on error (pm_last_error() gives the text):
+ *      -1 invalid argument, -2 HIP runtime error, -3 rocFFT error, -4 unsupported.
+ */
+#ifndef PMSTEP_H
+#define PMSTEP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pm_ctx pm_ctx;
+
+/* mass-assignment schemes: values are the reference's MAS_index (solver.py:82,85) */
+enum { PM_NGP = 1, PM_CIC = 2, PM_TSC = 3 };
+/* k-space Green's functions (fourier.py:460, 502, 555) */
+enum { PM_GREEN_PLAIN = 0, PM_GREEN_COMPENSATED = 1, PM_GREEN_7PT = 2 };
+
+int pm_version(void);
+const char *pm_last_error(void);
+
+/* Context: grid size, stream, rocFFT plans + work buffer, small device scratch.  `stream` is a
+ * hipStream_t (NULL = default stream).  One context per (process, grid size). */
+int pm_ctx_create(pm_ctx **out, int n, void *stream);
+int pm_ctx_destroy(pm_ctx *ctx);
+int pm_ctx_set_stream(pm_ctx *ctx, void *stream);
+int pm_ctx_sync(pm_ctx *ctx);
+/* Device-side timing on the context's stream (hipEvent); used by bench.py for the roofline. */
+int pm_timer_start(pm_ctx *ctx);
+int pm_timer_stop_ms(pm_ctx *ctx, float *h_ms); /* synchronises */
+
+/* ---- mesh.py ------------------------------------------------------------------------------ */
+/* mesh.NGP :2240 / mesh.CIC :2284 / mesh.TSC :2468 (and TSC_seq :2363): d_rho is overwritten.
+ * `sorted_hint` != 0 selects the LDS-tiled kernel that is fast when consecutive particles are
+ * spatially close (Morton-sorted streams); the result does not depend on it. */
+int pm_deposit(pm_ctx *ctx, int scheme, const float *d_pos, int64_t np, float *d_rho, int sorted_hint);
+/* mesh.invNGP_vec :2639 / invCIC_vec :2752 / invTSC_vec :2960  (ncomp = 3, grid [n,n,n,3])
+ * mesh.invNGP :2600 / invCIC :2679 / invTSC :2827             (ncomp = 1, grid [n,n,n])      */
+int pm_interp(pm_ctx *ctx, int scheme, int ncomp, const float *d_grid, const float *d_pos, int64_t np,
+              float *d_out);
+/* mesh.derivative :2072 -> derivative2/3/5/7 :639-850.  d_force [n,n,n,3] = +grad(phi). */
+int pm_gradient(pm_ctx *ctx, int order, const float *d_phi, float *d_force);
+/* mesh.derivative_fR :2112 -> derivativeK_fR_n1/n2 :860-2069: grad(phi) + f*grad(u**(fr_n+1)). */
+int pm_gradient_fr(pm_ctx *ctx, int order, int fr_n, float f, const float *d_phi, const float *d_u,
+                   float *d_force);
+
+/* ---- utils.py ----------------------------------------------------------------------------- */
+int pm_axpy(pm_ctx *ctx, float *d_y, const float *d_x, float a, int64_t count);              /* :264 */
+int pm_scale(pm_ctx *ctx, float *d_y, float a, int64_t count);                                /* :410 */
+int pm_linear_operator(pm_ctx *ctx, float *d_out, const float *d_x, float f1, float f2,
+                       int64_t count);                                                        /* :644, :684 */
+int pm_linear_operator_vectors(pm_ctx *ctx, float *d_x, float f1, const float *d_y, float f2,
+                               int64_t count);                                                /* :721 */
+int pm_max_abs(pm_ctx *ctx, const float *d_x, int64_t count, float *h_out);                   /* :220 (syncs) */
+int pm_periodic_wrap(pm_ctx *ctx, float *d_pos, int64_t count);                               /* :1120 */
+/* morton.positions_to_keys morton.py:113 */
+int pm_morton_keys(pm_ctx *ctx, const float *d_pos, int64_t np, int64_t *d_keys);
+/* utils.reorder_particles :1019: stable radix sort by Morton key, then gather of up to three
+ * [np,3] arrays (d_vel/d_acc and their outputs may be NULL).  d_perm (int64[np], may be NULL)
+ * receives the permutation (out[i] = in[perm[i]]). */
+int pm_reorder_particles(pm_ctx *ctx, int64_t np, const float *d_pos, const float *d_vel, const float *d_acc,
+                         float *d_pos_out, float *d_vel_out, float *d_acc_out, int64_t *d_perm);
+
+/* ---- fourier.py --------------------------------------------------------------------------- */
+/* fft_3D_real :104 (unnormalised r2c) and ifft_3D_real :251 (c2r carrying 1/n^3).
+ * d_xk is float2[n*n*(n/2+1)].  pm_fft_c2r may overwrite d_xk. */
+int pm_fft_r2c(pm_ctx *ctx, const float *d_x, void *d_xk);
+int pm_fft_c2r(pm_ctx *ctx, void *d_xk, float *d_x);
+/* inverse_laplacian :460 / _compensated(p) :502 / _7pt :555, in place on d_xk.
+ * h_k2 and h_s are the per-axis fp32 tables (length n) the host builds with the reference's own
+ * expressions: k2[i] = k_i**2 and s[i] = sinc(k_i/n) (compensated) or sin(pi k_i/n)**2 (7pt). */
+int pm_greens(pm_ctx *ctx, int kind, int p, void *d_xk, const float *h_k2, const float *h_s, float c0);
+/* fourier_grid_to_Pk :22-100: bins |k| into int(|k|+0.5), deconvolves sinc^p, also zeroes
+ * d_xk[0,0,0].  Outputs are host arrays of length n: per-bin sums of |k|, |delta_k|^2, counts
+ * (the caller slices [1:kmax] and divides, as :94-99). */
+int pm_pk(pm_ctx *ctx, int p, void *d_xk, const float *h_sinc, double *h_ksum, double *h_pksum,
+          double *h_nmodes);
+
+/* ---- fused step pieces (integration.py:192-264, solver.py:453-522) ---------------------------- */
+/* solver.fft :453 without the P(k) branch: r2c -> Green's function -> c2r.  d_rhs is preserved
+ * unless d_phi == d_rhs. */
+int pm_poisson_fft(pm_ctx *ctx, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
+                   const float *h_s, float c0);
+/* leapfrog first half, integration.py:250-258: v += -half_dt*a ; x += dt*v ; periodic_wrap(x) */
+int pm_kick_drift_wrap(pm_ctx *ctx, float *d_pos, float *d_vel, const float *d_acc, float half_dt, float dt,
+                       int64_t np);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMSTEP_H */

@@ -1,0 +1,176 @@
+"""ctypes binding of libpmstep.so (include/pmstep.h) and the device-array plumbing.
+
+There is deliberately NO CPU fallback: if the HIP library is missing or no GPU is visible, the
+first compute call raises.  PyTorch is used only to own device memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpmstep.so")
+
+NGP, CIC, TSC = 1, 2, 3
+GREEN_PLAIN, GREEN_COMPENSATED, GREEN_7PT = 0, 1, 2
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_f = C.c_float
+_i = C.c_int
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+SIGNATURES: Dict[str, tuple] = {
+    "pm_version": (),
+    "pm_last_error": (),
+    "pm_ctx_create": (C.POINTER(_vp), _i, _vp),
+    "pm_ctx_destroy": (_vp,),
+    "pm_ctx_set_stream": (_vp, _vp),
+    "pm_ctx_sync": (_vp,),
+    "pm_timer_start": (_vp,),
+    "pm_timer_stop_ms": (_vp, C.POINTER(_f)),
+    "pm_deposit": (_vp, _i, _vp, _i64, _vp, _i),
+    "pm_interp": (_vp, _i, _i, _vp, _vp, _i64, _vp),
+    "pm_gradient": (_vp, _i, _vp, _vp),
+    "pm_gradient_fr": (_vp, _i, _i, _f, _vp, _vp, _vp),
+    "pm_axpy": (_vp, _vp, _vp, _f, _i64),
+    "pm_scale": (_vp, _vp, _f, _i64),
+    "pm_linear_operator": (_vp, _vp, _vp, _f, _f, _i64),
+    "pm_linear_operator_vectors": (_vp, _vp, _f, _vp, _f, _i64),
+    "pm_max_abs": (_vp, _vp, _i64, C.POINTER(_f)),
+    "pm_periodic_wrap": (_vp, _vp, _i64),
+    "pm_morton_keys": (_vp, _vp, _i64, _vp),
+    "pm_reorder_particles": (_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp),
+    "pm_fft_r2c": (_vp, _vp, _vp),
+    "pm_fft_c2r": (_vp, _vp, _vp),
+    "pm_greens": (_vp, _i, _i, _vp, _vp, _vp, _f),
+    "pm_pk": (_vp, _i, _vp, _vp, _vp, _vp, _vp),
+    "pm_poisson_fft": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),
+    "pm_kick_drift_wrap": (_vp, _vp, _vp, _vp, _f, _f, _i64),
+}
+_RESTYPES = {"pm_last_error": C.c_char_p}
+
+_lib = None
+
+
+class PMStepError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libpmstep.so and attach signatures.  Works without a GPU (symbols only)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP extension first (python -m pysco_amd.build). "
+                "pysco_amd has no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+            fn.argtypes = list(argtypes)
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load_library().pm_last_error()
+        raise PMStepError(f"libpmstep error {rc}: {msg.decode() if msg else '?'}")
+
+
+# ------------------------------------------------------------------------------------------------
+# device plumbing
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise PMStepError("pysco_amd needs an MI355X (no HIP device visible); there is no CPU fallback")
+    return torch
+
+
+_ctxs: Dict[Tuple[int, int], "Context"] = {}
+
+
+class Context:
+    """pm_ctx for one (device, grid size)."""
+
+    def __init__(self, n: int):
+        torch = require_gpu()
+        self.lib = load_library()
+        self.n = int(n)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.handle = _vp()
+        stream = torch.cuda.current_stream().cuda_stream
+        check(self.lib.pm_ctx_create(C.byref(self.handle), self.n, _vp(stream)))
+        self._stream = stream
+
+    def use_current_stream(self):
+        stream = _torch().cuda.current_stream().cuda_stream
+        if stream != self._stream:
+            check(self.lib.pm_ctx_set_stream(self.handle, _vp(stream)))
+            self._stream = stream
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.pm_ctx_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def context(n: int) -> Context:
+    torch = require_gpu()
+    key = (torch.cuda.current_device(), int(n))
+    ctx = _ctxs.get(key)
+    if ctx is None:
+        ctx = _ctxs[key] = Context(n)
+    ctx.use_current_stream()
+    return ctx
+
+
+def is_device_array(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def to_device(x, dtype=None):
+    """numpy array or torch tensor -> contiguous CUDA tensor (no copy if already one)."""
+    torch = require_gpu()
+    if is_device_array(x):
+        if not x.is_cuda:
+            x = x.cuda()
+        if dtype is not None and x.dtype != dtype:
+            x = x.to(dtype)
+        return x.contiguous()
+    a = np.ascontiguousarray(x)
+    t = torch.from_numpy(a).cuda()
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t
+
+
+def like_input(t, template):
+    """Return `t` (a CUDA tensor) in the same kind as `template` (numpy in -> numpy out)."""
+    if is_device_array(template):
+        return t
+    return t.cpu().numpy()
+
+
+def ptr(t) -> _vp:
+    return _vp(t.data_ptr()) if t is not None else _vp(None)
+
+
+def hptr(a: np.ndarray) -> _vp:
+    return a.ctypes.data_as(_vp)

@@ -1,0 +1,147 @@
+// Context, error reporting, rocFFT plans (fourier.py:104-147, 251-294 replaced by persistent plans).
+#include <cstring>
+#include <mutex>
+
+#include "pm_common.h"
+
+static thread_local char g_err[512] = "";
+
+void pm_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *pm_last_error(void) { return g_err; }
+extern "C" int pm_version(void) { return 100; }
+
+static std::once_flag g_fft_once;
+
+static int build_plans(pm_ctx *c) {
+    if (c->plan_r2c) return PM_OK;
+    std::call_once(g_fft_once, [] { rocfft_setup(); });
+    const size_t len[3] = {(size_t)c->n, (size_t)c->n, (size_t)c->n};  // fastest first
+    PM_FFT(rocfft_plan_create(&c->plan_r2c, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                              rocfft_precision_single, 3, len, 1, nullptr));
+    rocfft_plan_description d = nullptr;
+    PM_FFT(rocfft_plan_description_create(&d));
+    // ifft_3D_real carries 1/n^3 (PyFFTW normalise_idft / np.fft.irfftn, fourier.py:277)
+    PM_FFT(rocfft_plan_description_set_scale_factor(d, 1.0 / ((double)c->n * c->n * c->n)));
+    PM_FFT(rocfft_plan_create(&c->plan_c2r, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                              rocfft_precision_single, 3, len, 1, d));
+    PM_FFT(rocfft_plan_description_destroy(d));
+    size_t w1 = 0, w2 = 0;
+    PM_FFT(rocfft_plan_get_work_buffer_size(c->plan_r2c, &w1));
+    PM_FFT(rocfft_plan_get_work_buffer_size(c->plan_c2r, &w2));
+    c->fft_work_bytes = w1 > w2 ? w1 : w2;
+    if (c->fft_work_bytes) PM_HIP(hipMalloc(&c->fft_work, c->fft_work_bytes));
+    PM_FFT(rocfft_execution_info_create(&c->info_r2c));
+    PM_FFT(rocfft_execution_info_create(&c->info_c2r));
+    if (c->fft_work_bytes) {
+        PM_FFT(rocfft_execution_info_set_work_buffer(c->info_r2c, c->fft_work, c->fft_work_bytes));
+        PM_FFT(rocfft_execution_info_set_work_buffer(c->info_c2r, c->fft_work, c->fft_work_bytes));
+    }
+    PM_FFT(rocfft_execution_info_set_stream(c->info_r2c, c->stream));
+    PM_FFT(rocfft_execution_info_set_stream(c->info_c2r, c->stream));
+    return PM_OK;
+}
+
+extern "C" int pm_ctx_create(pm_ctx **out, int n, void *stream) {
+    PM_REQUIRE(out != nullptr, "out is NULL");
+    PM_REQUIRE(n >= 4 && n <= 16384 && (n & (n - 1)) == 0, "n must be a power of two in [4, 16384]");
+    pm_ctx *c = new pm_ctx();
+    memset(c, 0, sizeof(*c));
+    c->n = n;
+    c->log2n = __builtin_ctz((unsigned)n);
+    c->stream = (hipStream_t)stream;
+    PM_HIP(hipMalloc((void **)&c->d_scratch, 64 * sizeof(unsigned)));
+    PM_HIP(hipMemset(c->d_scratch, 0, 64 * sizeof(unsigned)));
+    PM_HIP(hipMalloc((void **)&c->d_tab, 3 * (size_t)n * sizeof(float)));
+    PM_HIP(hipMalloc((void **)&c->d_hist, 3 * (size_t)n * sizeof(double)));
+    PM_HIP(hipEventCreate(&c->ev0));
+    PM_HIP(hipEventCreate(&c->ev1));
+    *out = c;
+    return PM_OK;
+}
+
+extern "C" int pm_ctx_destroy(pm_ctx *c) {
+    if (!c) return PM_OK;
+    hipStreamSynchronize(c->stream);
+    if (c->plan_r2c) rocfft_plan_destroy(c->plan_r2c);
+    if (c->plan_c2r) rocfft_plan_destroy(c->plan_c2r);
+    if (c->info_r2c) rocfft_execution_info_destroy(c->info_r2c);
+    if (c->info_c2r) rocfft_execution_info_destroy(c->info_c2r);
+    if (c->fft_work) hipFree(c->fft_work);
+    if (c->d_spec) hipFree(c->d_spec);
+    if (c->sort_tmp) hipFree(c->sort_tmp);
+    hipFree(c->d_scratch);
+    hipFree(c->d_tab);
+    hipFree(c->d_hist);
+    hipEventDestroy(c->ev0);
+    hipEventDestroy(c->ev1);
+    delete c;
+    return PM_OK;
+}
+
+extern "C" int pm_ctx_set_stream(pm_ctx *c, void *stream) {
+    PM_REQUIRE(c != nullptr, "ctx is NULL");
+    c->stream = (hipStream_t)stream;
+    if (c->info_r2c) {
+        PM_FFT(rocfft_execution_info_set_stream(c->info_r2c, c->stream));
+        PM_FFT(rocfft_execution_info_set_stream(c->info_c2r, c->stream));
+    }
+    return PM_OK;
+}
+
+extern "C" int pm_ctx_sync(pm_ctx *c) {
+    PM_REQUIRE(c != nullptr, "ctx is NULL");
+    PM_HIP(hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+extern "C" int pm_timer_start(pm_ctx *c) {
+    PM_REQUIRE(c != nullptr, "ctx is NULL");
+    PM_HIP(hipEventRecord(c->ev0, c->stream));
+    return PM_OK;
+}
+
+extern "C" int pm_timer_stop_ms(pm_ctx *c, float *h_ms) {
+    PM_REQUIRE(c != nullptr && h_ms != nullptr, "NULL argument");
+    PM_HIP(hipEventRecord(c->ev1, c->stream));
+    PM_HIP(hipEventSynchronize(c->ev1));
+    PM_HIP(hipEventElapsedTime(h_ms, c->ev0, c->ev1));
+    return PM_OK;
+}
+
+extern "C" int pm_fft_r2c(pm_ctx *c, const float *d_x, void *d_xk) {
+    PM_REQUIRE(c && d_x && d_xk, "NULL argument");
+    int rc = build_plans(c);
+    if (rc) return rc;
+    void *in[1] = {const_cast<float *>(d_x)};
+    void *out[1] = {d_xk};
+    PM_FFT(rocfft_execute(c->plan_r2c, in, out, c->info_r2c));
+    return PM_OK;
+}
+
+extern "C" int pm_fft_c2r(pm_ctx *c, void *d_xk, float *d_x) {
+    PM_REQUIRE(c && d_x && d_xk, "NULL argument");
+    int rc = build_plans(c);
+    if (rc) return rc;
+    void *in[1] = {d_xk};
+    void *out[1] = {d_x};
+    PM_FFT(rocfft_execute(c->plan_c2r, in, out, c->info_c2r));
+    return PM_OK;
+}
+
+extern "C" int pm_poisson_fft(pm_ctx *c, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
+                              const float *h_s, float c0) {
+    PM_REQUIRE(c && d_rhs && d_phi, "NULL argument");
+    const size_t nspec = (size_t)c->n * c->n * (c->n / 2 + 1);
+    if (!c->d_spec) PM_HIP(hipMalloc(&c->d_spec, nspec * 2 * sizeof(float)));
+    int rc = pm_fft_r2c(c, d_rhs, c->d_spec);
+    if (rc) return rc;
+    rc = pm_greens(c, kind, p, c->d_spec, h_k2, h_s, c0);
+    if (rc) return rc;
+    return pm_fft_c2r(c, c->d_spec, d_phi);
+}

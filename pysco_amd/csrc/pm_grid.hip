@@ -1,0 +1,479 @@
+// Streaming grid / vector kernels: utils.py element-wise ops and reductions, mesh.py gradients,
+// fourier.py Green's functions and the P(k) estimator.  All HBM-bound: 16 B per lane, grid-stride.
+// Built with -ffp-contract=off so a*x+y keeps the reference's two roundings (bit-exact vs oracle).
+#include "pm_common.h"
+
+#define BLK 256
+
+// ------------------------------------------------------------------------------------------------
+// element-wise (utils.py:264-298, 410-430, 644-755, 1120-1149)
+
+enum { OP_AXPY = 0, OP_ADD, OP_SUB, OP_SCALE, OP_LINOP, OP_LINOPV, OP_WRAP };
+
+template <int OP>
+__device__ __forceinline__ float ew_apply(float y, float x, float a, float b) {
+    if (OP == OP_AXPY) return y + a * x;          // y += a*x
+    if (OP == OP_ADD) return y + x;               // a == 1 special case (utils.py:289)
+    if (OP == OP_SUB) return y - x;               // a == -1 special case (utils.py:292)
+    if (OP == OP_SCALE) return y * a;             // y *= a
+    if (OP == OP_LINOP) return a * x + b;         // out = f1*x + f2
+    if (OP == OP_LINOPV) return a * y + b * x;    // x = f1*x + f2*y   (y arg = mutable, x arg = other)
+    if (OP == OP_WRAP) {                          // periodic_wrap; eps = -(2^-25)*(1+1e-6) as a double
+        const double eps = -(1.0 / 33554432.0) * (1.0 + 1e-6);
+        if (y < 0.0f) return ((double)y > eps) ? 0.0f : y + 1.0f;
+        if (y >= 1.0f) return y - 1.0f;
+        return y;
+    }
+    return y;
+}
+
+// out[i] = f(out_or_y[i], x[i]).  `y` is read only for ops that use it.
+template <int OP, bool READ_Y, bool READ_X>
+__global__ __launch_bounds__(BLK) void ew_kernel(float *__restrict__ out, const float *__restrict__ x, float a,
+                                                 float b, int64_t count, int vec_ok) {
+    const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * BLK;
+    if (vec_ok) {
+        const int64_t n4 = count >> 2;
+        float4 *o4 = reinterpret_cast<float4 *>(out);
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        for (int64_t i = tid; i < n4; i += nthreads) {
+            float4 yv = READ_Y ? o4[i] : make_float4(0, 0, 0, 0);
+            float4 xv = READ_X ? x4[i] : make_float4(0, 0, 0, 0);
+            float4 r;
+            r.x = ew_apply<OP>(yv.x, xv.x, a, b);
+            r.y = ew_apply<OP>(yv.y, xv.y, a, b);
+            r.z = ew_apply<OP>(yv.z, xv.z, a, b);
+            r.w = ew_apply<OP>(yv.w, xv.w, a, b);
+            o4[i] = r;
+        }
+        for (int64_t i = (n4 << 2) + tid; i < count; i += nthreads)
+            out[i] = ew_apply<OP>(READ_Y ? out[i] : 0.f, READ_X ? x[i] : 0.f, a, b);
+    } else {
+        for (int64_t i = tid; i < count; i += nthreads)
+            out[i] = ew_apply<OP>(READ_Y ? out[i] : 0.f, READ_X ? x[i] : 0.f, a, b);
+    }
+}
+
+template <int OP, bool RY, bool RX>
+static int ew_launch(pm_ctx *c, float *out, const float *x, float a, float b, int64_t count) {
+    if (count <= 0) return PM_OK;
+    int vec_ok = pm_aligned16(out) && (!RX || pm_aligned16(x));
+    int blocks = pm_stream_blocks(count, BLK * 4 * 4);
+    hipLaunchKernelGGL((ew_kernel<OP, RY, RX>), dim3(blocks), dim3(BLK), 0, c->stream, out, x, a, b, count, vec_ok);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+extern "C" int pm_axpy(pm_ctx *c, float *d_y, const float *d_x, float a, int64_t count) {
+    PM_REQUIRE(c && d_y && d_x && count >= 0, "bad argument");
+    if (a == 1.0f) return ew_launch<OP_ADD, true, true>(c, d_y, d_x, a, 0.f, count);
+    if (a == -1.0f) return ew_launch<OP_SUB, true, true>(c, d_y, d_x, a, 0.f, count);
+    return ew_launch<OP_AXPY, true, true>(c, d_y, d_x, a, 0.f, count);
+}
+
+extern "C" int pm_scale(pm_ctx *c, float *d_y, float a, int64_t count) {
+    PM_REQUIRE(c && d_y && count >= 0, "bad argument");
+    return ew_launch<OP_SCALE, true, false>(c, d_y, nullptr, a, 0.f, count);
+}
+
+extern "C" int pm_linear_operator(pm_ctx *c, float *d_out, const float *d_x, float f1, float f2, int64_t count) {
+    PM_REQUIRE(c && d_out && d_x && count >= 0, "bad argument");
+    return ew_launch<OP_LINOP, false, true>(c, d_out, d_x, f1, f2, count);
+}
+
+extern "C" int pm_linear_operator_vectors(pm_ctx *c, float *d_x, float f1, const float *d_y, float f2,
+                                          int64_t count) {
+    PM_REQUIRE(c && d_x && d_y && count >= 0, "bad argument");
+    return ew_launch<OP_LINOPV, true, true>(c, d_x, d_y, f1, f2, count);
+}
+
+extern "C" int pm_periodic_wrap(pm_ctx *c, float *d_pos, int64_t count) {
+    PM_REQUIRE(c && d_pos && count >= 0, "bad argument");
+    return ew_launch<OP_WRAP, true, false>(c, d_pos, nullptr, 0.f, 0.f, count);
+}
+
+// leapfrog first half (integration.py:250-258): v += -half_dt*a; x += dt*v; wrap(x).  One pass over
+// the three particle arrays instead of the reference's three (axpy, axpy, wrap).
+__global__ __launch_bounds__(BLK) void kick_drift_wrap_kernel(float *__restrict__ pos, float *__restrict__ vel,
+                                                              const float *__restrict__ acc, float mhalf_dt, float dt,
+                                                              int64_t count, int vec_ok) {
+    const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * BLK;
+    auto one = [&](float &x, float &v, float a) {
+        v = ew_apply<OP_AXPY>(v, a, mhalf_dt, 0.f);
+        x = (dt == 1.0f) ? x + v : ((dt == -1.0f) ? x - v : x + dt * v);
+        x = ew_apply<OP_WRAP>(x, 0.f, 0.f, 0.f);
+    };
+    int64_t start = 0;
+    if (vec_ok) {
+        const int64_t n4 = count >> 2;
+        float4 *p4 = reinterpret_cast<float4 *>(pos);
+        float4 *v4 = reinterpret_cast<float4 *>(vel);
+        const float4 *a4 = reinterpret_cast<const float4 *>(acc);
+        for (int64_t i = tid; i < n4; i += nthreads) {
+            float4 x = p4[i], v = v4[i], a = a4[i];
+            one(x.x, v.x, a.x);
+            one(x.y, v.y, a.y);
+            one(x.z, v.z, a.z);
+            one(x.w, v.w, a.w);
+            v4[i] = v;
+            p4[i] = x;
+        }
+        start = n4 << 2;
+    }
+    for (int64_t i = start + tid; i < count; i += nthreads) {
+        float x = pos[i], v = vel[i];
+        one(x, v, acc[i]);
+        vel[i] = v;
+        pos[i] = x;
+    }
+}
+
+extern "C" int pm_kick_drift_wrap(pm_ctx *c, float *d_pos, float *d_vel, const float *d_acc, float half_dt, float dt,
+                                  int64_t np) {
+    PM_REQUIRE(c && d_pos && d_vel && d_acc && np >= 0, "bad argument");
+    if (np == 0) return PM_OK;
+    PM_REQUIRE(half_dt != 1.0f && half_dt != -1.0f, "half_dt == +-1 not supported by the fused kick");
+    const int64_t count = 3 * np;
+    int vec_ok = pm_aligned16(d_pos) && pm_aligned16(d_vel) && pm_aligned16(d_acc);
+    int blocks = pm_stream_blocks(count, BLK * 4 * 2);
+    hipLaunchKernelGGL(kick_drift_wrap_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_pos, d_vel, d_acc, -half_dt,
+                       dt, count, vec_ok);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// max_abs (utils.py:220): the bit pattern of |x| orders like an unsigned int, and NaN (0x7fc00000)
+// sorts above +inf, so an integer max reproduces np.max(np.abs(x)) including NaN propagation.
+
+__global__ __launch_bounds__(BLK) void max_abs_kernel(const float *__restrict__ x, int64_t count, int vec_ok,
+                                                      unsigned *__restrict__ result) {
+    const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * BLK;
+    unsigned m = 0;
+    int64_t start = 0;
+    if (vec_ok) {
+        const int64_t n4 = count >> 2;
+        const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
+        for (int64_t i = tid; i < n4; i += nthreads) {
+            uint4 v = x4[i];
+            m = max(m, max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+        }
+        start = n4 << 2;
+    }
+    for (int64_t i = start + tid; i < count; i += nthreads) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_down((int)m, off, 64));
+    __shared__ unsigned wmax[BLK / 64];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BLK / 64; ++w) m = max(m, wmax[w]);
+        atomicMax(result, m);
+    }
+}
+
+extern "C" int pm_max_abs(pm_ctx *c, const float *d_x, int64_t count, float *h_out) {
+    PM_REQUIRE(c && d_x && h_out && count > 0, "bad argument");
+    PM_HIP(hipMemsetAsync(c->d_scratch, 0, sizeof(unsigned), c->stream));
+    int blocks = pm_stream_blocks(count, BLK * 4 * 8);
+    hipLaunchKernelGGL(max_abs_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_x, count, (int)pm_aligned16(d_x),
+                       c->d_scratch);
+    PM_LAUNCH_CHECK();
+    unsigned bits = 0;
+    PM_HIP(hipMemcpyAsync(&bits, c->d_scratch, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
+    memcpy(h_out, &bits, sizeof(float));
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradients (mesh.py:639-850 and the f(R) fused variants :860-2069)
+//
+// Thread (tx) owns 4 consecutive k-cells of one (i,j) row: the x/y neighbours are aligned float4
+// loads, the z neighbours come from the three float4 at k-4, k, k+4 (periodic), and the AoS
+// [n,n,n,3] output is three contiguous float4 stores (48 B) per thread.  Consecutive threads walk k
+// then j, so every wave reads and writes whole 1-3 KiB segments.
+
+template <int FRN>
+__device__ __forceinline__ float fr_pow(float b) {
+    return FRN == 1 ? b * b : b * b * b;
+}
+
+template <int ORDER, int FRN>
+struct Stencil {
+    // value of the 1-D stencil given a[-3..3] (and b when FRN>0); operation order as the reference
+    static __device__ __forceinline__ float eval(const float *a, const float *b, float f, float scale) {
+        // a[3] is the centre
+        if (ORDER == 2) {
+            if (FRN == 0) return scale * (-a[3] + a[4]);
+            return scale * (-a[3] + a[4] + f * (-fr_pow<FRN>(b[3]) + fr_pow<FRN>(b[4])));
+        } else if (ORDER == 3) {
+            if (FRN == 0) return scale * (-a[2] + a[4]);
+            return scale * (-a[2] + a[4] + f * (-fr_pow<FRN>(b[2]) + fr_pow<FRN>(b[4])));
+        } else if (ORDER == 5) {
+            if (FRN == 0) return scale * (8.0f * (-a[2] + a[4]) + a[1] - a[5]);
+            return scale * (8.0f * (-a[2] + a[4] + f * (-fr_pow<FRN>(b[2]) + fr_pow<FRN>(b[4]))) + a[1] - a[5] +
+                            f * (fr_pow<FRN>(b[1]) - fr_pow<FRN>(b[5])));
+        } else {
+            if (FRN == 0) return scale * (45.0f * (-a[2] + a[4]) + 9.0f * (a[1] - a[5]) - a[0] + a[6]);
+            return scale * (45.0f * (-a[2] + a[4] + f * (-fr_pow<FRN>(b[2]) + fr_pow<FRN>(b[4]))) +
+                            9.0f * (+a[1] - a[5] + f * (fr_pow<FRN>(b[1]) - fr_pow<FRN>(b[5]))) - a[0] + a[6] +
+                            f * (-fr_pow<FRN>(b[0]) + fr_pow<FRN>(b[6])));
+        }
+    }
+};
+
+template <int ORDER, int FRN>
+__global__ __launch_bounds__(BLK) void gradient_kernel(const float *__restrict__ phi, const float *__restrict__ u,
+                                                       float f, float scale, int n, int log2n,
+                                                       float *__restrict__ out) {
+    constexpr int R = (ORDER == 2) ? 1 : (ORDER == 3 ? 1 : (ORDER == 5 ? 2 : 3));  // stencil reach
+    const int nq = n >> 2;                                                        // float4 per row
+    const int64_t total = (int64_t)n * n * nq;
+    const int mask = n - 1;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int kq = (int)(t % nq);
+        const int64_t ij = t / nq;
+        const int j = (int)(ij & mask);
+        const int i = (int)(ij >> log2n);
+        const int k0 = kq << 2;
+        auto row = [&](const float *g, int ii, int jj) -> const float * {
+            return g + (((int64_t)(ii & mask) << log2n) + (jj & mask)) * n;
+        };
+        // gather lines: x[-R..R], y[-R..R] as float4 at k0; z as 12 floats k0-4..k0+7
+        float ax[7][4], ay[7][4], az[12];
+        float bx[7][4], by[7][4], bz[12];
+#pragma unroll
+        for (int o = -R; o <= R; ++o) {
+            if (ORDER == 2 && o < 0) continue;
+            float4 vx = *reinterpret_cast<const float4 *>(row(phi, i + o, j) + k0);
+            float4 vy = *reinterpret_cast<const float4 *>(row(phi, i, j + o) + k0);
+            ax[o + 3][0] = vx.x, ax[o + 3][1] = vx.y, ax[o + 3][2] = vx.z, ax[o + 3][3] = vx.w;
+            ay[o + 3][0] = vy.x, ay[o + 3][1] = vy.y, ay[o + 3][2] = vy.z, ay[o + 3][3] = vy.w;
+            if (FRN > 0) {
+                float4 wx = *reinterpret_cast<const float4 *>(row(u, i + o, j) + k0);
+                float4 wy = *reinterpret_cast<const float4 *>(row(u, i, j + o) + k0);
+                bx[o + 3][0] = wx.x, bx[o + 3][1] = wx.y, bx[o + 3][2] = wx.z, bx[o + 3][3] = wx.w;
+                by[o + 3][0] = wy.x, by[o + 3][1] = wy.y, by[o + 3][2] = wy.z, by[o + 3][3] = wy.w;
+            }
+        }
+        {
+            const float *r = row(phi, i, j);
+            float4 zl = *reinterpret_cast<const float4 *>(r + ((k0 - 4) & mask));
+            float4 zr = *reinterpret_cast<const float4 *>(r + ((k0 + 4) & mask));
+            az[0] = zl.x, az[1] = zl.y, az[2] = zl.z, az[3] = zl.w;
+            az[4] = ax[3][0], az[5] = ax[3][1], az[6] = ax[3][2], az[7] = ax[3][3];
+            az[8] = zr.x, az[9] = zr.y, az[10] = zr.z, az[11] = zr.w;
+            if (FRN > 0) {
+                const float *ru = row(u, i, j);
+                float4 wl = *reinterpret_cast<const float4 *>(ru + ((k0 - 4) & mask));
+                float4 wr = *reinterpret_cast<const float4 *>(ru + ((k0 + 4) & mask));
+                bz[0] = wl.x, bz[1] = wl.y, bz[2] = wl.z, bz[3] = wl.w;
+                bz[4] = bx[3][0], bz[5] = bx[3][1], bz[6] = bx[3][2], bz[7] = bx[3][3];
+                bz[8] = wr.x, bz[9] = wr.y, bz[10] = wr.z, bz[11] = wr.w;
+            }
+        }
+        float res[12];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float sa[7], sb[7];
+#pragma unroll
+            for (int o = 0; o < 7; ++o) sa[o] = ax[o][c], sb[o] = (FRN > 0) ? bx[o][c] : 0.f;
+            res[3 * c + 0] = Stencil<ORDER, FRN>::eval(sa, sb, f, scale);
+#pragma unroll
+            for (int o = 0; o < 7; ++o) sa[o] = ay[o][c], sb[o] = (FRN > 0) ? by[o][c] : 0.f;
+            res[3 * c + 1] = Stencil<ORDER, FRN>::eval(sa, sb, f, scale);
+#pragma unroll
+            for (int o = 0; o < 7; ++o) sa[o] = az[4 + c + o - 3], sb[o] = (FRN > 0) ? bz[4 + c + o - 3] : 0.f;
+            res[3 * c + 2] = Stencil<ORDER, FRN>::eval(sa, sb, f, scale);
+        }
+        float4 *o4 = reinterpret_cast<float4 *>(out + 3 * ((ij << log2n) + k0));
+        o4[0] = make_float4(res[0], res[1], res[2], res[3]);
+        o4[1] = make_float4(res[4], res[5], res[6], res[7]);
+        o4[2] = make_float4(res[8], res[9], res[10], res[11]);
+    }
+}
+
+template <int FRN>
+static int gradient_dispatch(pm_ctx *c, int order, float f, const float *phi, const float *u, float *out) {
+    const int n = c->n;
+    const int64_t total = (int64_t)n * n * (n >> 2);
+    const int blocks = pm_stream_blocks(total, BLK);
+    float scale;
+    switch (order) {
+        case 2:
+            scale = (float)n;  // invh (mesh.py:656)
+            hipLaunchKernelGGL((gradient_kernel<2, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, phi, u, f, scale, n,
+                               c->log2n, out);
+            break;
+        case 3:
+            scale = (float)(0.5 * n);  // inv2h (mesh.py:698)
+            hipLaunchKernelGGL((gradient_kernel<3, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, phi, u, f, scale, n,
+                               c->log2n, out);
+            break;
+        case 5:
+            scale = (float)(n / 12.0);  // inv12h (mesh.py:743)
+            hipLaunchKernelGGL((gradient_kernel<5, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, phi, u, f, scale, n,
+                               c->log2n, out);
+            break;
+        case 7:
+            scale = (float)(n / 60.0);  // inv60h (mesh.py:801)
+            hipLaunchKernelGGL((gradient_kernel<7, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, phi, u, f, scale, n,
+                               c->log2n, out);
+            break;
+        default:
+            pm_set_error("gradient order %d, should be 2, 3, 5 or 7", order);
+            return PM_EINVAL;
+    }
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+extern "C" int pm_gradient(pm_ctx *c, int order, const float *d_phi, float *d_force) {
+    PM_REQUIRE(c && d_phi && d_force, "NULL argument");
+    PM_REQUIRE(pm_aligned16(d_phi) && pm_aligned16(d_force), "grids must be 16-byte aligned");
+    PM_REQUIRE(c->n >= 8, "gradient kernels need n >= 8");
+    return gradient_dispatch<0>(c, order, 0.f, d_phi, nullptr, d_force);
+}
+
+extern "C" int pm_gradient_fr(pm_ctx *c, int order, int fr_n, float f, const float *d_phi, const float *d_u,
+                              float *d_force) {
+    PM_REQUIRE(c && d_phi && d_u && d_force, "NULL argument");
+    PM_REQUIRE(pm_aligned16(d_phi) && pm_aligned16(d_u) && pm_aligned16(d_force), "grids must be 16-byte aligned");
+    PM_REQUIRE(c->n >= 8, "gradient kernels need n >= 8");
+    if (fr_n == 1) return gradient_dispatch<1>(c, order, f, d_phi, d_u, d_force);
+    if (fr_n == 2) return gradient_dispatch<2>(c, order, f, d_phi, d_u, d_force);
+    pm_set_error("Only f(R) with n = 1 and 2, currently fR_n=%d", fr_n);
+    return PM_ENOSUP;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-space Green's functions (fourier.py:460-595): one thread per complex element, per-axis tables.
+
+template <int KIND>
+__global__ __launch_bounds__(BLK) void greens_kernel(float2 *__restrict__ x, int n, int log2n, int p,
+                                                     const float *__restrict__ k2, const float *__restrict__ s,
+                                                     float c0) {
+    const int nh = (n >> 1) + 1;
+    const int64_t total = (int64_t)n * n * nh;
+    const int mask = n - 1;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t % nh);
+        const int64_t ij = t / nh;
+        const int j = (int)(ij & mask);
+        const int i = (int)(ij >> log2n);
+        float g;
+        if (KIND == PM_GREEN_7PT) {
+            g = c0 / ((s[i] + s[j]) + s[k]);
+        } else {
+            const float invk2 = c0 / ((k2[i] + k2[j]) + k2[k]);
+            if (KIND == PM_GREEN_COMPENSATED) {
+                const float w = (s[i] * s[j]) * s[k];
+                g = powf(w, (float)(-2 * p)) * invk2;
+            } else {
+                g = invk2;
+            }
+        }
+        float2 v = x[t];
+        if (t == 0) {
+            v = make_float2(0.f, 0.f);  // x[0,0,0] = 0 (fourier.py:491, 544, 595)
+        } else {
+            v.x *= g;
+            v.y *= g;
+        }
+        x[t] = v;
+    }
+}
+
+extern "C" int pm_greens(pm_ctx *c, int kind, int p, void *d_xk, const float *h_k2, const float *h_s, float c0) {
+    PM_REQUIRE(c && d_xk && h_k2 && h_s, "NULL argument");
+    const int n = c->n;
+    // tables are tiny (n floats): staged through pageable memcpy on the stream
+    PM_HIP(hipMemcpyAsync(c->d_tab, h_k2, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    PM_HIP(hipMemcpyAsync(c->d_tab + n, h_s, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const int64_t total = (int64_t)n * n * (n / 2 + 1);
+    const int blocks = pm_stream_blocks(total, BLK * 2);
+    float2 *x = reinterpret_cast<float2 *>(d_xk);
+    switch (kind) {
+        case PM_GREEN_PLAIN:
+            hipLaunchKernelGGL((greens_kernel<PM_GREEN_PLAIN>), dim3(blocks), dim3(BLK), 0, c->stream, x, n, c->log2n,
+                               p, c->d_tab, c->d_tab + n, c0);
+            break;
+        case PM_GREEN_COMPENSATED:
+            hipLaunchKernelGGL((greens_kernel<PM_GREEN_COMPENSATED>), dim3(blocks), dim3(BLK), 0, c->stream, x, n,
+                               c->log2n, p, c->d_tab, c->d_tab + n, c0);
+            break;
+        case PM_GREEN_7PT:
+            hipLaunchKernelGGL((greens_kernel<PM_GREEN_7PT>), dim3(blocks), dim3(BLK), 0, c->stream, x, n, c->log2n, p,
+                               c->d_tab, c->d_tab + n, c0);
+            break;
+        default:
+            pm_set_error("unknown Green's function kind %d", kind);
+            return PM_EINVAL;
+    }
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// P(k) estimator (fourier.py:22-100).  Per-block LDS histograms in fp32 (the reference keeps one
+// private fp32 histogram per i-plane), flushed to fp64 global bins.
+
+__global__ __launch_bounds__(BLK) void pk_kernel(float2 *__restrict__ x, int n, int log2n, int p,
+                                                 const float *__restrict__ sincs, double *__restrict__ hist) {
+    extern __shared__ float lds[];  // 3*n floats: ksum, pksum, nmodes
+    for (int b = threadIdx.x; b < 3 * n; b += BLK) lds[b] = 0.f;
+    __syncthreads();
+    const int nh = (n >> 1) + 1, middle = n >> 1, mask = n - 1;
+    const int64_t total = (int64_t)n * n * nh;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t % nh);
+        const int64_t ij = t / nh;
+        const int j = (int)(ij & mask);
+        const int i = (int)(ij >> log2n);
+        if (t == 0) {
+            x[0] = make_float2(0.f, 0.f);  // side effect at fourier.py:80-82
+            continue;
+        }
+        const float kx = (i >= middle) ? (float)(i - n) : (float)i;
+        const float ky = (j >= middle) ? (float)(j - n) : (float)j;
+        const float kz = (float)k;
+        const float w = (sincs[i] * sincs[j]) * sincs[k];
+        const float comp = powf(w, (float)(-p));
+        const float2 v = x[t];
+        const float re = v.x * comp, im = v.y * comp;
+        const float delta2 = re * re + im * im;
+        const double knorm = sqrt((double)((kx * kx + ky * ky) + kz * kz));
+        const int kidx = (int)(knorm + 0.5);
+        atomicAdd(&lds[kidx], (float)knorm);
+        atomicAdd(&lds[n + kidx], delta2);
+        atomicAdd(&lds[2 * n + kidx], 1.0f);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 3 * n; b += BLK) {
+        float v = lds[b];
+        if (v != 0.f) atomicAdd(&hist[b], (double)v);
+    }
+}
+
+extern "C" int pm_pk(pm_ctx *c, int p, void *d_xk, const float *h_sinc, double *h_ksum, double *h_pksum,
+                     double *h_nmodes) {
+    PM_REQUIRE(c && d_xk && h_sinc && h_ksum && h_pksum && h_nmodes, "NULL argument");
+    const int n = c->n;
+    PM_REQUIRE((size_t)3 * n * sizeof(float) <= 64 * 1024, "n too large for the LDS histogram");
+    PM_HIP(hipMemcpyAsync(c->d_tab + 2 * n, h_sinc, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    PM_HIP(hipMemsetAsync(c->d_hist, 0, 3 * (size_t)n * sizeof(double), c->stream));
+    const int64_t total = (int64_t)n * n * (n / 2 + 1);
+    int blocks = pm_stream_blocks(total, BLK * 16);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pk_kernel, dim3(blocks), dim3(BLK), 3 * n * sizeof(float), c->stream,
+                       reinterpret_cast<float2 *>(d_xk), n, c->log2n, p, c->d_tab + 2 * n, c->d_hist);
+    PM_LAUNCH_CHECK();
+    PM_HIP(hipMemcpyAsync(h_ksum, c->d_hist, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipMemcpyAsync(h_pksum, c->d_hist + n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipMemcpyAsync(h_nmodes, c->d_hist + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
+    return PM_OK;
+}

@@ -1,0 +1,106 @@
+"""FFT wrappers (rocFFT, persistent plans), k-space Green's functions and the P(k) estimator.
+
+Mirror of the reference's fourier.py entry points on the hot path (fourier.py:22-100, 104-147,
+251-294, 460-595).  Half-spectra are complex64 [n, n, n//2+1] exactly as np.fft.rfftn lays them out.
+The per-axis tables (k_i^2, sinc(k_i/n), sin^2(pi k_i/n)) are O(n) host-side setup evaluated with
+the reference's own fp32 expressions; the O(n^3) work is on the GPU.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _kfreq(n: int) -> np.ndarray:
+    i = np.arange(n)
+    return np.where(i >= n // 2, i - n, i).astype(np.float32)  # fourier.py:523-527
+
+
+def green_tables(n: int, kind: int):
+    """(k2, s, c0) for pm_greens: fp32 per-axis tables + scalar prefactor."""
+    if kind == L.GREEN_PLAIN:  # fourier.py:470-489 ('>' middle, unlike the two below)
+        i = np.arange(n)
+        k = np.where(i > n // 2, n - i, i).astype(np.float32)
+        return k**2, np.ones(n, np.float32), float(np.float32(-0.25 / np.pi**2))
+    k = _kfreq(n)
+    if kind == L.GREEN_COMPENSATED:  # fourier.py:517-543
+        h = np.float32(1.0 / n)
+        return k**2, np.sinc(k * h).astype(np.float32), float(np.float32(-0.25 / np.pi**2))
+    if kind == L.GREEN_7PT:  # fourier.py:574-594
+        pi_h = np.float32(np.pi / n)
+        h = np.float32(1.0 / n)
+        c0 = float(-(np.float32(0.25) * h**2))
+        return np.zeros(n, np.float32), (np.sin(pi_h * k) ** 2).astype(np.float32), c0
+    raise ValueError(f"unknown Green's function kind {kind}")
+
+
+def fft_3D_real(x, threads: int = 1):
+    """Unnormalised r2c transform of a real [n,n,n] grid (`threads` is accepted and ignored)."""
+    torch = L.require_gpu()
+    xd = L.to_device(x, torch.float32)
+    n = xd.shape[0]
+    ctx = L.context(n)
+    xk = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64, device=xd.device)
+    L.check(ctx.lib.pm_fft_r2c(ctx.handle, L.ptr(xd), L.ptr(xk)))
+    return L.like_input(xk, x)
+
+
+def ifft_3D_real(x, threads: int = 1):
+    """c2r transform carrying 1/n^3; the device input buffer may be overwritten."""
+    torch = L.require_gpu()
+    xk = L.to_device(x, torch.complex64)
+    n = xk.shape[0]
+    ctx = L.context(n)
+    out = torch.empty((n, n, n), dtype=torch.float32, device=xk.device)
+    work = xk.clone() if L.is_device_array(x) else xk  # rocFFT c2r destroys its input
+    L.check(ctx.lib.pm_fft_c2r(ctx.handle, L.ptr(work), L.ptr(out)))
+    return L.like_input(out, x)
+
+
+def _greens_inplace(x, kind: int, p: int) -> None:
+    torch = L.require_gpu()
+    if not L.is_device_array(x):
+        xk = L.to_device(x, torch.complex64)
+    else:
+        xk = x
+        if not xk.is_contiguous() or xk.dtype != torch.complex64:
+            raise ValueError("device half-spectrum must be contiguous complex64")
+    n = xk.shape[0]
+    ctx = L.context(n)
+    k2, s, c0 = green_tables(n, kind)
+    L.check(ctx.lib.pm_greens(ctx.handle, kind, int(p), L.ptr(xk), L.hptr(k2), L.hptr(s), c0))
+    if not L.is_device_array(x):
+        x[...] = xk.cpu().numpy()
+
+
+def inverse_laplacian(x) -> None:  # fourier.py:460
+    _greens_inplace(x, L.GREEN_PLAIN, 0)
+
+
+def inverse_laplacian_compensated(x, p: int) -> None:  # fourier.py:502
+    _greens_inplace(x, L.GREEN_COMPENSATED, p)
+
+
+def inverse_laplacian_7pt(x) -> None:  # fourier.py:555
+    _greens_inplace(x, L.GREEN_7PT, 0)
+
+
+def fourier_grid_to_Pk(density_k, p: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(k, P(k), Nmodes) in grid units; also zeroes density_k[0,0,0] like the reference."""
+    torch = L.require_gpu()
+    xk = density_k if L.is_device_array(density_k) else L.to_device(density_k, torch.complex64)
+    n = xk.shape[0]
+    ctx = L.context(n)
+    sincs = np.sinc(_kfreq(n) * np.float32(1.0 / n)).astype(np.float32)
+    ks, ps, nm = (np.zeros(n, np.float64) for _ in range(3))
+    L.check(ctx.lib.pm_pk(ctx.handle, int(p), L.ptr(xk), L.hptr(sincs), L.hptr(ks), L.hptr(ps), L.hptr(nm)))
+    if not L.is_device_array(density_k):
+        density_k[0, 0, 0] = 0
+    kmax = int(2 * (n // 2) / 3)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        k = (ks[1:kmax] / nm[1:kmax]).astype(np.float32)
+        pk = (ps[1:kmax] / nm[1:kmax]).astype(np.float32)
+    return k, pk, nm[1:kmax].astype(np.float32)

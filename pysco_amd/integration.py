@@ -1,0 +1,94 @@
+"""Time integration: drop-in for the reference's integration.integrate() (integration.py:17-358).
+
+dt selection and the integrator dispatch stay on the host (scalars); the particle passes are HIP
+kernels.  With torch CUDA tensors the particle state never leaves the GPU between steps.
+"""
+from __future__ import annotations
+
+import logging
+from typing import List
+
+import numpy as np
+
+from . import _lib as L
+from . import solver, utils
+
+
+def integrate(position, velocity, acceleration, potential, additional_field, tables: List, param,
+              t_snap_next=np.float32(0)):
+    """One step: dt = min(free-fall, CFL, scale-factor criterion), then leapfrog or euler."""
+    dt1 = dt_CFL_maxacc(acceleration, param)
+    dt2 = dt_CFL_maxvel(velocity, param)
+    dt3 = dt_weak_variation(tables[1], param)
+    dt = np.min([dt1, dt2, dt3])
+    if (param["t"] + dt) > t_snap_next:
+        dt = t_snap_next - param["t"]
+        param["write_snapshot"] = True
+    else:
+        param["write_snapshot"] = False
+    logging.info(f"Conditions: velocity {dt1=}, acceleration {dt2=}, scale factor {dt3=}")
+    INTEGRATOR = param["integrator"].casefold()
+    if INTEGRATOR == "leapfrog":
+        return leapfrog(position, velocity, acceleration, potential, additional_field, dt, tables, param)
+    if INTEGRATOR == "euler":
+        return euler(position, velocity, acceleration, potential, additional_field, dt, tables, param)
+    raise NotImplementedError("ERROR: Integrator must be 'leapfrog' or 'euler'")
+
+
+def _advance_clock(dt, tables, param) -> None:
+    param["t"] += dt
+    param["aexp_old"] = param["aexp"]
+    param["aexp"] = np.exp(tables[0](param["t"]))
+    utils.set_units(param)
+
+
+def euler(position, velocity, acceleration, potential, additional_field, dt, tables, param):
+    """Drift, wrap, kick with the old acceleration, then pm (integration.py:121-189)."""
+    utils.add_vector_scalar_inplace(position, velocity, dt)
+    _advance_clock(dt, tables, param)
+    utils.periodic_wrap(position)
+    utils.add_vector_scalar_inplace(velocity, acceleration, -dt)
+    acceleration, potential, additional_field = solver.pm(position, param, potential, additional_field, tables)
+    return position, velocity, acceleration, potential, additional_field
+
+
+def leapfrog(position, velocity, acceleration, potential, additional_field, dt, tables, param):
+    """Kick-drift-kick (integration.py:192-264).  On device tensors the first kick, the drift and
+    the periodic wrap are one fused pass over the particle arrays."""
+    half_dt = np.float32(0.5 * dt)
+    fused = (L.is_device_array(position) and L.is_device_array(velocity) and L.is_device_array(acceleration)
+             and abs(float(half_dt)) != 1.0)
+    if fused:
+        ctx = L.context(4)
+        L.check(ctx.lib.pm_kick_drift_wrap(ctx.handle, L.ptr(position), L.ptr(velocity), L.ptr(acceleration),
+                                           float(half_dt), float(np.float32(dt)), position.shape[0]))
+        _advance_clock(dt, tables, param)
+    else:
+        utils.add_vector_scalar_inplace(velocity, acceleration, -half_dt)
+        utils.add_vector_scalar_inplace(position, velocity, dt)
+        _advance_clock(dt, tables, param)
+        utils.periodic_wrap(position)
+    logging.info(f"{param['t']=} {param['aexp']=}")
+    acceleration, potential, additional_field = solver.pm(position, param, potential, additional_field, tables)
+    utils.add_vector_scalar_inplace(velocity, acceleration, -half_dt)
+    return position, velocity, acceleration, potential, additional_field
+
+
+def dt_CFL_maxacc(acceleration, param) -> np.float32:
+    """Free-fall criterion C*sqrt(dx/max|a|) (integration.py:267-295)."""
+    dx = np.float32(0.5 ** param["ncoarse"])
+    max_acc = utils.max_abs(acceleration)
+    return np.float32(param["Courant_factor"]) * np.sqrt(dx / max_acc)
+
+
+def dt_CFL_maxvel(velocity, param) -> np.float32:
+    """Courant criterion C*dx/max|v| (integration.py:298-326)."""
+    dx = np.float32(0.5 ** param["ncoarse"])
+    max_vel = utils.max_abs(velocity)
+    return np.float32(param["Courant_factor"]) * dx / max_vel
+
+
+def dt_weak_variation(func_t_a, param) -> np.float32:
+    """Step giving a max_aexp_stepping % change of the scale factor (integration.py:329-358)."""
+    aexp_factor = 1.0 + 0.01 * param["max_aexp_stepping"]
+    return np.float32(func_t_a(np.log(aexp_factor * param["aexp"])) - func_t_a(np.log(param["aexp"])))

@@ -1,0 +1,110 @@
+"""Mass assignment, inverse interpolation and finite-difference gradients on the GPU.
+
+Host-side mirror of the reference's mesh.py entry points (same names, argument meaning and
+errors); the bodies are the HIP kernels in csrc/pm_particles.hip and csrc/pm_grid.hip.
+Arrays may be NumPy (uploaded, result returned as NumPy) or torch CUDA tensors (zero-copy).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _deposit(scheme: int, position, ncells_1d: int, sorted_hint: bool = True):
+    torch = L.require_gpu()
+    pos = L.to_device(position, torch.float32)
+    if pos.ndim != 2 or pos.shape[1] != 3:
+        raise ValueError("position must have shape [N_part, 3]")
+    ctx = L.context(ncells_1d)
+    rho = torch.empty((ncells_1d,) * 3, dtype=torch.float32, device=pos.device)
+    L.check(ctx.lib.pm_deposit(ctx.handle, scheme, L.ptr(pos), pos.shape[0], L.ptr(rho), int(sorted_hint)))
+    return L.like_input(rho, position)
+
+
+def NGP(position, ncells_1d: int):
+    """Nearest-grid-point density [n,n,n] (reference mesh.py:2240)."""
+    return _deposit(L.NGP, position, ncells_1d)
+
+
+def CIC(position, ncells_1d: int):
+    """Cloud-in-cell density (reference mesh.py:2284)."""
+    return _deposit(L.CIC, position, ncells_1d)
+
+
+def TSC(position, ncells_1d: int):
+    """Triangular-shaped-cloud density (reference mesh.py:2468)."""
+    return _deposit(L.TSC, position, ncells_1d)
+
+
+def TSC_seq(position, ncells_1d: int):
+    """Same result as TSC (reference mesh.py:2363 is its single-threaded twin)."""
+    return _deposit(L.TSC, position, ncells_1d)
+
+
+def _interp(scheme: int, ncomp: int, grid, position):
+    torch = L.require_gpu()
+    g = L.to_device(grid, torch.float32)
+    pos = L.to_device(position, torch.float32)
+    n = g.shape[0]
+    want = (n, n, n, 3) if ncomp == 3 else (n, n, n)
+    if tuple(g.shape) != want:
+        raise ValueError(f"grid must have shape {want}")
+    ctx = L.context(n)
+    out = torch.empty((pos.shape[0], 3) if ncomp == 3 else (pos.shape[0],), dtype=torch.float32, device=pos.device)
+    L.check(ctx.lib.pm_interp(ctx.handle, scheme, ncomp, L.ptr(g), L.ptr(pos), pos.shape[0], L.ptr(out)))
+    return L.like_input(out, position)
+
+
+def invNGP(grid, position):  # reference mesh.py:2600
+    return _interp(L.NGP, 1, grid, position)
+
+
+def invCIC(grid, position):  # reference mesh.py:2679
+    return _interp(L.CIC, 1, grid, position)
+
+
+def invTSC(grid, position):  # reference mesh.py:2827
+    return _interp(L.TSC, 1, grid, position)
+
+
+def invNGP_vec(grid, position):  # reference mesh.py:2639
+    return _interp(L.NGP, 3, grid, position)
+
+
+def invCIC_vec(grid, position):  # reference mesh.py:2752
+    return _interp(L.CIC, 3, grid, position)
+
+
+def invTSC_vec(grid, position):  # reference mesh.py:2960
+    return _interp(L.TSC, 3, grid, position)
+
+
+def derivative(a, gradient_order: int):
+    """+grad(a) as [n,n,n,3]; order 2 (forward), 3, 5, 7 (central) -- reference mesh.py:2072."""
+    if gradient_order not in (2, 3, 5, 7):
+        raise ValueError(f"gradient_order={gradient_order}, should be 2, 3, 5 or 7")
+    torch = L.require_gpu()
+    phi = L.to_device(a, torch.float32)
+    n = phi.shape[0]
+    ctx = L.context(n)
+    out = torch.empty((n, n, n, 3), dtype=torch.float32, device=phi.device)
+    L.check(ctx.lib.pm_gradient(ctx.handle, int(gradient_order), L.ptr(phi), L.ptr(out)))
+    return L.like_input(out, a)
+
+
+def derivative_fR(a, b, f, fR_n: int, gradient_order: int):
+    """grad(a) + f*grad(b**(fR_n+1)) -- reference mesh.py:2112."""
+    if gradient_order not in (2, 3, 5, 7):
+        raise ValueError(f"gradient_order={gradient_order}, should be 2, 3, 5 or 7")
+    if fR_n not in (1, 2):
+        raise NotImplementedError(f"Only f(R) with n = 1 and 2, currently fR_n={fR_n}")
+    torch = L.require_gpu()
+    phi = L.to_device(a, torch.float32)
+    u = L.to_device(b, torch.float32)
+    n = phi.shape[0]
+    ctx = L.context(n)
+    out = torch.empty((n, n, n, 3), dtype=torch.float32, device=phi.device)
+    L.check(ctx.lib.pm_gradient_fr(ctx.handle, int(gradient_order), int(fR_n), float(np.float32(f)), L.ptr(phi),
+                                   L.ptr(u), L.ptr(out)))
+    return L.like_input(out, a)

@@ -1,0 +1,123 @@
+"""Element-wise helpers, reductions, periodic wrap, unit system and Morton re-ordering.
+
+Mirror of the reference's utils.py functions that sit on the per-step path (utils.py:167-298,
+410-430, 644-755, 1019-1149).  In-place functions mutate device tensors directly; NumPy inputs
+are round-tripped through the GPU and written back in place.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib as L
+
+# CODATA 2018, the values astropy.constants exposes as G, pc (utils.py:11)
+_G = 6.6743e-11
+_PC = 3.0856775814913674e16
+
+
+def set_units(param) -> None:
+    """Box units -> km, kg, s conversion factors (utils.py:167-192); pure host scalars."""
+    mpc_to_km = 1e3 * _PC
+    g = _G * 1e-9
+    H0 = param["H0"] / mpc_to_km
+    rhoc = 3.0 * H0**2 / (8.0 * np.pi * g)
+    param["unit_l"] = param["aexp"] * param["boxlen"] * 100.0 / H0
+    param["unit_t"] = param["aexp"] ** 2 / H0
+    param["unit_d"] = param["Om_m"] * rhoc / param["aexp"] ** 3
+    param["mpart"] = param["unit_d"] * param["unit_l"] ** 3 / param["npart"]
+
+
+def _inplace(y, fn):
+    """Run fn(device_tensor) and write the result back if y was a NumPy array."""
+    torch = L.require_gpu()
+    if L.is_device_array(y):
+        if not y.is_contiguous() or y.dtype != torch.float32:
+            raise ValueError("device arrays must be contiguous float32")
+        fn(y)
+    else:
+        t = L.to_device(y, torch.float32)
+        fn(t)
+        y[...] = t.cpu().numpy().reshape(y.shape)
+
+
+def _ctx():
+    return L.context(4)  # element-wise kernels do not depend on the grid size
+
+
+def add_vector_scalar_inplace(y, x, a) -> None:
+    """y += a*x (utils.py:264)."""
+    torch = L.require_gpu()
+    xd = L.to_device(x, torch.float32)
+    ctx = _ctx()
+    _inplace(y, lambda t: L.check(ctx.lib.pm_axpy(ctx.handle, L.ptr(t), L.ptr(xd), float(np.float32(a)), t.numel())))
+
+
+def prod_vector_scalar_inplace(y, a) -> None:
+    """y *= a (utils.py:410)."""
+    ctx = _ctx()
+    _inplace(y, lambda t: L.check(ctx.lib.pm_scale(ctx.handle, L.ptr(t), float(np.float32(a)), t.numel())))
+
+
+def linear_operator(x, f1, f2):
+    """f1*x + f2 into a new array (utils.py:644)."""
+    torch = L.require_gpu()
+    xd = L.to_device(x, torch.float32)
+    out = torch.empty_like(xd)
+    ctx = _ctx()
+    L.check(ctx.lib.pm_linear_operator(ctx.handle, L.ptr(out), L.ptr(xd), float(np.float32(f1)),
+                                       float(np.float32(f2)), xd.numel()))
+    return L.like_input(out, x)
+
+
+def linear_operator_inplace(x, f1, f2) -> None:
+    """x = f1*x + f2 (utils.py:684)."""
+    ctx = _ctx()
+    _inplace(x, lambda t: L.check(ctx.lib.pm_linear_operator(ctx.handle, L.ptr(t), L.ptr(t), float(np.float32(f1)),
+                                                               float(np.float32(f2)), t.numel())))
+
+
+def linear_operator_vectors_inplace(x, f1, y, f2) -> None:
+    """x = f1*x + f2*y (utils.py:721)."""
+    torch = L.require_gpu()
+    yd = L.to_device(y, torch.float32)
+    ctx = _ctx()
+    _inplace(x, lambda t: L.check(ctx.lib.pm_linear_operator_vectors(ctx.handle, L.ptr(t), float(np.float32(f1)),
+                                                                       L.ptr(yd), float(np.float32(f2)), t.numel())))
+
+
+def max_abs(x) -> np.float32:
+    """max |x| (utils.py:220); NaN propagates as in np.max(np.abs(x))."""
+    import ctypes as C
+
+    torch = L.require_gpu()
+    xd = L.to_device(x, torch.float32)
+    ctx = _ctx()
+    out = C.c_float(0)
+    L.check(ctx.lib.pm_max_abs(ctx.handle, L.ptr(xd), xd.numel(), C.byref(out)))
+    return np.float32(out.value)
+
+
+def periodic_wrap(position) -> None:
+    """Wrap positions into [0,1) with the reference's -2^-25 guard (utils.py:1120)."""
+    ctx = _ctx()
+    _inplace(position, lambda t: L.check(ctx.lib.pm_periodic_wrap(ctx.handle, L.ptr(t), t.numel())))
+
+
+def reorder_particles(position, velocity=None, acceleration=None):
+    """Sort particles by Morton key (utils.py:1019).  Unlike the reference's per-thread partial
+    argsort (utils.py:1080-1116) this is always a full, stable sort."""
+    torch = L.require_gpu()
+    pos = L.to_device(position, torch.float32)
+    vel = L.to_device(velocity, torch.float32) if velocity is not None else None
+    acc = L.to_device(acceleration, torch.float32) if acceleration is not None else None
+    ctx = _ctx()
+    po = torch.empty_like(pos)
+    vo = torch.empty_like(vel) if vel is not None else None
+    ao = torch.empty_like(acc) if acc is not None else None
+    L.check(ctx.lib.pm_reorder_particles(ctx.handle, pos.shape[0], L.ptr(pos), L.ptr(vel), L.ptr(acc), L.ptr(po),
+                                         L.ptr(vo), L.ptr(ao), None))
+    if acceleration is not None:
+        return L.like_input(po, position), L.like_input(vo, velocity), L.like_input(ao, acceleration)
+    if velocity is not None:
+        return L.like_input(po, position), L.like_input(vo, velocity)
+    return L.like_input(po, position)

@@ -1,0 +1,262 @@
+"""GPU parity tests for the Newtonian PM path: HIP kernels (through the C ABI) vs the CPU oracle
+and vs the golden vectors captured from the reference.  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pysco_oracle as orc  # noqa: E402  (checker only)
+from tests.helpers import param_from_json, synth_tables, zeldovich_particles  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import pysco_amd.fourier as fourier
+    import pysco_amd.integration as integration
+    import pysco_amd.mesh as mesh
+    import pysco_amd.morton as morton
+    import pysco_amd.solver as solver
+    import pysco_amd.utils as utils
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.mesh, ns.fourier, ns.utils, ns.solver, ns.integration, ns.morton, ns.torch = (
+        mesh, fourier, utils, solver, integration, morton, torch)
+    return ns
+
+
+def _scale(x):
+    return float(np.abs(x).max())
+
+
+DEPOSIT_SETS = ["uniform_n16", "lattice_n16", "edge_n16", "cluster_n16", "uniform_n32", "lattice_n32"]
+
+
+@pytest.mark.parametrize("tag", DEPOSIT_SETS)
+def test_deposit_vs_golden_and_oracle(amd, golden, tag):
+    g = golden("deposit_" + tag)
+    pos, n = g["pos"], int(g["n"])
+    for name, fn, ofn in (("tsc", amd.mesh.TSC, orc.TSC), ("cic", amd.mesh.CIC, orc.CIC), ("ngp", amd.mesh.NGP, orc.NGP)):
+        rho = fn(pos, n)
+        assert rho.dtype == np.float32 and rho.shape == (n, n, n)
+        # atomics reorder the fp32 sums: tolerance = a few ulp of the largest cell, never an index error
+        tol = 4e-6 * max(1.0, _scale(g[name]))
+        np.testing.assert_allclose(rho, g[name], rtol=0, atol=tol, err_msg=f"{name} vs golden")
+        np.testing.assert_allclose(rho, ofn(pos, n), rtol=0, atol=tol, err_msg=f"{name} vs oracle")
+    np.testing.assert_array_equal(amd.mesh.NGP(pos, n), g["ngp"])  # integer counts: exact
+    np.testing.assert_array_equal(amd.mesh.TSC_seq(pos, n).shape, (n, n, n))
+
+
+@pytest.mark.parametrize("tag", DEPOSIT_SETS)
+def test_gather_bit_exact_vs_oracle(amd, golden, tag):
+    g = golden("deposit_" + tag)
+    pos, F, S = g["pos"], g["F"], g["S"]
+    np.testing.assert_array_equal(amd.mesh.invTSC_vec(F, pos), orc.invTSC_vec(F, pos))
+    np.testing.assert_array_equal(amd.mesh.invCIC_vec(F, pos), orc.invCIC_vec(F, pos))
+    np.testing.assert_array_equal(amd.mesh.invNGP_vec(F, pos), orc.invNGP_vec(F, pos))
+    np.testing.assert_array_equal(amd.mesh.invTSC(S, pos), orc.invTSC(S, pos))
+    np.testing.assert_array_equal(amd.mesh.invCIC_vec(F, pos), g["inv_cic_vec"])
+    np.testing.assert_array_equal(amd.mesh.invNGP_vec(F, pos), g["inv_ngp_vec"])
+    np.testing.assert_allclose(amd.mesh.invTSC_vec(F, pos), g["inv_tsc_vec"], rtol=0, atol=2e-6)
+
+
+def test_deposit_order_independent_and_sorted_path(amd):
+    """The LDS-tiled kernel (sorted stream) and the atomic fallback (shuffled) agree; sum(rho)=Np."""
+    n = 64
+    pos, _ = zeldovich_particles(n, seed=7, rms_cells=1.5)
+    pos_sorted = amd.utils.reorder_particles(pos)
+    rng = np.random.default_rng(0)
+    pos_shuf = pos[rng.permutation(len(pos))]
+    ref = orc.TSC(pos, n)
+    for p in (pos, pos_sorted, pos_shuf):
+        rho = amd.mesh.TSC(p, n)
+        np.testing.assert_allclose(rho, ref, rtol=0, atol=4e-6 * _scale(ref))
+        assert abs(rho.sum(dtype=np.float64) - len(pos)) < 1e-5 * len(pos)
+    for fn, ofn in ((amd.mesh.CIC, orc.CIC), (amd.mesh.NGP, orc.NGP)):
+        np.testing.assert_allclose(fn(pos_sorted, n), ofn(pos_sorted, n), rtol=0, atol=4e-6 * _scale(ref))
+
+
+def test_gradient_bit_exact(amd, golden):
+    g = golden("gradient_n16")
+    a, b, f = g["a"], g["b"], np.float32(g["f"])
+    for order in (2, 3, 5, 7):
+        np.testing.assert_array_equal(amd.mesh.derivative(a, order), g[f"d{order}"])
+        np.testing.assert_array_equal(amd.mesh.derivative(a, order), orc.derivative(a, order))
+        for frn in (1, 2):
+            np.testing.assert_array_equal(amd.mesh.derivative_fR(a, b, f, frn, order), orc.derivative_fR(a, b, f, frn, order))
+    with pytest.raises(ValueError):
+        amd.mesh.derivative(a, 4)
+    with pytest.raises(NotImplementedError):
+        amd.mesh.derivative_fR(a, b, f, 3, 5)
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_kspace(amd, golden, n):
+    g = golden(f"kspace_n{n}")
+    x, xk = g["x"], g["xk"]
+    got = amd.fourier.fft_3D_real(x)
+    assert got.dtype == np.complex64 and got.shape == xk.shape
+    # rocFFT fp32 vs numpy's fp64-then-cast: relative to the spectrum's scale
+    np.testing.assert_allclose(got, xk, rtol=0, atol=3e-6 * _scale(xk))
+    np.testing.assert_allclose(amd.fourier.ifft_3D_real(xk.copy()), g["ifft_xk"], rtol=0, atol=3e-6 * _scale(g["ifft_xk"]))
+    for name, fn in (("plain", amd.fourier.inverse_laplacian),
+                     ("comp2", lambda a: amd.fourier.inverse_laplacian_compensated(a, 2)),
+                     ("comp3", lambda a: amd.fourier.inverse_laplacian_compensated(a, 3)),
+                     ("sevenpt", amd.fourier.inverse_laplacian_7pt)):
+        a = xk.copy()
+        fn(a)
+        assert a[0, 0, 0] == 0
+        np.testing.assert_allclose(a, g["green_" + name], rtol=4e-6, atol=0)
+    for p in (0, 2, 3):
+        a = xk.copy()
+        k, pk, nm = amd.fourier.fourier_grid_to_Pk(a, p)
+        assert a[0, 0, 0] == 0
+        np.testing.assert_array_equal(nm, g[f"pk{p}_nmodes"])
+        np.testing.assert_allclose(k, g[f"pk{p}_k"], rtol=2e-6)
+        np.testing.assert_allclose(pk, g[f"pk{p}_pk"], rtol=1e-5)
+
+
+def test_utils_bit_exact(amd, golden):
+    g = golden("utils")
+    x, y0 = g["x"], g["y0"]
+    for tag in ("p1", "m1", "gen"):
+        y = y0.copy()
+        amd.utils.add_vector_scalar_inplace(y, x, np.float32(g["axpy_" + tag + "_a"]))
+        np.testing.assert_array_equal(y, g["axpy_" + tag])
+    y = y0.copy()
+    amd.utils.prod_vector_scalar_inplace(y, np.float32(1.7))
+    np.testing.assert_array_equal(y, g["scale"])
+    np.testing.assert_array_equal(amd.utils.linear_operator(x, np.float32(0.193), np.float32(-0.193)), g["linop"])
+    y = y0.copy()
+    amd.utils.linear_operator_vectors_inplace(y, np.float32(0.3), x, np.float32(-1.2))
+    np.testing.assert_array_equal(y, g["linop_vec"])
+    assert amd.utils.max_abs(x) == g["max_abs"]
+    assert np.isnan(amd.utils.max_abs(np.array([1.0, np.nan, -3.0], np.float32)))
+    w = g["wrap_in"].copy()
+    amd.utils.periodic_wrap(w)
+    np.testing.assert_array_equal(w, g["wrap_out"])
+    # odd lengths / unaligned tails exercise the scalar epilogue of the float4 kernels
+    for m in (1, 3, 5, 1023):
+        y = y0[:m].copy()
+        amd.utils.add_vector_scalar_inplace(y, x[:m], np.float32(0.5))
+        ref = y0[:m].copy()
+        orc.add_vector_scalar_inplace(ref, x[:m].copy(), np.float32(0.5))
+        np.testing.assert_array_equal(y, ref)
+
+
+def test_morton_and_reorder(amd, golden):
+    g = golden("utils")
+    pos, vel = g["morton_pos"], g["morton_vel"]
+    keys = amd.morton.positions_to_keys(pos)
+    assert keys.dtype == np.int64
+    np.testing.assert_array_equal(keys, g["morton_keys"])
+    p2, v2 = amd.utils.reorder_particles(pos, vel)
+    k2 = orc.positions_to_keys(p2)
+    assert (np.diff(k2) >= 0).all()
+    # stable sort == the oracle's stable argsort
+    po, vo = orc.reorder_particles(pos, vel)
+    np.testing.assert_array_equal(p2, po)
+    np.testing.assert_array_equal(v2, vo)
+    p3, v3, a3 = amd.utils.reorder_particles(pos, vel, vel * 2)
+    np.testing.assert_array_equal(a3, vo * 2)
+    np.testing.assert_array_equal(amd.utils.reorder_particles(pos), po)
+
+
+PM_NEWTON = ["fft_tsc_o5", "fft_cic_o3", "fft7pt_tsc_o2", "fft_tsc_o7", "fft_tsc_o5_np5000_n16"]
+
+
+@pytest.mark.parametrize("tag", PM_NEWTON)
+def test_pm_newton_vs_golden(amd, golden, tag):
+    g = golden("pm_newton_" + tag)
+    param = param_from_json(g["param_json"])
+    acc, pot, extra = amd.solver.pm(g["pos"], param, tables=synth_tables())
+    assert isinstance(acc, np.ndarray) and acc.dtype == np.float32
+    assert extra.size == 0
+    np.testing.assert_allclose(pot, g["pot"], rtol=0, atol=5e-6 * _scale(g["pot"]))
+    np.testing.assert_allclose(acc, g["acc"], rtol=0, atol=2e-5 * _scale(g["acc"]))
+    ref = param_from_json(g["param_json"])
+    for key in ("MAS_index", "save_pk", "compute_additional_field"):
+        assert param[key] == ref[key]
+
+
+def test_pm_errors(amd, golden):
+    g = golden("pm_newton_fft_tsc_o5")
+    base = param_from_json(g["param_json"])
+    for key, val, exc in (("mass_scheme", "NGP", NotImplementedError), ("save_power_spectrum", "maybe", NotImplementedError),
+                          ("linear_newton_solver", "cg", NotImplementedError), ("theory", "brans-dicke", NotImplementedError),
+                          ("linear_newton_solver", "full_fft", TypeError), ("gradient_stencil_order", 4, ValueError)):
+        p = dict(base)
+        p[key] = val
+        with pytest.raises(exc):
+            amd.solver.pm(g["pos"], p, tables=synth_tables())
+
+
+def test_pm_pk_file(amd, golden, tmp_path):
+    g = golden("pm_newton_pk")
+    param = param_from_json(g["param_json"])
+    (tmp_path / "power").mkdir()
+    param["base"], param["extra"] = str(tmp_path), "gpu"
+    amd.solver.pm(g["pos"], param, tables=synth_tables())
+    got = np.loadtxt(tmp_path / "power" / "pk_gpu_00000.dat")
+    ref = g["pk_table"]
+    np.testing.assert_allclose(got[:, 0], ref[:, 0], rtol=2e-6)
+    np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=1e-4)  # BASELINE.md P(k) bar
+    np.testing.assert_array_equal(got[:, 2], ref[:, 2])
+
+
+@pytest.mark.parametrize("integ,nsteps", [("leapfrog", 10), ("euler", 3)])
+@pytest.mark.parametrize("resident", [False, True])
+def test_integrate_vs_golden(amd, golden, integ, nsteps, resident):
+    g = golden("integrate_" + integ)
+    tables = synth_tables()
+    param = param_from_json(g["param0_json"])
+    p, v = g["pos0"].copy(), g["vel0"].copy()
+    if resident:  # device-resident state: torch CUDA tensors in, same tensors out
+        p, v = amd.torch.from_numpy(p).cuda(), amd.torch.from_numpy(v).cuda()
+    acc, pot, extra = amd.solver.pm(p, dict(param), tables=tables)
+    host = (lambda t: t.cpu().numpy()) if resident else (lambda t: t)
+    np.testing.assert_allclose(host(acc), g["acc0"], rtol=0, atol=2e-5 * _scale(g["acc0"]))
+    t_next = np.float32(g["t_snap_next"])
+    for s in range(nsteps):
+        p, v, acc, pot, extra = amd.integration.integrate(p, v, acc, pot, extra, tables, param, t_next)
+        assert abs(param["t"] - g["t"][s]) < 1e-6
+        assert abs(param["aexp"] - g["aexp"][s]) < 1e-6
+        assert bool(param["write_snapshot"]) == bool(g["write_snapshot"][s])
+        if s in (0, nsteps - 1):
+            d = np.abs(host(p) - g[f"pos_{s+1}"])
+            d = np.minimum(d, 1 - d)
+            assert d.max() <= 1e-5, d.max()  # max |dx| <= 1e-5 box units after 10 steps
+            np.testing.assert_allclose(host(v), g[f"vel_{s+1}"], rtol=0, atol=2e-5 * _scale(g[f"vel_{s+1}"]))
+    with pytest.raises(NotImplementedError):
+        param["integrator"] = "rk4"
+        amd.integration.integrate(p, v, acc, pot, extra, tables, param, t_next)
+
+
+def test_full_size_properties(amd):
+    """256^3 (17M particles): size-independent properties -- mass conservation, zero net force,
+    deposit/gather adjointness, and sorted/unsorted agreement -- where the oracle is too slow."""
+    torch = amd.torch
+    n = 256
+    pos_h, _ = zeldovich_particles(n, seed=3, rms_cells=1.0)
+    pos = torch.from_numpy(pos_h).cuda()
+    pos_s = amd.utils.reorder_particles(pos)
+    rho_s = amd.mesh.TSC(pos_s, n)
+    rho_u = amd.mesh.TSC(pos, n)
+    assert abs(float(rho_s.double().sum()) - n**3) < 1e-6 * n**3
+    assert float((rho_s - rho_u).abs().max()) < 1e-4
+    param = {"theory": "newton", "mass_scheme": "TSC", "npart": n**3, "ncoarse": 8, "Om_m": 0.25733, "aexp": 0.5,
+             "linear_newton_solver": "fft", "gradient_stencil_order": 5, "save_power_spectrum": "no", "nthreads": 1}
+    acc, pot, _ = amd.solver.pm(pos_s, param)
+    assert torch.isfinite(acc).all()
+    # momentum conservation of the PM force: sum of accelerations ~ 0 relative to sum |a|
+    assert float(acc.double().sum(0).abs().max()) < 1e-4 * float(acc.double().abs().sum(0).max())
+    # adjointness <TSC(pos), S> == sum_p invTSC(S)(pos_p)
+    S = torch.randn((n, n, n), device="cuda", dtype=torch.float32)
+    lhs = float((rho_s.double() * S.double()).sum())
+    rhs = float(amd.mesh.invTSC(S, pos_s).double().sum())
+    assert abs(lhs - rhs) < 1e-6 * n**3
