@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particles pushed per second for one complete PM step
+(= one integration.integrate() call including its solver.pm()) -- Newtonian, TSC, FFT Poisson,
+order-5 gradient, Np = N^3, fp32, device-resident state (BASELINE.json / SURVEY.md section 8d).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--ncells 1024]
+
+Prints ONE JSON line (rank 0).  `value` = particles * K / wall time of the K timed steps (max over
+ranks, barrier + synchronize on both sides).  `roofline` describes the dominant C-ABI stage,
+timed with HIP events on the launch stream inside the timed region; `cpu_baseline` times the CPU
+oracle (oracle/, a restatement of the reference's Numba path -- NOT PySCo itself) on a bounded
+sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); 6.29e12 measured float4 copy
+B_ALG_PER_PARTICLE = 200.0  # fused-ideal bytes per particle-step, fp32, Np = N^3
+
+
+def synth_tables():
+    """Monotone stand-ins for tables[0]=lna(t), [1]=t(lna), [3]=D1(lna) (EdS-like)."""
+    from scipy.interpolate import interp1d
+
+    t = np.linspace(-0.95, 0.0, 4000)
+    a = (1.0 + t) ** (2.0 / 3.0)
+    lna = np.log(a)
+    return [interp1d(t, lna, fill_value="extrapolate"), interp1d(lna, t, fill_value="extrapolate"), None,
+            interp1d(lna, a, fill_value="extrapolate")] + [None] * 9
+
+
+def make_param(n, npart):
+    ncoarse = int(np.log2(n))
+    p = {"theory": "newton", "mass_scheme": "TSC", "npart": npart, "ncoarse": ncoarse, "Om_m": 0.25733,
+         "Om_lambda": 0.742589237, "H0": 72.0, "boxlen": 100.0 * (n / 128), "aexp": 0.5, "aexp_old": 0.49,
+         "linear_newton_solver": "fft", "gradient_stencil_order": 5, "save_power_spectrum": "no", "nthreads": 1,
+         "Courant_factor": 1.0, "max_aexp_stepping": 10, "integrator": "leapfrog", "write_snapshot": False,
+         "nsteps": 0, "n_reorder": 50}
+    tables = synth_tables()
+    p["t"] = float(tables[1](np.log(p["aexp"])))
+    return p, tables
+
+
+def zeldovich_device(n, seed=42, rms_cells=0.5, vel_factor=0.02):
+    """Synthetic ICs built on the GPU with torch (input synthesis only, not the product path):
+    cell-centred lattice + Zel'dovich displacement from a k^-2 Gaussian field truncated at k_Nyq/2,
+    rms |psi| = rms_cells cells, v = vel_factor * psi.  Returns (pos, vel) float32 [n^3, 3] on cuda."""
+    import torch
+
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    kf = torch.fft.fftfreq(n, d=1.0 / n, device=dev)
+    kz = torch.fft.rfftfreq(n, d=1.0 / n, device=dev)
+    k2 = kf[:, None, None] ** 2 + kf[None, :, None] ** 2 + kz[None, None, :] ** 2
+    k2[0, 0, 0] = 1.0
+    amp = torch.where(k2.sqrt() <= n / 4, 1.0 / k2, torch.zeros_like(k2)).sqrt()
+    amp[0, 0, 0] = 0.0
+    delta_k = torch.complex(torch.randn(k2.shape, generator=g, device=dev), torch.randn(k2.shape, generator=g, device=dev))
+    delta_k *= amp / k2
+    del amp, k2
+    npart = n**3
+    vel = torch.empty((npart, 3), dtype=torch.float32, device=dev)
+    for ax, kk in enumerate((kf[:, None, None], kf[None, :, None], kz[None, None, :])):
+        psi = torch.fft.irfftn(1j * kk * delta_k, s=(n, n, n))
+        vel[:, ax] = psi.reshape(-1)
+        del psi
+    del delta_k
+    rms = float((vel.double() ** 2).sum(dim=1).mean().sqrt())
+    vel *= (rms_cells / n) / rms
+    lat = (torch.arange(n, device=dev, dtype=torch.float32) + 0.5) / n
+    pos = vel.clone()
+    pos.view(n, n, n, 3)[..., 0] += lat[:, None, None]
+    pos.view(n, n, n, 3)[..., 1] += lat[None, :, None]
+    pos.view(n, n, n, 3)[..., 2] += lat[None, None, :]
+    vel *= vel_factor
+    return pos, vel
+
+
+# algorithmic HBM bytes per launch of each C-ABI stage (compulsory traffic)
+def alg_bytes(n, npart):
+    cells = float(n) ** 3
+    spec = float(n) * n * (n // 2 + 1) * 8.0
+    return {
+        "pm_kick_drift_wrap": 60.0 * npart,          # read x,v,a; write x,v
+        "pm_deposit": 12.0 * npart + 4.0 * cells,    # read x; write rho
+        "pm_linear_operator": 8.0 * cells,           # rhs scaling (fused into the FFT in the ideal count)
+        "pm_fft_r2c": 24.0 * cells,                  # 3 axis passes, read+write
+        "pm_greens": 2.0 * spec,                     # read+write half spectrum (0 in the fused ideal)
+        "pm_fft_c2r": 24.0 * cells,
+        "pm_gradient": 16.0 * cells,                 # read phi, write F(3)
+        "pm_interp": 24.0 * npart + 12.0 * cells,    # read x, F; write a
+        "pm_interp_kick": 48.0 * npart + 12.0 * cells,  # gather + second kick + CFL maxima: read x,v,F; write v,a
+        "pm_axpy": 36.0 * npart,                     # second kick: read v,a; write v
+        "pm_max_abs": 12.0 * npart,                  # CFL reductions (two per step)
+    }
+
+
+def cpu_baseline(cpu_n, steps=1):
+    """CPU oracle (single-threaded C restatement + numpy FFT) timed on `steps` leapfrog steps."""
+    from oracle import pysco_oracle as orc
+
+    pos_d, vel_d = zeldovich_device(cpu_n)
+    pos, vel = pos_d.cpu().numpy(), vel_d.cpu().numpy()
+    del pos_d, vel_d
+    orc.periodic_wrap(pos)
+    param, tables = make_param(cpu_n, cpu_n**3)
+    acc, phi, extra = orc.pm(pos, param, tables=tables)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pos, vel, acc, phi, extra = orc.integrate(pos, vel, acc, phi, extra, tables, param, np.float32(1))
+    dt = time.perf_counter() - t0
+    return {"value": cpu_n**3 * steps / dt, "unit": "particles/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} leapfrog step(s) at {cpu_n}^3 particles / {cpu_n}^3 mesh (TSC, FFT, order 5), "
+                      f"oracle/pm_oracle.c + numpy.fft, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ncells", type=int, default=1024)
+    ap.add_argument("--rms-cells", type=float, default=0.5)
+    ap.add_argument("--cpu-ncells", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        raise SystemExit("bench.py: the slab-decomposed multi-GPU step is not wired in yet (see DESIGN.md)")
+    torch.cuda.set_device(local_rank)
+
+    from pysco_amd import _lib as L
+    from pysco_amd import integration, solver, utils
+
+    n = args.ncells
+    npart = n**3
+    pos, vel = zeldovich_device(n, rms_cells=args.rms_cells)
+    utils.periodic_wrap(pos)
+    pos, vel = utils.reorder_particles(pos, vel)  # Morton-sorted once before timing
+    L._ctxs.clear()  # drop the sort workspace
+    torch.cuda.empty_cache()
+    param, tables = make_param(n, npart)
+    acc, phi, extra = solver.pm(pos, param, tables=tables)
+    t_far = np.float32(1.0)
+    for _ in range(args.warmup):
+        pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, t_far)
+
+    torch.cuda.synchronize()
+    L.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, t_far)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    stages = L.profile_stop()
+
+    ms_per_step = wall / args.steps * 1e3
+    value = npart * args.steps / wall
+    assert bool(torch.isfinite(pos).all()) and bool(torch.isfinite(vel).all())
+
+    ab = alg_bytes(n, npart)
+    table = []
+    for name, (calls, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):
+        avg = ms / calls
+        gbs = ab.get(name, 0.0) / (avg * 1e-3) / 1e9 if name in ab else None
+        table.append({"stage": name, "calls_per_step": calls / args.steps, "avg_ms": round(avg, 4),
+                      "alg_GBps": None if gbs is None else round(gbs, 1)})
+    dom = table[0]
+    achieved = dom["alg_GBps"] or 0.0
+    roofline = {"bound": "hbm", "kernel": dom["stage"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(achieved / (HBM_PEAK / 1e9), 4), "traffic": None,
+                "alg_bytes_per_launch": ab.get(dom["stage"]),
+                "step_frac": round(B_ALG_PER_PARTICLE * npart / (wall / args.steps) / HBM_PEAK, 4),
+                "step_alg_bytes_per_particle": B_ALG_PER_PARTICLE, "stages": table}
+
+    out = {"metric": "particles pushed/sec (one PM step), Newtonian TSC+FFT, fp32", "value": value,
+           "unit": "particles/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"Newton {n}^3 mesh / {n}^3 particles, TSC, FFT Poisson (compensated), "
+                                  f"order-5 gradient, leapfrog KDK, Zel'dovich ICs rms {args.rms_cells} cell, "
+                                  "Morton-sorted once", "ncells_1d": n, "npart": npart, "parallelism": "1 GPU"},
+           "roofline": roofline}
+    if not args.no_cpu_baseline and rank == 0:
+        del pos, vel, acc, phi, extra
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(args.cpu_ncells)
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,16 @@ int pm_poisson_fft(pm_ctx *ctx, int kind, int p, const float *d_rhs, float *d_ph
 int pm_kick_drift_wrap(pm_ctx *ctx, float *d_pos, float *d_vel, const float *d_acc, float half_dt, float dt,
                        int64_t np);
 
+/* solver.py:205-209 + integration.py:262 + the next step's integration.py:294, 325 in one pass:
+ *   acc = inv<scheme>_vec(force, pos);  if (d_vel) vel += -half_dt*acc;
+ * and max|acc|, max|vel| (after the kick) are left in the context for pm_last_maxabs().  LDS-tiled
+ * for Morton-sorted streams; any particle order gives the same result.  Needs n >= 16. */
+int pm_interp_kick(pm_ctx *ctx, int scheme, const float *d_force, const float *d_pos, int64_t np, float *d_acc,
+                   float *d_vel, float half_dt);
+/* utils.max_abs of the acc / vel arrays written by the last pm_interp_kick (syncs).  *h_max_vel is 0
+ * if that call had d_vel == NULL. */
+int pm_last_maxabs(pm_ctx *ctx, float *h_max_acc, float *h_max_vel);
+
 #ifdef __cplusplus
 }
 #endif

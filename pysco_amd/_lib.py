@@ -50,6 +50,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_pk": (_vp, _i, _vp, _vp, _vp, _vp, _vp),
     "pm_poisson_fft": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),
     "pm_kick_drift_wrap": (_vp, _vp, _vp, _vp, _f, _f, _i64),
+    "pm_interp_kick": (_vp, _i, _vp, _vp, _i64, _vp, _vp, _f),
+    "pm_last_maxabs": (_vp, C.POINTER(_f), C.POINTER(_f)),
 }
 _RESTYPES = {"pm_last_error": C.c_char_p}
 
@@ -102,6 +104,25 @@ def require_gpu():
 
 
 _ctxs: Dict[Tuple[int, int], "Context"] = {}
+_profiler = None  # list of (name, start_event, stop_event) while stage profiling is enabled
+
+
+def profile_start() -> None:
+    """Start recording a (HIP event, HIP event) pair around every C-ABI call (bench.py roofline)."""
+    global _profiler
+    _profiler = []
+
+
+def profile_stop() -> Dict[str, Tuple[int, float]]:
+    """Stop recording; returns {entry point: (calls, total milliseconds)} after synchronising."""
+    global _profiler
+    rec, _profiler = _profiler or [], None
+    _torch().cuda.synchronize()
+    out: Dict[str, Tuple[int, float]] = {}
+    for name, e0, e1 in rec:
+        c, t = out.get(name, (0, 0.0))
+        out[name] = (c + 1, t + e0.elapsed_time(e1))
+    return out
 
 
 class Context:
@@ -116,6 +137,21 @@ class Context:
         stream = torch.cuda.current_stream().cuda_stream
         check(self.lib.pm_ctx_create(C.byref(self.handle), self.n, _vp(stream)))
         self._stream = stream
+
+    def call(self, name: str, *args) -> None:
+        """Invoke one C-ABI entry point on this context; raises PMStepError on failure.  When the
+        stage profiler is on, the call is bracketed by events on the stream it launches on."""
+        fn = getattr(self.lib, name)
+        prof = _profiler
+        if prof is None:
+            check(fn(self.handle, *args))
+            return
+        torch = _torch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(fn(self.handle, *args))
+        e1.record()
+        prof.append((name, e0, e1))
 
     def use_current_stream(self):
         stream = _torch().cuda.current_stream().cuda_stream

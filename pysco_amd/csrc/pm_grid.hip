@@ -134,7 +134,7 @@ extern "C" int pm_kick_drift_wrap(pm_ctx *c, float *d_pos, float *d_vel, const f
                                   int64_t np) {
     PM_REQUIRE(c && d_pos && d_vel && d_acc && np >= 0, "bad argument");
     if (np == 0) return PM_OK;
-    PM_REQUIRE(half_dt != 1.0f && half_dt != -1.0f, "half_dt == +-1 not supported by the fused kick");
+    // (the reference's a == +-1 special cases, utils.py:289-295, are arithmetically identical to y + a*x)
     const int64_t count = 3 * np;
     int vec_ok = pm_aligned16(d_pos) && pm_aligned16(d_vel) && pm_aligned16(d_acc);
     int blocks = pm_stream_blocks(count, BLK * 4 * 2);

@@ -5,8 +5,11 @@
 // Deposit, MI355X design: global fp32 atomics run at ~1.3 TB/s chip-wide and only when a wave
 // instruction touches contiguous bytes, so scattering 27 atomics per particle is ~20x off the HBM
 // roofline.  Instead a workgroup takes a contiguous chunk of the (Morton-sorted) particle stream,
-// accumulates it into an LDS tile of 16x16x16 cells + a one-cell halo with ds_add_f32, and flushes
-// the tile with one global atomic per touched cell (rows of 18 contiguous floats).  A chunk that
+// accumulates it into an LDS tile of 16x16x16 cells + a one-cell halo, and flushes the tile with
+// one global atomic per touched cell (rows of 18 contiguous floats).  The LDS tile is fp64:
+// measured on gfx950 (tools/micro/lds_atomics.hip) ds_add_f32 retires 0.33 lane-ops/clk/CU while
+// ds_add_f64 retires 6.4 and ds_add_u64 7.8 -- a 20x difference -- so each fp32 weight (computed
+// exactly as the reference does) is widened and summed in fp64, then rounded once at the flush.  A chunk that
 // spans several tiles is handled by re-anchoring the LDS tile (a few passes); particles that fall
 // outside the first PM_MAX_PASSES tiles -- unsorted input -- go straight to global atomics, so
 // the result never depends on the order, only the speed does.
@@ -93,23 +96,69 @@ __global__ __launch_bounds__(BLK) void deposit_atomic_kernel(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// deposit, LDS-tiled (see the header comment)
+// LDS tiles shared by the tiled deposit and the tiled gather.
+// A tile is 8 x 16 x 16 cells (x, y, z) -- a contiguous range of 2048 Morton codes, i.e. what one
+// 2048-particle workgroup chunk of a sorted stream covers at one particle per cell -- plus a
+// one-cell halo on every side (TSC/CIC reach i +- 1).
 
-constexpr int PM_T = 16;                       // tile edge in cells
-constexpr int PM_TH = PM_T + 2;                // + halo
-constexpr int PM_TILE = PM_TH * PM_TH * PM_TH; // 5832 floats = 23.3 KB
-constexpr int PM_PPT = 8;                      // particles per thread
-constexpr int PM_CHUNK = BLK * PM_PPT;         // particles per workgroup
+constexpr int PM_TI = 8, PM_TJ = 16, PM_TK = 16;      // tile extent in cells
+constexpr int PM_LI = 3, PM_LJ = 4, PM_LK = 4;        // log2 of the above
+constexpr int PM_HI = PM_TI + 2, PM_HJ = PM_TJ + 2, PM_HK = PM_TK + 2;
+constexpr int PM_TILE = PM_HI * PM_HJ * PM_HK;        // 3240 cells
+constexpr int PM_PPT = 8;                             // particles per thread
+constexpr int PM_CHUNK = BLK * PM_PPT;                // particles per workgroup
 constexpr int PM_MAX_PASSES = 6;
 
+struct TileId {
+    int ti, tj, tk;
+};
+
+__device__ __forceinline__ bool in_tile(int i, int j, int k, const TileId &t) {
+    return (i >> PM_LI) == t.ti && (j >> PM_LJ) == t.tj && (k >> PM_LK) == t.tk;
+}
+
+// Picks the tile of the first still-unprocessed particle of the workgroup's chunk (uniform result);
+// returns false when nothing is left.  Two barriers.
+__device__ __forceinline__ bool next_anchor(unsigned todo, const float *chunk_pos, float nf, int n, int *s_first,
+                                            int *s_anchor, TileId &t) {
+    const int tid = threadIdx.x;
+    if (tid == 0) *s_first = 0x7fffffff;
+    __syncthreads();
+    if (todo) atomicMin(s_first, (__ffs((int)todo) - 1) * BLK + tid);
+    __syncthreads();
+    const int first = *s_first;
+    if (first == 0x7fffffff) return false;
+    if (tid == 0) {
+        const float *q = chunk_pos + 3 * first;
+        s_anchor[0] = cell_of(q[0] * nf, n) >> PM_LI;
+        s_anchor[1] = cell_of(q[1] * nf, n) >> PM_LJ;
+        s_anchor[2] = cell_of(q[2] * nf, n) >> PM_LK;
+    }
+    __syncthreads();
+    t.ti = s_anchor[0], t.tj = s_anchor[1], t.tk = s_anchor[2];
+    return true;
+}
+
+// global cell index of tile-local cell c (with halo, periodic)
+__device__ __forceinline__ int64_t tile_cell_global(int c, const TileId &t, int mask, int log2n) {
+    const int lk = c % PM_HK, lij = c / PM_HK;
+    const int lj = lij % PM_HJ, li = lij / PM_HJ;
+    const int gi = (t.ti * PM_TI - 1 + li) & mask, gj = (t.tj * PM_TJ - 1 + lj) & mask,
+              gk = (t.tk * PM_TK - 1 + lk) & mask;
+    return ((((int64_t)gi << log2n) + gj) << log2n) + gk;
+}
+
+// ------------------------------------------------------------------------------------------------
+// deposit, LDS-tiled (see the header comment)
+
 template <int SCHEME>
-__device__ __forceinline__ void deposit_lds(float xp, float yp, float zp, int i, int j, int k, int ti, int tj, int tk,
-                                            float *tile) {
-    // local coordinates inside the haloed tile: cell (ti*T-1) is local 0
-    const int li = i - ti * PM_T + 1, lj = j - tj * PM_T + 1, lk = k - tk * PM_T + 1;
-    auto at = [&](int a, int b, int c) -> float * { return tile + ((li + a) * PM_TH + (lj + b)) * PM_TH + (lk + c); };
+__device__ __forceinline__ void deposit_lds(float xp, float yp, float zp, int i, int j, int k, const TileId &t,
+                                            double *tile) {
+    // local coordinates inside the haloed tile: cell (ti*TI-1) is local 0
+    const int li = i - t.ti * PM_TI + 1, lj = j - t.tj * PM_TJ + 1, lk = k - t.tk * PM_TK + 1;
+    auto at = [&](int a, int b, int c) -> double * { return tile + ((li + a) * PM_HJ + (lj + b)) * PM_HK + (lk + c); };
     if (SCHEME == PM_NGP) {
-        atomicAdd(at(0, 0, 0), 1.0f);
+        atomicAdd(at(0, 0, 0), 1.0);
     } else if (SCHEME == PM_CIC) {
         float wx[2], wy[2], wz[2];
         int sx, sy, sz;
@@ -121,7 +170,8 @@ __device__ __forceinline__ void deposit_lds(float xp, float yp, float zp, int i,
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) atomicAdd(at(a * sx, b * sy, c * sz), wx[a] * wy[b] * wz[c]);
+                for (int c = 0; c < 2; ++c)
+                    atomicAdd(at(a * sx, b * sy, c * sz), (double)(wx[a] * wy[b] * wz[c]));
     } else {
         float wx[3], wy[3], wz[3];
         tsc_weights(xp, i, wx);
@@ -133,7 +183,7 @@ __device__ __forceinline__ void deposit_lds(float xp, float yp, float zp, int i,
             for (int b = 0; b < 3; ++b) {
                 const float wxy = wx[a] * wy[b];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) atomicAdd(at(a - 1, b - 1, c - 1), wxy * wz[c]);
+                for (int c = 0; c < 3; ++c) atomicAdd(at(a - 1, b - 1, c - 1), (double)(wxy * wz[c]));
             }
     }
 }
@@ -141,67 +191,45 @@ __device__ __forceinline__ void deposit_lds(float xp, float yp, float zp, int i,
 template <int SCHEME>
 __global__ __launch_bounds__(BLK) void deposit_tiled_kernel(const float *__restrict__ pos, int64_t np, int n,
                                                             int log2n, float *__restrict__ rho) {
-    __shared__ float tile[PM_TILE];
+    __shared__ double tile[PM_TILE];  // 25.9 KB
     __shared__ int s_first;
-    __shared__ int s_anchor;
+    __shared__ int s_anchor[3];
     const int tid = threadIdx.x;
     const int mask = n - 1;
     const float nf = (float)n;
-    const int tshift = log2n - 4;  // tiles per side = n / 16
-    for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0.f;
+    for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0.0;
 
     const int64_t base = (int64_t)blockIdx.x * PM_CHUNK;
-    // Particles are re-read from L2 on every pass rather than held in registers: 27 weights per
-    // particle already fill the VGPR budget, and a sorted chunk needs only 1-3 passes.
+    // Particles are re-read from L2 on every pass rather than held in registers or staged in LDS
+    // (staging measured 25 % slower: it costs occupancy and a sorted chunk needs only 1-3 passes).
     unsigned todo = 0;
 #pragma unroll
     for (int r = 0; r < PM_PPT; ++r)
         if (base + r * BLK + tid < np) todo |= 1u << r;
 
+    TileId t;
     for (int pass = 0; pass < PM_MAX_PASSES; ++pass) {
-        if (tid == 0) s_first = 0x7fffffff;
-        __syncthreads();  // also orders the tile zeroing / previous flush before this pass's adds
-        if (todo) {
-            const int r = __ffs((int)todo) - 1;
-            atomicMin(&s_first, r * BLK + tid);
-        }
-        __syncthreads();
-        const int first = s_first;
-        if (first == 0x7fffffff) break;  // uniform: nothing left in the whole workgroup
-        if (tid == 0) {
-            const float *q = pos + 3 * (base + first);
-            const int i = cell_of(q[0] * nf, n), j = cell_of(q[1] * nf, n), k = cell_of(q[2] * nf, n);
-            s_anchor = ((((i >> 4) << tshift) + (j >> 4)) << tshift) + (k >> 4);
-        }
-        __syncthreads();
-        const int anchor = s_anchor;
-        const int tk = anchor & ((1 << tshift) - 1);
-        const int tj = (anchor >> tshift) & ((1 << tshift) - 1);
-        const int ti = anchor >> (2 * tshift);
+        // (the first barrier inside also orders the tile zeroing / previous flush before the adds)
+        if (!next_anchor(todo, pos + 3 * base, nf, n, &s_first, s_anchor, t)) break;
 #pragma unroll 1
         for (int r = 0; r < PM_PPT; ++r) {
             if (todo >> r & 1u) {
                 const float *q = pos + 3 * (base + r * BLK + tid);
                 const float xp = q[0] * nf, yp = q[1] * nf, zp = q[2] * nf;
                 const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
-                if ((i >> 4) == ti && (j >> 4) == tj && (k >> 4) == tk) {
-                    deposit_lds<SCHEME>(xp, yp, zp, i, j, k, ti, tj, tk, tile);
+                if (in_tile(i, j, k, t)) {
+                    deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
                     todo &= ~(1u << r);
                 }
             }
         }
         __syncthreads();
         // flush: one global atomic per touched cell; rows of 18 contiguous floats along k
-        const int gi0 = ti * PM_T - 1, gj0 = tj * PM_T - 1, gk0 = tk * PM_T - 1;
         for (int c = tid; c < PM_TILE; c += BLK) {
-            const float v = tile[c];
-            if (v != 0.f) {
-                const int lk = c % PM_TH, lij = c / PM_TH;
-                const int lj = lij % PM_TH, li = lij / PM_TH;
-                const int64_t g =
-                    ((((int64_t)((gi0 + li) & mask) << log2n) + ((gj0 + lj) & mask)) << log2n) + ((gk0 + lk) & mask);
-                unsafeAtomicAdd(rho + g, v);
-                tile[c] = 0.f;
+            const double v = tile[c];
+            if (v != 0.0) {
+                unsafeAtomicAdd(rho + tile_cell_global(c, t, mask, log2n), (float)v);
+                tile[c] = 0.0;
             }
         }
     }
@@ -343,6 +371,254 @@ extern "C" int pm_interp(pm_ctx *c, int scheme, int ncomp, const float *d_grid, 
     if (ncomp == 1) return interp_launch<1>(c, scheme, d_grid, d_pos, np, d_out);
     pm_set_error("ncomp %d, should be 1 or 3", ncomp);
     return PM_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather, LDS-tiled and fused with the second leapfrog kick (integration.py:262) and the two CFL
+// reductions of the next step (integration.py:294, 325).
+//
+// The direct kernel above is bound by the L1 tag rate (27 scattered 12-byte loads per particle).
+// Here the workgroup stages the force tile of its chunk (8x16x16 cells + halo, float4 per cell,
+// 51.8 KB) in LDS with coalesced loads and every particle does 27 ds_read_b128.  Sum order is the
+// reference's, so the accelerations are bit-identical to the direct kernel and to the oracle.
+
+template <int SCHEME>
+__device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, int j, int k, const TileId &t,
+                                           const float4 *tile, float acc[3]) {
+    const int li = i - t.ti * PM_TI + 1, lj = j - t.tj * PM_TJ + 1, lk = k - t.tk * PM_TK + 1;
+    auto at = [&](int a, int b, int c) -> float4 { return tile[((li + a) * PM_HJ + (lj + b)) * PM_HK + (lk + c)]; };
+    if (SCHEME == PM_NGP) {
+        const float4 g = at(0, 0, 0);
+        acc[0] = g.x, acc[1] = g.y, acc[2] = g.z;
+    } else if (SCHEME == PM_CIC) {
+        float wx[2], wy[2], wz[2];
+        int sx, sy, sz;
+        cic_weights(xp, i, wx[0], wx[1], sx);
+        cic_weights(yp, j, wy[0], wy[1], sy);
+        cic_weights(zp, k, wz[0], wz[1], sz);
+        bool first = true;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float w = wx[a] * wy[b] * wz[c];
+                    const float4 g = at(a * sx, b * sy, c * sz);
+                    acc[0] = first ? w * g.x : acc[0] + w * g.x;
+                    acc[1] = first ? w * g.y : acc[1] + w * g.y;
+                    acc[2] = first ? w * g.z : acc[2] + w * g.z;
+                    first = false;
+                }
+    } else {
+        float wx[3], wy[3], wz[3];
+        tsc_weights(xp, i, wx);
+        tsc_weights(yp, j, wy);
+        tsc_weights(zp, k, wz);
+        bool first = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float wxy = wx[a] * wy[b];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float w = wxy * wz[c];
+                    const float4 g = at(a - 1, b - 1, c - 1);
+                    acc[0] = first ? w * g.x : acc[0] + w * g.x;
+                    acc[1] = first ? w * g.y : acc[1] + w * g.y;
+                    acc[2] = first ? w * g.z : acc[2] + w * g.z;
+                    first = false;
+                }
+            }
+    }
+}
+
+template <int SCHEME>
+__device__ __forceinline__ void gather_global(const float *__restrict__ grid, float xp, float yp, float zp, int i,
+                                              int j, int k, int mask, int log2n, float acc[3]) {
+    auto at = [&](int ii, int jj, int kk) -> const float * {
+        return grid + 3 * (((((int64_t)(ii & mask) << log2n) + (jj & mask)) << log2n) + (kk & mask));
+    };
+    if (SCHEME == PM_NGP) {
+        const float *g = at(i, j, k);
+        acc[0] = g[0], acc[1] = g[1], acc[2] = g[2];
+    } else if (SCHEME == PM_CIC) {
+        float wx[2], wy[2], wz[2];
+        int sx, sy, sz;
+        cic_weights(xp, i, wx[0], wx[1], sx);
+        cic_weights(yp, j, wy[0], wy[1], sy);
+        cic_weights(zp, k, wz[0], wz[1], sz);
+        bool first = true;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float w = wx[a] * wy[b] * wz[c];
+                    const float *g = at(i + a * sx, j + b * sy, k + c * sz);
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) acc[m] = first ? w * g[m] : acc[m] + w * g[m];
+                    first = false;
+                }
+    } else {
+        float wx[3], wy[3], wz[3];
+        tsc_weights(xp, i, wx);
+        tsc_weights(yp, j, wy);
+        tsc_weights(zp, k, wz);
+        bool first = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float wxy = wx[a] * wy[b];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float w = wxy * wz[c];
+                    const float *g = at(i + a - 1, j + b - 1, k + c - 1);
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) acc[m] = first ? w * g[m] : acc[m] + w * g[m];
+                    first = false;
+                }
+            }
+    }
+}
+
+template <int SCHEME, bool KICK>
+__global__ __launch_bounds__(BLK) void interp_tiled_kernel(const float *__restrict__ grid,
+                                                           const float *__restrict__ pos, int64_t np, int n, int log2n,
+                                                           float *__restrict__ out, float *__restrict__ vel,
+                                                           float mhalf_dt, unsigned *__restrict__ maxbits) {
+    __shared__ float4 tile[PM_TILE];  // 51.8 KB
+    __shared__ int s_first;
+    __shared__ int s_anchor[3];
+    __shared__ unsigned s_max[2][BLK / 64];
+    const int tid = threadIdx.x;
+    const int mask = n - 1;
+    const float nf = (float)n;
+    const int64_t base = (int64_t)blockIdx.x * PM_CHUNK;
+    unsigned todo = 0;
+#pragma unroll
+    for (int r = 0; r < PM_PPT; ++r)
+        if (base + r * BLK + tid < np) todo |= 1u << r;
+    unsigned ma = 0, mv = 0;  // bit patterns of max|a|, max|v| (integer order == float order, NaN on top)
+
+    auto finish = [&](int64_t p, const float a[3]) {
+        out[3 * p] = a[0], out[3 * p + 1] = a[1], out[3 * p + 2] = a[2];
+        ma = max(ma, __float_as_uint(a[0]) & 0x7fffffffu);
+        ma = max(ma, __float_as_uint(a[1]) & 0x7fffffffu);
+        ma = max(ma, __float_as_uint(a[2]) & 0x7fffffffu);
+        if (KICK) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float v = vel[3 * p + m] + mhalf_dt * a[m];  // y += a*x (utils.py:297)
+                vel[3 * p + m] = v;
+                mv = max(mv, __float_as_uint(v) & 0x7fffffffu);
+            }
+        }
+    };
+
+    TileId t;
+    for (int pass = 0; pass < PM_MAX_PASSES; ++pass) {
+        // (the first barrier inside keeps this pass's tile fill behind the previous pass's reads)
+        if (!next_anchor(todo, pos + 3 * base, nf, n, &s_first, s_anchor, t)) break;
+        {   // tile fill: all loads in flight before the first LDS write
+            constexpr int NQ = (PM_TILE + BLK - 1) / BLK;
+            float gx[NQ], gy[NQ], gz[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = q * BLK + tid;
+                if (c < PM_TILE) {
+                    const float *g = grid + 3 * tile_cell_global(c, t, mask, log2n);
+                    gx[q] = g[0], gy[q] = g[1], gz[q] = g[2];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = q * BLK + tid;
+                if (c < PM_TILE) tile[c] = make_float4(gx[q], gy[q], gz[q], 0.f);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < PM_PPT; ++r) {
+            if (todo >> r & 1u) {
+                const int64_t p = base + r * BLK + tid;
+                const float xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
+                const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+                if (in_tile(i, j, k, t)) {
+                    float a[3];
+                    gather_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile, a);
+                    finish(p, a);
+                    todo &= ~(1u << r);
+                }
+            }
+        }
+    }
+#pragma unroll 1
+    for (int r = 0; r < PM_PPT; ++r)
+        if (todo >> r & 1u) {
+            const int64_t p = base + r * BLK + tid;
+            const float xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
+            const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+            float a[3];
+            gather_global<SCHEME>(grid, xp, yp, zp, i, j, k, mask, log2n, a);
+            finish(p, a);
+        }
+    // workgroup max -> two global atomics
+    for (int off = 32; off > 0; off >>= 1) {
+        ma = max(ma, (unsigned)__shfl_down((int)ma, off, 64));
+        mv = max(mv, (unsigned)__shfl_down((int)mv, off, 64));
+    }
+    if ((tid & 63) == 0) s_max[0][tid >> 6] = ma, s_max[1][tid >> 6] = mv;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < BLK / 64; ++w) ma = max(ma, s_max[0][w]), mv = max(mv, s_max[1][w]);
+        atomicMax(maxbits, ma);
+        if (KICK) atomicMax(maxbits + 1, mv);
+    }
+}
+
+template <int SCHEME>
+static int interp_kick_launch(pm_ctx *c, const float *grid, const float *pos, int64_t np, float *out, float *vel,
+                              float half_dt) {
+    const int64_t blocks = (np + PM_CHUNK - 1) / PM_CHUNK;
+    unsigned *mb = c->d_scratch + 8;
+    if (vel)
+        hipLaunchKernelGGL((interp_tiled_kernel<SCHEME, true>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, grid,
+                           pos, np, c->n, c->log2n, out, vel, -half_dt, mb);
+    else
+        hipLaunchKernelGGL((interp_tiled_kernel<SCHEME, false>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, grid,
+                           pos, np, c->n, c->log2n, out, vel, 0.f, mb);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+extern "C" int pm_interp_kick(pm_ctx *c, int scheme, const float *d_force, const float *d_pos, int64_t np,
+                              float *d_acc, float *d_vel, float half_dt) {
+    PM_REQUIRE(c && d_force && np >= 0 && ((d_pos && d_acc) || np == 0), "bad argument");
+    PM_REQUIRE(c->n >= 16, "pm_interp_kick needs n >= 16 (use pm_interp + pm_axpy below that)");
+    PM_REQUIRE((np + PM_CHUNK - 1) / PM_CHUNK < 2147483647LL, "too many particles for one launch");
+    PM_HIP(hipMemsetAsync(c->d_scratch + 8, 0, 2 * sizeof(unsigned), c->stream));
+    if (np == 0) return PM_OK;
+    switch (scheme) {
+        case PM_NGP: return interp_kick_launch<PM_NGP>(c, d_force, d_pos, np, d_acc, d_vel, half_dt);
+        case PM_CIC: return interp_kick_launch<PM_CIC>(c, d_force, d_pos, np, d_acc, d_vel, half_dt);
+        case PM_TSC: return interp_kick_launch<PM_TSC>(c, d_force, d_pos, np, d_acc, d_vel, half_dt);
+    }
+    pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme);
+    return PM_EINVAL;
+}
+
+extern "C" int pm_last_maxabs(pm_ctx *c, float *h_max_acc, float *h_max_vel) {
+    PM_REQUIRE(c && h_max_acc && h_max_vel, "NULL argument");
+    unsigned bits[2] = {0, 0};
+    PM_HIP(hipMemcpyAsync(bits, c->d_scratch + 8, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
+    memcpy(h_max_acc, &bits[0], sizeof(float));
+    memcpy(h_max_vel, &bits[1], sizeof(float));
+    return PM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

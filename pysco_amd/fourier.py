@@ -44,7 +44,7 @@ def fft_3D_real(x, threads: int = 1):
     n = xd.shape[0]
     ctx = L.context(n)
     xk = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64, device=xd.device)
-    L.check(ctx.lib.pm_fft_r2c(ctx.handle, L.ptr(xd), L.ptr(xk)))
+    ctx.call("pm_fft_r2c", L.ptr(xd), L.ptr(xk))
     return L.like_input(xk, x)
 
 
@@ -56,7 +56,7 @@ def ifft_3D_real(x, threads: int = 1):
     ctx = L.context(n)
     out = torch.empty((n, n, n), dtype=torch.float32, device=xk.device)
     work = xk.clone() if L.is_device_array(x) else xk  # rocFFT c2r destroys its input
-    L.check(ctx.lib.pm_fft_c2r(ctx.handle, L.ptr(work), L.ptr(out)))
+    ctx.call("pm_fft_c2r", L.ptr(work), L.ptr(out))
     return L.like_input(out, x)
 
 
@@ -71,7 +71,7 @@ def _greens_inplace(x, kind: int, p: int) -> None:
     n = xk.shape[0]
     ctx = L.context(n)
     k2, s, c0 = green_tables(n, kind)
-    L.check(ctx.lib.pm_greens(ctx.handle, kind, int(p), L.ptr(xk), L.hptr(k2), L.hptr(s), c0))
+    ctx.call("pm_greens", kind, int(p), L.ptr(xk), L.hptr(k2), L.hptr(s), c0)
     if not L.is_device_array(x):
         x[...] = xk.cpu().numpy()
 
@@ -96,7 +96,7 @@ def fourier_grid_to_Pk(density_k, p: int) -> Tuple[np.ndarray, np.ndarray, np.nd
     ctx = L.context(n)
     sincs = np.sinc(_kfreq(n) * np.float32(1.0 / n)).astype(np.float32)
     ks, ps, nm = (np.zeros(n, np.float64) for _ in range(3))
-    L.check(ctx.lib.pm_pk(ctx.handle, int(p), L.ptr(xk), L.hptr(sincs), L.hptr(ks), L.hptr(ps), L.hptr(nm)))
+    ctx.call("pm_pk", int(p), L.ptr(xk), L.hptr(sincs), L.hptr(ks), L.hptr(ps), L.hptr(nm))
     if not L.is_device_array(density_k):
         density_k[0, 0, 0] = 0
     kmax = int(2 * (n // 2) / 3)

@@ -56,12 +56,11 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
     """Kick-drift-kick (integration.py:192-264).  On device tensors the first kick, the drift and
     the periodic wrap are one fused pass over the particle arrays."""
     half_dt = np.float32(0.5 * dt)
-    fused = (L.is_device_array(position) and L.is_device_array(velocity) and L.is_device_array(acceleration)
-             and abs(float(half_dt)) != 1.0)
+    fused = L.is_device_array(position) and L.is_device_array(velocity) and L.is_device_array(acceleration)
     if fused:
         ctx = L.context(4)
-        L.check(ctx.lib.pm_kick_drift_wrap(ctx.handle, L.ptr(position), L.ptr(velocity), L.ptr(acceleration),
-                                           float(half_dt), float(np.float32(dt)), position.shape[0]))
+        ctx.call("pm_kick_drift_wrap", L.ptr(position), L.ptr(velocity), L.ptr(acceleration),
+                                           float(half_dt), float(np.float32(dt)), position.shape[0])
         _advance_clock(dt, tables, param)
     else:
         utils.add_vector_scalar_inplace(velocity, acceleration, -half_dt)
@@ -69,8 +68,12 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
         _advance_clock(dt, tables, param)
         utils.periodic_wrap(position)
     logging.info(f"{param['t']=} {param['aexp']=}")
-    acceleration, potential, additional_field = solver.pm(position, param, potential, additional_field, tables)
-    utils.add_vector_scalar_inplace(velocity, acceleration, -half_dt)
+    if fused:  # second kick fused into the interpolation kernel
+        acceleration, potential, additional_field = solver.pm(position, param, potential, additional_field, tables,
+                                                              _kick=(velocity, half_dt))
+    else:
+        acceleration, potential, additional_field = solver.pm(position, param, potential, additional_field, tables)
+        utils.add_vector_scalar_inplace(velocity, acceleration, -half_dt)
     return position, velocity, acceleration, potential, additional_field
 
 

@@ -18,7 +18,7 @@ def _deposit(scheme: int, position, ncells_1d: int, sorted_hint: bool = True):
         raise ValueError("position must have shape [N_part, 3]")
     ctx = L.context(ncells_1d)
     rho = torch.empty((ncells_1d,) * 3, dtype=torch.float32, device=pos.device)
-    L.check(ctx.lib.pm_deposit(ctx.handle, scheme, L.ptr(pos), pos.shape[0], L.ptr(rho), int(sorted_hint)))
+    ctx.call("pm_deposit", scheme, L.ptr(pos), pos.shape[0], L.ptr(rho), int(sorted_hint))
     return L.like_input(rho, position)
 
 
@@ -52,8 +52,31 @@ def _interp(scheme: int, ncomp: int, grid, position):
         raise ValueError(f"grid must have shape {want}")
     ctx = L.context(n)
     out = torch.empty((pos.shape[0], 3) if ncomp == 3 else (pos.shape[0],), dtype=torch.float32, device=pos.device)
-    L.check(ctx.lib.pm_interp(ctx.handle, scheme, ncomp, L.ptr(g), L.ptr(pos), pos.shape[0], L.ptr(out)))
+    if ncomp == 3 and n >= 16:  # LDS-tiled gather (fast on Morton-sorted streams, same result otherwise)
+        from . import utils
+
+        ctx.call("pm_interp_kick", scheme, L.ptr(g), L.ptr(pos), pos.shape[0], L.ptr(out), None, 0.0)
+        utils.register_fused_maxabs(None, None, None)
+    else:
+        ctx.call("pm_interp", scheme, ncomp, L.ptr(g), L.ptr(pos), pos.shape[0], L.ptr(out))
     return L.like_input(out, position)
+
+
+def interp_vec_kick(scheme_name: str, grid, position, velocity, half_dt):
+    """Fused solver.py:205-209 + integration.py:262 on device tensors: returns acc = inv*_vec(grid,
+    position) and applies velocity += -half_dt*acc in place; the maxima for the next step's CFL
+    criteria are kept in the context (utils.max_abs picks them up)."""
+    from . import utils
+
+    torch = L.require_gpu()
+    n = grid.shape[0]
+    scheme = {"cic": L.CIC, "tsc": L.TSC, "ngp": L.NGP}[scheme_name]
+    ctx = L.context(n)
+    out = torch.empty_like(position)
+    ctx.call("pm_interp_kick", scheme, L.ptr(grid), L.ptr(position), position.shape[0], L.ptr(out),
+             L.ptr(velocity), float(np.float32(half_dt)))
+    utils.register_fused_maxabs(ctx, out, velocity)
+    return out
 
 
 def invNGP(grid, position):  # reference mesh.py:2600
@@ -89,7 +112,7 @@ def derivative(a, gradient_order: int):
     n = phi.shape[0]
     ctx = L.context(n)
     out = torch.empty((n, n, n, 3), dtype=torch.float32, device=phi.device)
-    L.check(ctx.lib.pm_gradient(ctx.handle, int(gradient_order), L.ptr(phi), L.ptr(out)))
+    ctx.call("pm_gradient", int(gradient_order), L.ptr(phi), L.ptr(out))
     return L.like_input(out, a)
 
 
@@ -105,6 +128,6 @@ def derivative_fR(a, b, f, fR_n: int, gradient_order: int):
     n = phi.shape[0]
     ctx = L.context(n)
     out = torch.empty((n, n, n, 3), dtype=torch.float32, device=phi.device)
-    L.check(ctx.lib.pm_gradient_fr(ctx.handle, int(gradient_order), int(fR_n), float(np.float32(f)), L.ptr(phi),
-                                   L.ptr(u), L.ptr(out)))
+    ctx.call("pm_gradient_fr", int(gradient_order), int(fR_n), float(np.float32(f)), L.ptr(phi),
+                                   L.ptr(u), L.ptr(out))
     return L.like_input(out, a)

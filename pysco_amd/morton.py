@@ -9,5 +9,5 @@ def positions_to_keys(positions):
     pos = L.to_device(positions, torch.float32)
     ctx = L.context(4)
     keys = torch.empty(pos.shape[0], dtype=torch.int64, device=pos.device)
-    L.check(ctx.lib.pm_morton_keys(ctx.handle, L.ptr(pos), pos.shape[0], L.ptr(keys)))
+    ctx.call("pm_morton_keys", L.ptr(pos), pos.shape[0], L.ptr(keys))
     return L.like_input(keys, positions)

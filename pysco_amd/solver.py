@@ -25,11 +25,14 @@ def _empty(template):
     return np.empty(0, dtype=np.float32)
 
 
-def pm(position, param, potential=None, additional_field=None, tables: List = ()):
+def pm(position, param, potential=None, additional_field=None, tables: List = (), *, _kick=None):
     """Acceleration at the particles, potential and (for f(R)/MOND) the extra field.
 
     Mirrors solver.py:30-215: deposit -> density scaling -> [P(k)] -> extra field -> rhs ->
     Poisson solve (fft | fft_7pt | multigrid) -> gradient -> inverse interpolation.
+
+    `_kick=(velocity, half_dt)` is the private hook integration.leapfrog uses to fuse its second
+    kick (integration.py:262) into the interpolation kernel; not part of the reference API.
     """
     L.require_gpu()
     if potential is None:
@@ -117,7 +120,12 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     else:
         force = mesh.derivative(potential_d, param["gradient_stencil_order"])
 
-    acceleration = mesh.invCIC_vec(force, pos_d) if MASS_SCHEME == "cic" else mesh.invTSC_vec(force, pos_d)
+    if _kick is not None and ncells_1d >= 16:
+        acceleration = mesh.interp_vec_kick(MASS_SCHEME, force, pos_d, _kick[0], _kick[1])
+    else:
+        acceleration = mesh.invCIC_vec(force, pos_d) if MASS_SCHEME == "cic" else mesh.invTSC_vec(force, pos_d)
+        if _kick is not None:
+            utils.add_vector_scalar_inplace(_kick[0], acceleration, -_kick[1])
     del force
     if L.is_device_array(position):
         return acceleration, potential_d, additional_field_d
@@ -251,16 +259,17 @@ def fft(rhs, param):
     k2, s, c0 = fourier.green_tables(n, kind)
     want_pk = ("save_pk" in param) and param["save_pk"] and not compute_MOND_potential
     phi = torch.empty_like(rhs_d)
-    if not want_pk:
-        L.check(ctx.lib.pm_poisson_fft(ctx.handle, kind, p, L.ptr(rhs_d), L.ptr(phi), L.hptr(k2), L.hptr(s), c0))
-        return phi
-    rhs_fourier = fourier.fft_3D_real(rhs_d)
-    k, Pk, Nmodes = fourier.fourier_grid_to_Pk(rhs_fourier, MAS_index)
-    Pk *= np.float32(
-        (param["boxlen"] / n**2) ** 3 / (1.5 * param["aexp"] * param["Om_m"]) ** 2 / param["parametrized_mu_z"] ** 2
-    )
-    k *= np.float32(2 * np.pi / param["boxlen"])
-    iostream.write_power_spectrum_to_ascii_file(k, Pk, Nmodes, param)
-    L.check(ctx.lib.pm_greens(ctx.handle, kind, p, L.ptr(rhs_fourier), L.hptr(k2), L.hptr(s), c0))
-    L.check(ctx.lib.pm_fft_c2r(ctx.handle, L.ptr(rhs_fourier), L.ptr(phi)))
+    # three C-ABI calls (== pm_poisson_fft) so that per-stage event timing sees each of them
+    rhs_fourier = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64, device=rhs_d.device)
+    ctx.call("pm_fft_r2c", L.ptr(rhs_d), L.ptr(rhs_fourier))
+    if want_pk:
+        k, Pk, Nmodes = fourier.fourier_grid_to_Pk(rhs_fourier, MAS_index)
+        Pk *= np.float32(
+            (param["boxlen"] / n**2) ** 3 / (1.5 * param["aexp"] * param["Om_m"]) ** 2
+            / param["parametrized_mu_z"] ** 2
+        )
+        k *= np.float32(2 * np.pi / param["boxlen"])
+        iostream.write_power_spectrum_to_ascii_file(k, Pk, Nmodes, param)
+    ctx.call("pm_greens", kind, p, L.ptr(rhs_fourier), L.hptr(k2), L.hptr(s), c0)
+    ctx.call("pm_fft_c2r", L.ptr(rhs_fourier), L.ptr(phi))
     return phi

@@ -27,12 +27,48 @@ def set_units(param) -> None:
     param["mpart"] = param["unit_d"] * param["unit_l"] ** 3 / param["npart"]
 
 
+# max|acc|, max|vel| left in a context by the fused gather+kick kernel (pm_interp_kick); consumed by
+# the next integrate()'s dt criteria instead of two more passes over the particle arrays.
+_fused_maxabs = None
+
+
+def _tensor_key(t):
+    return (t.data_ptr(), t._version, t.numel())
+
+
+def register_fused_maxabs(ctx, acc, vel) -> None:
+    global _fused_maxabs
+    _fused_maxabs = None if acc is None else {
+        "ctx": ctx, "acc": _tensor_key(acc), "vel": None if vel is None else _tensor_key(vel), "values": None}
+
+
+def _lookup_fused_maxabs(x):
+    import ctypes as C
+
+    f = _fused_maxabs
+    if f is None or not L.is_device_array(x):
+        return None
+    key = _tensor_key(x)
+    which = 0 if key == f["acc"] else (1 if key == f["vel"] else None)
+    if which is None:
+        return None
+    if f["values"] is None:
+        a, v = C.c_float(0), C.c_float(0)
+        f["ctx"].call("pm_last_maxabs", C.byref(a), C.byref(v))
+        f["values"] = (np.float32(a.value), np.float32(v.value))
+    return f["values"][which]
+
+
 def _inplace(y, fn):
     """Run fn(device_tensor) and write the result back if y was a NumPy array."""
+    global _fused_maxabs
     torch = L.require_gpu()
     if L.is_device_array(y):
         if not y.is_contiguous() or y.dtype != torch.float32:
             raise ValueError("device arrays must be contiguous float32")
+        f = _fused_maxabs
+        if f is not None and y.data_ptr() in (f["acc"][0], f["vel"][0] if f["vel"] else None):
+            _fused_maxabs = None  # the array is about to change under the cached maxima
         fn(y)
     else:
         t = L.to_device(y, torch.float32)
@@ -49,13 +85,13 @@ def add_vector_scalar_inplace(y, x, a) -> None:
     torch = L.require_gpu()
     xd = L.to_device(x, torch.float32)
     ctx = _ctx()
-    _inplace(y, lambda t: L.check(ctx.lib.pm_axpy(ctx.handle, L.ptr(t), L.ptr(xd), float(np.float32(a)), t.numel())))
+    _inplace(y, lambda t: ctx.call("pm_axpy", L.ptr(t), L.ptr(xd), float(np.float32(a)), t.numel()))
 
 
 def prod_vector_scalar_inplace(y, a) -> None:
     """y *= a (utils.py:410)."""
     ctx = _ctx()
-    _inplace(y, lambda t: L.check(ctx.lib.pm_scale(ctx.handle, L.ptr(t), float(np.float32(a)), t.numel())))
+    _inplace(y, lambda t: ctx.call("pm_scale", L.ptr(t), float(np.float32(a)), t.numel()))
 
 
 def linear_operator(x, f1, f2):
@@ -64,16 +100,16 @@ def linear_operator(x, f1, f2):
     xd = L.to_device(x, torch.float32)
     out = torch.empty_like(xd)
     ctx = _ctx()
-    L.check(ctx.lib.pm_linear_operator(ctx.handle, L.ptr(out), L.ptr(xd), float(np.float32(f1)),
-                                       float(np.float32(f2)), xd.numel()))
+    ctx.call("pm_linear_operator", L.ptr(out), L.ptr(xd), float(np.float32(f1)),
+                                       float(np.float32(f2)), xd.numel())
     return L.like_input(out, x)
 
 
 def linear_operator_inplace(x, f1, f2) -> None:
     """x = f1*x + f2 (utils.py:684)."""
     ctx = _ctx()
-    _inplace(x, lambda t: L.check(ctx.lib.pm_linear_operator(ctx.handle, L.ptr(t), L.ptr(t), float(np.float32(f1)),
-                                                               float(np.float32(f2)), t.numel())))
+    _inplace(x, lambda t: ctx.call("pm_linear_operator", L.ptr(t), L.ptr(t), float(np.float32(f1)),
+                                                               float(np.float32(f2)), t.numel()))
 
 
 def linear_operator_vectors_inplace(x, f1, y, f2) -> None:
@@ -81,26 +117,29 @@ def linear_operator_vectors_inplace(x, f1, y, f2) -> None:
     torch = L.require_gpu()
     yd = L.to_device(y, torch.float32)
     ctx = _ctx()
-    _inplace(x, lambda t: L.check(ctx.lib.pm_linear_operator_vectors(ctx.handle, L.ptr(t), float(np.float32(f1)),
-                                                                       L.ptr(yd), float(np.float32(f2)), t.numel())))
+    _inplace(x, lambda t: ctx.call("pm_linear_operator_vectors", L.ptr(t), float(np.float32(f1)),
+                                                                       L.ptr(yd), float(np.float32(f2)), t.numel()))
 
 
 def max_abs(x) -> np.float32:
     """max |x| (utils.py:220); NaN propagates as in np.max(np.abs(x))."""
     import ctypes as C
 
+    cached = _lookup_fused_maxabs(x)
+    if cached is not None:
+        return cached
     torch = L.require_gpu()
     xd = L.to_device(x, torch.float32)
     ctx = _ctx()
     out = C.c_float(0)
-    L.check(ctx.lib.pm_max_abs(ctx.handle, L.ptr(xd), xd.numel(), C.byref(out)))
+    ctx.call("pm_max_abs", L.ptr(xd), xd.numel(), C.byref(out))
     return np.float32(out.value)
 
 
 def periodic_wrap(position) -> None:
     """Wrap positions into [0,1) with the reference's -2^-25 guard (utils.py:1120)."""
     ctx = _ctx()
-    _inplace(position, lambda t: L.check(ctx.lib.pm_periodic_wrap(ctx.handle, L.ptr(t), t.numel())))
+    _inplace(position, lambda t: ctx.call("pm_periodic_wrap", L.ptr(t), t.numel()))
 
 
 def reorder_particles(position, velocity=None, acceleration=None):
@@ -114,8 +153,8 @@ def reorder_particles(position, velocity=None, acceleration=None):
     po = torch.empty_like(pos)
     vo = torch.empty_like(vel) if vel is not None else None
     ao = torch.empty_like(acc) if acc is not None else None
-    L.check(ctx.lib.pm_reorder_particles(ctx.handle, pos.shape[0], L.ptr(pos), L.ptr(vel), L.ptr(acc), L.ptr(po),
-                                         L.ptr(vo), L.ptr(ao), None))
+    ctx.call("pm_reorder_particles", pos.shape[0], L.ptr(pos), L.ptr(vel), L.ptr(acc), L.ptr(po),
+                                         L.ptr(vo), L.ptr(ao), None)
     if acceleration is not None:
         return L.like_input(po, position), L.like_input(vo, velocity), L.like_input(ao, acceleration)
     if velocity is not None:
