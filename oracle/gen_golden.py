@@ -284,9 +284,169 @@ def g_integrate():
         save(f"integrate_{integ}", **rec)
 
 
+def g_multigrid():
+    """G6/G7: transfer operators (mesh.py:14-551) and the linear multigrid pieces (laplacian.py, multigrid.py)."""
+    n = 16
+    rng = np.random.default_rng(70)
+    x = rng.normal(size=(n, n, n)).astype(np.float32)
+    b = rng.normal(size=(n, n, n)).astype(np.float32)
+    xc = rng.normal(size=(n // 2,) * 3).astype(np.float32)
+    out = {"x": x, "b": b, "xc": xc}
+    out["restriction"] = mesh.restriction(x)
+    out["minus_restriction"] = mesh.minus_restriction(x)
+    out["prolongation"] = mesh.prolongation(xc)
+    y = x.copy()
+    mesh.add_prolongation(y, xc)
+    out["add_prolongation"] = y
+    out["operator"] = laplacian.operator(x)
+    out["residual"] = laplacian.residual(x, b)
+    out["restrict_residual"] = laplacian.restrict_residual(x, b)
+    out["residual_error"] = laplacian.residual_error(x, b)
+    out["truncation_error"] = laplacian.truncation_error(x)
+    out["initialise_potential"] = laplacian.initialise_potential(b)
+    y = x.copy()
+    laplacian.gauss_seidel(y, b, f32(1.25))
+    out["gauss_seidel_1"] = y
+    y = x.copy()
+    laplacian.smoothing(y, b, 3)
+    out["smoothing_3"] = y
+    # small grids: the coarsest levels of the V-cycle (4^3 and 8^3)
+    for m in (4, 8):
+        xs = rng.normal(size=(m, m, m)).astype(np.float32)
+        bs = rng.normal(size=(m, m, m)).astype(np.float32)
+        ys = xs.copy()
+        laplacian.gauss_seidel(ys, bs, f32(1.25))
+        out[f"small{m}_x"], out[f"small{m}_b"], out[f"small{m}_gs"] = xs, bs, ys
+        if m == 8:
+            out["small8_restrict_residual"] = laplacian.restrict_residual(xs, bs)
+            yp = xs.copy()
+            mesh.add_prolongation(yp, out["small4_x"])
+            out["small8_add_prolongation"] = yp
+    # one V-cycle and a converged solve on a smooth problem
+    g = (np.arange(n) + 0.5) / n
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    rhs = (np.sin(2 * np.pi * X) * np.cos(4 * np.pi * Y) + 0.5 * np.sin(6 * np.pi * Z + 1.0)
+           + 0.1 * rng.normal(size=X.shape)).astype(np.float32)
+    rhs -= rhs.mean(dtype=np.float64).astype(np.float32)
+    param = base_param(4, n**3, linear_newton_solver="multigrid")
+    param["compute_additional_field"] = False
+    phi = laplacian.initialise_potential(rhs)
+    out["vc_rhs"], out["vc_phi0"] = rhs, phi.copy()
+    multigrid.V_cycle(phi, rhs, param)
+    out["vc_phi1"] = phi.copy()
+    phi = out["vc_phi0"].copy()
+    ncyc = [0]
+    orig = multigrid.V_cycle
+
+    def counting(*a, **k):
+        if len(a) < 4 and "nlevel" not in k:
+            ncyc[0] += 1
+        return orig(*a, **k)
+
+    multigrid.V_cycle = counting
+    phi = multigrid.linear(phi, rhs, param)
+    multigrid.V_cycle = orig
+    out["lin_phi"], out["lin_cycles"], out["lin_tolerance"] = phi, ncyc[0], f32(param["tolerance"])
+    out["lin_param_json"] = np.array(param_to_json(param))
+    save("multigrid_n16", **out)
+
+
+def fr_param(ncoarse, npart, **kw):
+    return base_param(ncoarse, npart, theory="fr", fR_n=1, fR_logfR0=5, linear_newton_solver="multigrid",
+                      boxlen=1000.0, **kw)
+
+
+def g_cubic():
+    """G8: f(R) n=1 operator pieces (cubic.py) and the FAS cycle (multigrid.py:88-138, 521-579)."""
+    n = 16
+    rng = np.random.default_rng(80)
+    # the regime solver.py:334-348 produces for |f_R0| = 1e-5, boxlen 1000, a = 0.5: q h^2 ~ -5.5,
+    # b = f1*rho + f2 ~ |q| (1 +- 0.4 delta); outside it cubic.initialise_potential cancels catastrophically
+    u = (1.0 + 0.1 * rng.normal(size=(n, n, n))).astype(np.float32)
+    b = (1415.0 + 170.0 * rng.normal(size=(n, n, n))).astype(np.float32)
+    rhs = (0.05 * rng.normal(size=(n, n, n))).astype(np.float32)
+    q = f32(-1415.0)
+    out = {"u": u, "b": b, "rhs": rhs, "q": q}
+    with np.errstate(all="ignore"):
+        out["operator"] = cubic.operator(u, b, q)
+        out["residual_with_rhs"] = cubic.residual_with_rhs(u, b, q, rhs)
+        out["initialise_potential"] = cubic.initialise_potential(b, q)
+        P, D = np.meshgrid(np.linspace(-3, 3, 41), np.linspace(-6, 6, 41), indexing="ij")
+        pd_ = np.stack([P.ravel(), D.ravel()], axis=1).astype(np.float32)
+        out["root_pd"] = pd_
+        out["root"] = np.array([cubic.solution_cubic_equation(f32(p), f32(d)) for p, d in pd_], dtype=np.float32)
+        y = u.copy()
+        cubic.gauss_seidel(y, b, q, f32(1.25))
+        out["gauss_seidel"] = y
+        y = u.copy()
+        cubic.gauss_seidel_with_rhs(y, b, q, rhs, f32(1.25))
+        out["gauss_seidel_with_rhs"] = y
+        out["residual_error"] = cubic.residual_error(u, b, q)
+        out["truncation_error"] = cubic.truncation_error(u, b, q)
+    save("cubic_n16", **out)
+
+
+def g_mond():
+    """G9: QUMOND interpolating functions and source-term stencils (mond.py)."""
+    n = 16
+    rng = np.random.default_rng(90)
+    pot = rng.normal(size=(n, n, n)).astype(np.float32)
+    ys = np.array([1e-3, 0.05, 0.3, 1.0, 2.5, 10.0, 300.0], dtype=np.float32)
+    out = {"pot": pot, "ys": ys, "g0": f32(7.5)}
+    out["nu_simple"] = np.array([mond.nu_simple(y) for y in ys], dtype=np.float32)
+    out["nu_n2"] = np.array([mond.nu_n(y, 2) for y in ys], dtype=np.float32)
+    out["nu_beta"] = np.array([mond.nu_beta(y, f32(1.3)) for y in ys], dtype=np.float32)
+    out["nu_gamma"] = np.array([mond.nu_gamma(y, f32(1.3)) for y in ys], dtype=np.float32)
+    out["nu_delta"] = np.array([mond.nu_delta(y, f32(1.3)) for y in ys], dtype=np.float32)
+    for name, fn, kw in (("simple", mond.rhs_simple, {}), ("n", mond.rhs_n, {"n": 2}),
+                         ("beta", mond.rhs_beta, {"beta": f32(1.3)}), ("gamma", mond.rhs_gamma, {"gamma": f32(1.3)}),
+                         ("delta", mond.rhs_delta, {"delta": f32(1.3)})):
+        o = np.empty_like(pot)
+        fn(pot, o, out["g0"], **kw)
+        out["rhs_" + name] = o
+    save("mond_n16", **out)
+
+
+def g_pm_mg():
+    """G12 (multigrid / f(R) / MOND rows): solver.pm end-to-end, two consecutive calls each so that the
+    warm-start branches (solver.py:273-280) are pinned too."""
+    n, nc = 32, 5
+    pos, _ = particles_lattice(50, n, 0.8)
+    cases = (
+        ("newton_multigrid", base_param(nc, n**3, linear_newton_solver="multigrid")),
+        ("fr_multigrid", fr_param(nc, n**3)),
+        ("mond_multigrid", base_param(nc, n**3, theory="mond", mond_function="simple", mond_g0=1.2, mond_alpha=1,
+                                      mond_scale_factor_exponent=0, linear_newton_solver="multigrid")),
+        ("mond_fft7pt", base_param(nc, n**3, theory="mond", mond_function="simple", mond_g0=1.2, mond_alpha=1,
+                                   mond_scale_factor_exponent=0, linear_newton_solver="fft_7pt")),
+    )
+    tables = synth_tables()
+    for tag, param in cases:
+        p0 = np.array(param_to_json(param))
+        with np.errstate(all="ignore"):
+            acc, pot, extra = solver.pm(pos, param, tables=tables)
+            rec = {"pos": pos, "param0_json": p0, "acc1": acc.copy(), "pot1": pot.copy(), "extra1": extra.copy(),
+                   "param1_json": np.array(param_to_json(param))}
+            # second call, warm start from (pot, extra), one step later
+            param["nsteps"] = 1
+            param["aexp_old"] = param["aexp"]
+            param["aexp"] = 0.51
+            utils.set_units(param)
+            pos2 = pos.copy()
+            pos2 += f32(0.2 / n) * np.sin(2 * np.pi * pos[:, ::-1]).astype(np.float32)
+            utils.periodic_wrap(pos2)
+            acc, pot, extra = solver.pm(pos2, param, pot, extra, tables)
+        rec.update(pos2=pos2, acc2=acc, pot2=pot, extra2=extra, param2_json=np.array(param_to_json(param)))
+        assert np.isfinite(acc).all(), tag
+        print("   ", tag, "finite; |acc|max", np.abs(acc).max(), "extra range",
+              (extra.min(), extra.max()) if extra.size else None)
+        save("pm_" + tag, **rec)
+
+
 GROUPS = {
     "deposit": g_deposit, "kspace": g_kspace, "gradient": g_gradient, "utils": g_utils,
     "pm_newton": g_pm_newton, "pk_pm": g_pk_pm, "integrate": g_integrate,
+    "multigrid": g_multigrid, "cubic": g_cubic, "mond": g_mond, "pm_mg": g_pm_mg,
 }
 
 if __name__ == "__main__":

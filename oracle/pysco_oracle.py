@@ -28,8 +28,8 @@ _fp = C.POINTER(C.c_float)
 def build(force: bool = False) -> None:
     """Compile the C restatement (gcc, a second or two)."""
     out = os.path.join(_HERE, "_build", "libpm_oracle.so")
-    src = os.path.join(_HERE, "pm_oracle.c")
-    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("pm_oracle.c", "pm_oracle_mg.c", "Makefile")]
+    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
@@ -42,7 +42,9 @@ def _lib(omp: bool = False):
         build()
         name = "libpm_oracle_omp.so" if omp else "libpm_oracle.so"
         lib = C.CDLL(os.path.join(_HERE, "_build", name))
-        lib.pmo_max_abs.restype = C.c_float
+        for fn in ("pmo_max_abs", "pmo_lap_residual_error", "pmo_diff_norm", "pmo_cubic_residual_error",
+                   "pmo_cubic_solution", "pmo_mond_nu"):
+            getattr(lib, fn).restype = C.c_float
         lib.pmo_num_threads.restype = C.c_int
         _libs[key] = lib
     return _libs[key]
@@ -412,26 +414,6 @@ def rhs_poisson_full(density, additional_field, param) -> None:  # solver.py:381
         rhs_poisson(density, additional_field, param)
 
 
-def _fr_additional_field(*a):  # filled in below once the multigrid oracle exists
-    raise NotImplementedError("f(R) oracle not built yet")
-
-
-def _mond_additional_field(*a):
-    raise NotImplementedError("MOND oracle not built yet")
-
-
-def _mond_rhs(*a):
-    raise NotImplementedError("MOND oracle not built yet")
-
-
-def initialise_potential(*a):
-    raise NotImplementedError("multigrid oracle not built yet")
-
-
-def mg_linear(*a):
-    raise NotImplementedError("multigrid oracle not built yet")
-
-
 def fr_half_c2(param):  # solver.py:167-179
     c = 299792458.0
     Rbar = 3 * param["Om_m"] * param["aexp"] ** (-3) + 12 * param["Om_lambda"]
@@ -490,3 +472,288 @@ def integrate(position, velocity, acceleration, potential, additional_field, tab
     else:
         raise NotImplementedError("ERROR: Integrator must be 'leapfrog' or 'euler'")
     return position, velocity, acceleration, potential, additional_field
+
+
+# ------------------------------------------------------------------ multigrid pieces (laplacian.py, mesh.py)
+
+
+def restriction(x) -> np.ndarray:  # mesh.py:14
+    x = _c32(x)
+    n = x.shape[0]
+    out = np.empty((n // 2,) * 3, np.float32)
+    _lib(_use_omp).pmo_restriction(_p(x), C.c_int(n), C.c_float(0.125), _p(out))
+    return out
+
+
+def minus_restriction(x) -> np.ndarray:  # mesh.py:63
+    x = _c32(x)
+    n = x.shape[0]
+    out = np.empty((n // 2,) * 3, np.float32)
+    _lib(_use_omp).pmo_restriction(_p(x), C.c_int(n), C.c_float(-0.125), _p(out))
+    return out
+
+
+def prolongation(x) -> np.ndarray:  # mesh.py:206
+    x = _c32(x)
+    nc = x.shape[0]
+    y = np.empty((2 * nc,) * 3, np.float32)
+    _lib(_use_omp).pmo_prolongation(_p(y), _p(x), C.c_int(nc), C.c_int(0))
+    return y
+
+
+def add_prolongation(y, x) -> None:  # mesh.py:334
+    assert y.dtype == np.float32 and y.flags.c_contiguous
+    x = _c32(x)
+    _lib(_use_omp).pmo_prolongation(_p(y), _p(x), C.c_int(x.shape[0]), C.c_int(1))
+
+
+def lap_operator(x) -> np.ndarray:  # laplacian.py:12
+    x = _c32(x)
+    out = np.empty_like(x)
+    _lib(_use_omp).pmo_lap_operator(_p(x), None, C.c_int(x.shape[0]), C.c_int(0), _p(out))
+    return out
+
+
+def lap_residual(x, b) -> np.ndarray:  # laplacian.py:63
+    x, b = _c32(x), _c32(b)
+    out = np.empty_like(x)
+    _lib(_use_omp).pmo_lap_operator(_p(x), _p(b), C.c_int(x.shape[0]), C.c_int(1), _p(out))
+    return out
+
+
+def lap_restrict_residual(x, b) -> np.ndarray:  # laplacian.py:125
+    x, b = _c32(x), _c32(b)
+    n = x.shape[0]
+    out = np.empty((n // 2,) * 3, np.float32)
+    _lib(_use_omp).pmo_lap_restrict_residual(_p(x), _p(b), C.c_int(n), _p(out))
+    return out
+
+
+def lap_residual_error(x, b) -> np.float32:  # laplacian.py:327
+    x, b = _c32(x), _c32(b)
+    return np.float32(_lib(False).pmo_lap_residual_error(_p(x), _p(b), C.c_int(x.shape[0])))
+
+
+def _diff_norm(a, b, f) -> np.float32:
+    a, b = _c32(a), _c32(b)
+    return np.float32(_lib(False).pmo_diff_norm(_p(a), _p(b), C.c_float(f), C.c_int64(a.size)))
+
+
+def lap_truncation_error(x) -> np.float32:  # laplacian.py:502
+    return _diff_norm(restriction(lap_operator(x)), lap_operator(restriction(x)), 1.0)
+
+
+def lap_initialise_potential(b) -> np.ndarray:  # laplacian.py:765
+    b = _c32(b)
+    out = np.empty_like(b)
+    _lib(_use_omp).pmo_lap_initialise_potential(_p(b), C.c_int(b.shape[0]), _p(out))
+    return out
+
+
+def lap_gauss_seidel(x, b, f_relax) -> None:  # laplacian.py:844
+    assert x.dtype == np.float32 and x.flags.c_contiguous
+    b = _c32(b)
+    _lib(_use_omp).pmo_lap_gauss_seidel(_p(x), _p(b), C.c_int(x.shape[0]), C.c_float(f_relax))
+
+
+def lap_smoothing(x, b, n_smoothing) -> None:  # laplacian.py:1026
+    for _ in range(int(n_smoothing)):
+        lap_gauss_seidel(x, b, np.float32(1.25))
+
+
+# ------------------------------------------------------------------ cubic.py (f(R), n = 1)
+
+
+def cubic_operator(x, b, q) -> np.ndarray:  # cubic.py:23
+    x, b = _c32(x), _c32(b)
+    out = np.empty_like(x)
+    _lib(_use_omp).pmo_cubic_operator(_p(x), _p(b), C.c_float(q), None, C.c_int(x.shape[0]), _p(out))
+    return out
+
+
+def cubic_residual_with_rhs(x, b, q, rhs) -> np.ndarray:  # cubic.py:90
+    x, b, rhs = _c32(x), _c32(b), _c32(rhs)
+    out = np.empty_like(x)
+    _lib(_use_omp).pmo_cubic_operator(_p(x), _p(b), C.c_float(q), _p(rhs), C.c_int(x.shape[0]), _p(out))
+    return out
+
+
+def solution_cubic_equation(p, d1) -> np.float32:  # cubic.py:162
+    return np.float32(_lib(False).pmo_cubic_solution(C.c_float(p), C.c_float(d1)))
+
+
+def cubic_initialise_potential(b, q) -> np.ndarray:  # cubic.py:217
+    b = _c32(b)
+    out = np.empty_like(b)
+    _lib(_use_omp).pmo_cubic_initialise_potential(_p(b), C.c_float(q), C.c_int(b.shape[0]), _p(out))
+    return out
+
+
+def cubic_gauss_seidel(x, b, q, f_relax, rhs=None) -> None:  # cubic.py:269 / :446
+    assert x.dtype == np.float32 and x.flags.c_contiguous
+    b = _c32(b)
+    r = None if rhs is None else _c32(rhs)
+    _lib(_use_omp).pmo_cubic_gauss_seidel(_p(x), _p(b), C.c_float(q), None if r is None else _p(r),
+                                          C.c_int(x.shape[0]), C.c_float(f_relax))
+
+
+def cubic_smoothing(x, b, q, n_smoothing, rhs=None) -> None:  # cubic.py:1065 / :1100
+    for _ in range(int(n_smoothing)):
+        cubic_gauss_seidel(x, b, q, np.float32(1.25), rhs)
+
+
+def cubic_residual_error(x, b, q) -> np.float32:  # cubic.py:844
+    x, b = _c32(x), _c32(b)
+    return np.float32(_lib(False).pmo_cubic_residual_error(_p(x), _p(b), C.c_float(q), C.c_int(x.shape[0])))
+
+
+def cubic_truncation_error(x, b, q) -> np.float32:  # cubic.py:1021
+    RLx = restriction(cubic_operator(x, b, q))
+    LRx = cubic_operator(restriction(x), restriction(b), q)
+    return _diff_norm(RLx, LRx, 4.0)
+
+
+# ------------------------------------------------------------------ mond.py
+
+_MOND_KIND = {"simple": 0, "n": 1, "beta": 2, "gamma": 3, "delta": 4}
+
+
+def mond_nu(y, kind: str, alpha=1.0) -> np.float32:  # mond.py:16-162
+    return np.float32(_lib(False).pmo_mond_nu(C.c_float(y), C.c_int(_MOND_KIND[kind]), C.c_float(alpha)))
+
+
+def mond_rhs(potential, out, g0, kind: str, alpha=1.0) -> None:  # mond.py:171-932
+    assert out.dtype == np.float32 and out.flags.c_contiguous
+    pot = _c32(potential)
+    _lib(_use_omp).pmo_mond_rhs(_p(pot), _p(out), C.c_int(pot.shape[0]), C.c_float(g0), C.c_int(_MOND_KIND[kind]),
+                                C.c_float(alpha))
+
+
+# ------------------------------------------------------------------ multigrid.py / solver.py orchestration
+
+
+def initialise_potential(potential, rhs, param, tables):  # solver.py:218-282
+    if len(potential) == 0:
+        if param["compute_additional_field"] and param["theory"].casefold() == "fr":
+            if param["fR_n"] != 1:
+                raise NotImplementedError("oracle: only f(R) n = 1")
+            return cubic_initialise_potential(rhs, param["fR_q"])
+        return lap_initialise_potential(rhs)
+    if not param["compute_additional_field"]:
+        scaling = (param["aexp"] * tables[3](np.log(param["aexp"]))
+                   / (param["aexp_old"] * tables[3](np.log(param["aexp_old"]))))
+        prod_vector_scalar_inplace(potential, scaling)
+    return potential
+
+
+def V_cycle(x, b, param, nlevel=0) -> None:  # multigrid.py:474-517
+    lap_smoothing(x, b, param["Npre"])
+    res_c = lap_restrict_residual(x, b)
+    x_corr_c = lap_initialise_potential(res_c)
+    if nlevel >= (param["ncoarse"] - 3):
+        lap_smoothing(x_corr_c, res_c, param["Npre"])
+    else:
+        V_cycle(x_corr_c, res_c, param, nlevel + 1)
+    add_prolongation(x, x_corr_c)
+    lap_smoothing(x, b, param["Npost"])
+
+
+def mg_linear(x, b, param, info: dict | None = None):  # multigrid.py:23-83
+    theory = param["theory"].casefold()
+    if param["compute_additional_field"] and theory == "fr":
+        raise ValueError("Linear should not be used for scalaron field")
+    mond_pot = (not param["compute_additional_field"]) and theory == "mond"
+    if ("tolerance" not in param) or (param["nsteps"] % 3) == 0:
+        tolerance = param["epsrel"] * lap_truncation_error(x)
+        param["tolerance_mond" if mond_pot else "tolerance"] = tolerance
+    tolerance = param["tolerance_mond"] if mond_pot else param["tolerance"]
+    residual_err = 1e30
+    cycles = 0
+    while residual_err > tolerance:
+        V_cycle(x, b, param)
+        cycles += 1
+        tmp = lap_residual_error(x, b)
+        if tmp < tolerance or residual_err / tmp < 2:
+            break
+        residual_err = tmp
+    if info is not None:
+        info["cycles"] = cycles
+    return x
+
+
+def V_cycle_FAS(x, b, param, nlevel=0, rhs=None) -> None:  # multigrid.py:521-579 (f(R) n=1 branch)
+    q = np.float32(param["fR_q"])
+    cubic_smoothing(x, b, q, param["Npre"], rhs)
+    if rhs is None:
+        res_c = minus_restriction(cubic_operator(x, b, q))
+    else:
+        res_c = restriction(cubic_residual_with_rhs(x, b, q, rhs))
+    x_c = restriction(x)
+    x_corr_c = x_c.copy()
+    b_c = restriction(b)
+    L_c = cubic_operator(x_c, b_c, q)
+    linear_operator_vectors_inplace(res_c, np.float32(4), L_c, np.float32(1))
+    if nlevel >= (param["ncoarse"] - 3):
+        cubic_smoothing(x_corr_c, b_c, q, param["Npre"], res_c)
+    else:
+        V_cycle_FAS(x_corr_c, b_c, param, nlevel + 1, res_c)
+    add_vector_scalar_inplace(x_corr_c, x_c, np.float32(-1))
+    add_prolongation(x, x_corr_c)
+    cubic_smoothing(x, b, q, param["Npost"], rhs)
+
+
+def FAS(x, b, param, info: dict | None = None):  # multigrid.py:88-138
+    q = np.float32(param["fR_q"])
+    if ("tolerance_FAS" not in param) or (param["nsteps"] % 3) == 0:
+        param["tolerance_FAS"] = param["epsrel"] * cubic_truncation_error(x, b, q)
+    tolerance = param["tolerance_FAS"]
+    residual_err = 1e30
+    cycles = 0
+    while residual_err > tolerance:
+        V_cycle_FAS(x, b, param)
+        cycles += 1
+        tmp = cubic_residual_error(x, b, q)
+        if tmp < tolerance or residual_err / tmp < 2:
+            break
+        residual_err = tmp
+    if info is not None:
+        info["cycles"] = cycles
+    return x
+
+
+def _fr_additional_field(additional_field, density, param, tables):  # solver.py:326-359
+    c = 299792458.0
+    Rbar = 3 * param["Om_m"] * param["aexp"] ** (-3) + 12 * param["Om_lambda"]
+    Rbar0 = 3 * param["Om_m"] + 12 * param["Om_lambda"]
+    fR_a = -param["aexp"] ** 2 * ((Rbar0 / Rbar) ** (param["fR_n"] + 1)) * 10.0 ** (-param["fR_logfR0"])
+    c2 = (c * 1e-3 * param["unit_t"] / (param["unit_l"] * param["aexp"])) ** 2
+    f1 = np.float32(param["aexp"] * param["Om_m"] / (c2 * 6)) / (-fR_a)
+    f2 = np.float32(Rbar / 3 * param["aexp"] ** 4 - param["Om_m"] * param["aexp"]) / (6 * c2) / (-fR_a)
+    dens_term = linear_operator(density, f1, f2)
+    q = np.float32(-param["aexp"] ** 4 * Rbar / (18 * c2)) / (-fR_a)
+    param["fR_q"] = q
+    additional_field = initialise_potential(additional_field, dens_term, param, tables)
+    return FAS(additional_field, dens_term, param)
+
+
+def _mond_g0(param):  # solver.py:418-425
+    return (param["mond_g0"] * 1e-3 * 1e-10 * param["unit_t"] ** 2 / param["unit_l"]
+            * param["aexp"] ** (1 + param["mond_scale_factor_exponent"]))
+
+
+def _mond_rhs(density, additional_field, param) -> None:  # solver.py:413-443
+    fn = param["mond_function"].casefold()
+    if fn not in _MOND_KIND:
+        raise NotImplementedError(f"MOND_FUNCTION={fn!r}, should be 'simple', 'n', 'beta', 'gamma' or 'delta'")
+    mond_rhs(additional_field, density, _mond_g0(param), fn, param["mond_alpha"])
+
+
+def _mond_additional_field(additional_field, density, param, tables):  # solver.py:360-374
+    rhs_poisson_full(density, additional_field, param)  # compute_additional_field is True -> linear branch
+    solver = param["linear_newton_solver"].casefold()
+    if solver == "multigrid":
+        additional_field = initialise_potential(additional_field, density, param, tables)
+        return mg_linear(additional_field, density, param)
+    if solver == "fft_7pt":
+        return fft(density, param)
+    raise NotImplementedError(f"{param['linear_newton_solver']=}, should be 'multigrid' or 'fft_7pt'")

@@ -156,3 +156,123 @@ def test_integrate(golden, integ, nsteps):
             d = np.minimum(d, 1 - d)
             assert d.max() <= 1e-5  # positions after 10 steps max |dx| <= 1e-5 box units
             np.testing.assert_allclose(v, g[f"vel_{s+1}"], rtol=0, atol=1e-5 * _scale(g[f"vel_{s+1}"]))
+
+
+def test_transfer_and_laplacian_bit_exact(golden):
+    g = golden("multigrid_n16")
+    x, b, xc = g["x"], g["b"], g["xc"]
+    np.testing.assert_array_equal(orc.restriction(x), g["restriction"])
+    np.testing.assert_array_equal(orc.minus_restriction(x), g["minus_restriction"])
+    np.testing.assert_array_equal(orc.prolongation(xc), g["prolongation"])
+    y = x.copy()
+    orc.add_prolongation(y, xc)
+    np.testing.assert_array_equal(y, g["add_prolongation"])
+    np.testing.assert_array_equal(orc.lap_operator(x), g["operator"])
+    np.testing.assert_array_equal(orc.lap_residual(x, b), g["residual"])
+    np.testing.assert_array_equal(orc.lap_restrict_residual(x, b), g["restrict_residual"])
+    np.testing.assert_array_equal(orc.lap_initialise_potential(b), g["initialise_potential"])
+    y = x.copy()
+    orc.lap_gauss_seidel(y, b, np.float32(1.25))
+    np.testing.assert_array_equal(y, g["gauss_seidel_1"])
+    y = x.copy()
+    orc.lap_smoothing(y, b, 3)
+    np.testing.assert_array_equal(y, g["smoothing_3"])
+    # norms: the interpreter squares through powf (1-ulp artefacts), fp32 sequential accumulation
+    np.testing.assert_allclose(orc.lap_residual_error(x, b), g["residual_error"], rtol=2e-6)
+    np.testing.assert_allclose(orc.lap_truncation_error(x), g["truncation_error"], rtol=2e-6)
+    for m in (4, 8):
+        y = g[f"small{m}_x"].copy()
+        orc.lap_gauss_seidel(y, g[f"small{m}_b"], np.float32(1.25))
+        np.testing.assert_array_equal(y, g[f"small{m}_gs"])
+    np.testing.assert_array_equal(orc.lap_restrict_residual(g["small8_x"], g["small8_b"]), g["small8_restrict_residual"])
+    y = g["small8_x"].copy()
+    orc.add_prolongation(y, g["small4_x"])
+    np.testing.assert_array_equal(y, g["small8_add_prolongation"])
+
+
+def test_linear_multigrid(golden):
+    from tests.helpers import param_from_json
+
+    g = golden("multigrid_n16")
+    param = param_from_json(g["lin_param_json"])
+    param.pop("tolerance", None)
+    phi = g["vc_phi0"].copy()
+    orc.V_cycle(phi, g["vc_rhs"], param)
+    np.testing.assert_array_equal(phi, g["vc_phi1"])  # whole V-cycle bit-exact
+    phi = g["vc_phi0"].copy()
+    info = {}
+    phi = orc.mg_linear(phi, g["vc_rhs"], param, info)
+    assert info["cycles"] == int(g["lin_cycles"])
+    np.testing.assert_allclose(param["tolerance"], g["lin_tolerance"], rtol=1e-5)
+    np.testing.assert_array_equal(phi, g["lin_phi"])
+
+
+def test_cubic(golden):
+    g = golden("cubic_n16")
+    u, b, rhs, q = g["u"], g["b"], g["rhs"], np.float32(g["q"])
+    s = float(np.abs(g["operator"]).max())
+    np.testing.assert_allclose(orc.cubic_operator(u, b, q), g["operator"], rtol=0, atol=3e-6 * s)
+    np.testing.assert_allclose(orc.cubic_residual_with_rhs(u, b, q, rhs), g["residual_with_rhs"], rtol=0, atol=3e-6 * s)
+    ip, ipg = orc.cubic_initialise_potential(b, q), g["initialise_potential"]
+    assert np.array_equal(np.isnan(ip), np.isnan(ipg))
+    np.testing.assert_allclose(ip[~np.isnan(ip)], ipg[~np.isnan(ipg)], rtol=2e-5)
+    roots = np.array([orc.solution_cubic_equation(p, d) for p, d in g["root_pd"]], dtype=np.float32)
+    ref = g["root"]
+    assert np.array_equal(np.isnan(roots), np.isnan(ref))  # same NaN branch structure (cubic.py:192-197)
+    ok = ~np.isnan(ref)
+    np.testing.assert_allclose(roots[ok], ref[ok], rtol=2e-6, atol=1e-6)
+    y = u.copy()
+    orc.cubic_gauss_seidel(y, b, q, np.float32(1.25))
+    np.testing.assert_allclose(y, g["gauss_seidel"], rtol=0, atol=5e-6)
+    y = u.copy()
+    orc.cubic_gauss_seidel(y, b, q, np.float32(1.25), rhs)
+    np.testing.assert_allclose(y, g["gauss_seidel_with_rhs"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(orc.cubic_residual_error(u, b, q), g["residual_error"], rtol=1e-5)
+    np.testing.assert_allclose(orc.cubic_truncation_error(u, b, q), g["truncation_error"], rtol=1e-4)
+
+
+def test_mond(golden):
+    g = golden("mond_n16")
+    ys = g["ys"]
+    for name, kind, alpha in (("nu_simple", "simple", 1), ("nu_n2", "n", 2), ("nu_beta", "beta", 1.3),
+                              ("nu_gamma", "gamma", 1.3), ("nu_delta", "delta", 1.3)):
+        got = np.array([orc.mond_nu(y, kind, alpha) for y in ys], dtype=np.float32)
+        np.testing.assert_allclose(got, g[name], rtol=5e-6, err_msg=name)
+    for name, alpha in (("simple", 1), ("n", 2), ("beta", 1.3), ("gamma", 1.3), ("delta", 1.3)):
+        out = np.empty_like(g["pot"])
+        orc.mond_rhs(g["pot"], out, np.float32(g["g0"]), name, alpha)
+        ref = g["rhs_" + name]
+        np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5 * float(np.abs(ref).max()), err_msg=name)
+
+
+PM_MG = ["newton_multigrid", "fr_multigrid", "mond_multigrid", "mond_fft7pt"]
+
+
+@pytest.mark.parametrize("tag", PM_MG)
+def test_pm_multigrid_theories(golden, tag):
+    from oracle.pysco_oracle import set_units
+    from tests.helpers import param_from_json, synth_tables
+
+    g = golden("pm_" + tag)
+    tables = synth_tables()
+    param = param_from_json(g["param0_json"])
+    acc, pot, extra = orc.pm(g["pos"], param, tables=tables)
+    sa, sp = _scale(g["acc1"]), _scale(g["pot1"])
+    # iterative solves stop at epsrel * truncation error: compare at the solver's own accuracy
+    np.testing.assert_allclose(pot, g["pot1"], rtol=0, atol=2e-4 * sp)
+    np.testing.assert_allclose(acc, g["acc1"], rtol=0, atol=1e-3 * sa)
+    if g["extra1"].size:
+        np.testing.assert_allclose(extra, g["extra1"], rtol=0, atol=2e-4 * _scale(g["extra1"]))
+    else:
+        assert extra.size == 0
+    ref1 = param_from_json(g["param1_json"])
+    for key in ("tolerance", "tolerance_FAS", "tolerance_mond", "fR_q"):
+        if key in ref1:
+            np.testing.assert_allclose(float(param[key]), float(ref1[key]), rtol=1e-3, err_msg=key)
+    # second call: warm start (solver.py:273-280)
+    ref2 = param_from_json(g["param2_json"])
+    param["nsteps"], param["aexp_old"], param["aexp"] = 1, param["aexp"], 0.51
+    set_units(param)
+    acc, pot, extra = orc.pm(g["pos2"], param, pot, extra, tables)
+    np.testing.assert_allclose(pot, g["pot2"], rtol=0, atol=5e-4 * sp)
+    np.testing.assert_allclose(acc, g["acc2"], rtol=0, atol=2e-3 * sa)
