@@ -114,6 +114,37 @@ int pm_interp_kick(pm_ctx *ctx, int scheme, const float *d_force, const float *d
  * if that call had d_vel == NULL. */
 int pm_last_maxabs(pm_ctx *ctx, float *h_max_acc, float *h_max_vel);
 
+/* ---- multigrid pieces (laplacian.py, cubic.py, mond.py, mesh.py transfer operators) --------------
+ * The V-cycle recursion stays on the host (multigrid.py:474-579); every function takes the grid
+ * size `n` of the level it works on.  Norm functions return a host value and synchronise. */
+/* mesh.restriction :14 (scale = 0.125f) / mesh.minus_restriction :63 (scale = -0.125f): [nf]^3 -> [nf/2]^3 */
+int pm_restriction(pm_ctx *ctx, const float *d_x, int nf, float scale, float *d_out);
+/* mesh.prolongation :206 (add = 0) / mesh.add_prolongation :334 (add = 1): [nc]^3 -> (+=) [2nc]^3 */
+int pm_prolongation(pm_ctx *ctx, float *d_y, const float *d_xc, int nc, int add);
+/* laplacian.operator :12 (mode 0, d_b unused) / laplacian.residual :63 (mode 1: b - Ax) */
+int pm_lap_operator(pm_ctx *ctx, const float *d_x, const float *d_b, int n, int mode, float *d_out);
+/* laplacian.restrict_residual :125: fused residual + restriction, [n]^3 -> [n/2]^3 */
+int pm_lap_restrict_residual(pm_ctx *ctx, const float *d_x, const float *d_b, int n, float *d_out);
+/* laplacian.residual_error :327: sqrt(sum (b - Ax)^2) */
+int pm_lap_residual_error(pm_ctx *ctx, const float *d_x, const float *d_b, int n, float *h_out);
+/* sqrt(sum (f*a - b)^2): tail of laplacian.truncation_error :529 (f = 1) and cubic.truncation_error :1057 (f = 4) */
+int pm_diff_norm(pm_ctx *ctx, const float *d_a, const float *d_b, float f, int64_t count, float *h_out);
+/* laplacian.gauss_seidel :844: one red + one black sweep with over-relaxation f_relax, in place */
+int pm_lap_gauss_seidel(pm_ctx *ctx, float *d_x, const float *d_b, int n, float f_relax);
+/* cubic.operator :23 (d_rhs NULL) / cubic.residual_with_rhs :90 */
+int pm_cubic_operator(pm_ctx *ctx, const float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                      float *d_out);
+/* cubic.residual_error :844 */
+int pm_cubic_residual_error(pm_ctx *ctx, const float *d_x, const float *d_b, float q, int n, float *h_out);
+/* cubic.initialise_potential :217 */
+int pm_cubic_initialise_potential(pm_ctx *ctx, const float *d_b, float q, int n, float *d_out);
+/* cubic.gauss_seidel :269 (d_rhs NULL) / cubic.gauss_seidel_with_rhs :446 */
+int pm_cubic_gauss_seidel(pm_ctx *ctx, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                          float f_relax);
+/* mond.rhs_simple :171 / rhs_n :322 / rhs_beta :476 / rhs_gamma :630 / rhs_delta :784
+ * (kind 0..4; alpha = n, beta, gamma or delta): d_out = div[nu(|grad pot|/g0) grad pot] */
+int pm_mond_rhs(pm_ctx *ctx, const float *d_pot, float *d_out, int n, float g0, int kind, float alpha);
+
 #ifdef __cplusplus
 }
 #endif

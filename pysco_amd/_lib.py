@@ -52,6 +52,18 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_kick_drift_wrap": (_vp, _vp, _vp, _vp, _f, _f, _i64),
     "pm_interp_kick": (_vp, _i, _vp, _vp, _i64, _vp, _vp, _f),
     "pm_last_maxabs": (_vp, C.POINTER(_f), C.POINTER(_f)),
+    "pm_restriction": (_vp, _vp, _i, _f, _vp),
+    "pm_prolongation": (_vp, _vp, _vp, _i, _i),
+    "pm_lap_operator": (_vp, _vp, _vp, _i, _i, _vp),
+    "pm_lap_restrict_residual": (_vp, _vp, _vp, _i, _vp),
+    "pm_lap_residual_error": (_vp, _vp, _vp, _i, C.POINTER(_f)),
+    "pm_diff_norm": (_vp, _vp, _vp, _f, _i64, C.POINTER(_f)),
+    "pm_lap_gauss_seidel": (_vp, _vp, _vp, _i, _f),
+    "pm_cubic_operator": (_vp, _vp, _vp, _f, _vp, _i, _vp),
+    "pm_cubic_residual_error": (_vp, _vp, _vp, _f, _i, C.POINTER(_f)),
+    "pm_cubic_initialise_potential": (_vp, _vp, _f, _i, _vp),
+    "pm_cubic_gauss_seidel": (_vp, _vp, _vp, _f, _vp, _i, _f),
+    "pm_mond_rhs": (_vp, _vp, _vp, _i, _f, _i, _f),
 }
 _RESTYPES = {"pm_last_error": C.c_char_p}
 

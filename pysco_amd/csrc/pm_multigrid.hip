@@ -1,0 +1,509 @@
+// Grid solvers: 7-point Laplacian multigrid pieces (laplacian.py, mesh.py transfer operators), the
+// f(R) n=1 cubic operator with its per-cell fp64 root (cubic.py) and the QUMOND source stencil
+// (mond.py).  Every function takes the level's grid size explicitly: the host walks the V-cycle.
+//
+// Arithmetic: fp32 with the reference's operation order (built with -ffp-contract=off), so the
+// linear-Laplacian kernels are bit-identical to the CPU oracle; the norms accumulate in fp64.
+#include "pm_common.h"
+
+#define BLK 256
+
+__device__ __forceinline__ int64_t cidx(int i, int j, int k, int log2n) {
+    return ((((int64_t)i << log2n) + j) << log2n) + k;
+}
+
+static inline int ilog2(int n) { return __builtin_ctz((unsigned)n); }
+
+#define PM_CHECK_GRID(n) PM_REQUIRE((n) >= 2 && (n) <= 16384 && (((n) & ((n)-1)) == 0), "grid size must be a power of two")
+
+// ------------------------------------------------------------------------------------------------
+// transfer operators
+
+// mesh.py:14-60 restriction (scale 1/8), :63-110 minus_restriction (scale -1/8)
+__global__ __launch_bounds__(BLK) void restriction_kernel(const float *__restrict__ x, int log2nf, float scale,
+                                                          float *__restrict__ out) {
+    const int log2nc = log2nf - 1, nc = 1 << log2nc;
+    const int64_t total = (int64_t)nc * nc * nc;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t & (nc - 1)), j = (int)((t >> log2nc) & (nc - 1)), i = (int)(t >> (2 * log2nc));
+        const int ii = 2 * i, jj = 2 * j, kk = 2 * k;
+        const float2 a = *reinterpret_cast<const float2 *>(x + cidx(ii, jj, kk, log2nf));
+        const float2 b = *reinterpret_cast<const float2 *>(x + cidx(ii, jj + 1, kk, log2nf));
+        const float2 c = *reinterpret_cast<const float2 *>(x + cidx(ii + 1, jj, kk, log2nf));
+        const float2 d = *reinterpret_cast<const float2 *>(x + cidx(ii + 1, jj + 1, kk, log2nf));
+        out[t] = scale * (a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y);
+    }
+}
+
+extern "C" int pm_restriction(pm_ctx *c, const float *d_x, int nf, float scale, float *d_out) {
+    PM_REQUIRE(c && d_x && d_out, "NULL argument");
+    PM_CHECK_GRID(nf);
+    const int64_t total = (int64_t)(nf / 2) * (nf / 2) * (nf / 2);
+    hipLaunchKernelGGL(restriction_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_x, ilog2(nf),
+                       scale, d_out);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// mesh.py:206-330 prolongation / :334-455 add_prolongation: one thread per FINE cell
+__global__ __launch_bounds__(BLK) void prolongation_kernel(float *__restrict__ y, const float *__restrict__ xc,
+                                                           int log2nc, int add) {
+    const int log2nf = log2nc + 1, nf = 1 << log2nf, nc = 1 << log2nc, mc = nc - 1;
+    const float f0 = (float)(27.0 / 64), f1 = (float)(9.0 / 64), f2 = (float)(3.0 / 64), f3 = (float)(1.0 / 64);
+    const int64_t total = (int64_t)nf * nf * nf;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int kf = (int)(t & (nf - 1)), jf = (int)((t >> log2nf) & (nf - 1)), fi = (int)(t >> (2 * log2nf));
+        const int i = fi >> 1, j = jf >> 1, k = kf >> 1;
+        const int ia = (i + ((fi & 1) ? 1 : -1)) & mc, jb = (j + ((jf & 1) ? 1 : -1)) & mc,
+                  kd = (k + ((kf & 1) ? 1 : -1)) & mc;
+        const float tmp0 = f0 * xc[cidx(i, j, k, log2nc)];
+        const float X = xc[cidx(ia, j, k, log2nc)], Y = xc[cidx(i, jb, k, log2nc)], Z = xc[cidx(i, j, kd, log2nc)];
+        const float XY = xc[cidx(ia, jb, k, log2nc)], XZ = xc[cidx(ia, j, kd, log2nc)], YZ = xc[cidx(i, jb, kd, log2nc)];
+        const float XYZ = xc[cidx(ia, jb, kd, log2nc)];
+        const float v = tmp0 + f1 * (X + Y + Z) + f2 * (XY + XZ + YZ) + f3 * XYZ;
+        y[t] = add ? y[t] + v : v;
+    }
+}
+
+extern "C" int pm_prolongation(pm_ctx *c, float *d_y, const float *d_xc, int nc, int add) {
+    PM_REQUIRE(c && d_y && d_xc, "NULL argument");
+    PM_CHECK_GRID(nc);
+    const int64_t total = (int64_t)8 * nc * nc * nc;
+    hipLaunchKernelGGL(prolongation_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_y, d_xc,
+                       ilog2(nc), add);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 7-point Laplacian
+
+// laplacian.py:12-59 operator (mode 0) / :63-121 residual b - Ax (mode 1)
+__global__ __launch_bounds__(BLK) void lap_operator_kernel(const float *__restrict__ x, const float *__restrict__ b,
+                                                           int log2n, int mode, float invh2,
+                                                           float *__restrict__ out) {
+    const int n = 1 << log2n, m = n - 1;
+    const int64_t total = (int64_t)n * n * n;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t & m), j = (int)((t >> log2n) & m), i = (int)(t >> (2 * log2n));
+        const float s = x[cidx((i - 1) & m, j, k, log2n)] + x[cidx(i, (j - 1) & m, k, log2n)] +
+                        x[cidx(i, j, (k - 1) & m, log2n)] - 6.0f * x[t] + x[cidx(i, j, (k + 1) & m, log2n)] +
+                        x[cidx(i, (j + 1) & m, k, log2n)] + x[cidx((i + 1) & m, j, k, log2n)];
+        out[t] = mode ? (-(s)*invh2 + b[t]) : s * invh2;
+    }
+}
+
+extern "C" int pm_lap_operator(pm_ctx *c, const float *d_x, const float *d_b, int n, int mode, float *d_out) {
+    PM_REQUIRE(c && d_x && d_out && (mode == 0 || d_b), "NULL argument");
+    PM_CHECK_GRID(n);
+    const int64_t total = (int64_t)n * n * n;
+    hipLaunchKernelGGL(lap_operator_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_x, d_b,
+                       ilog2(n), mode, (float)((double)n * n), d_out);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// laplacian.py:125-226 restrict_residual: fused residual + 1/8 restriction, reference summation order
+__global__ __launch_bounds__(BLK) void lap_restrict_residual_kernel(const float *__restrict__ x,
+                                                                    const float *__restrict__ b, int log2n,
+                                                                    float invh2, float *__restrict__ out) {
+    const int n = 1 << log2n, m = n - 1, log2nc = log2n - 1, nc = n >> 1;
+    const int64_t total = (int64_t)nc * nc * nc;
+#define X(a, bb, cc) x[cidx((a)&m, (bb)&m, (cc)&m, log2n)]
+#define B(a, bb, cc) b[cidx(a, bb, cc, log2n)]
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t & (nc - 1)), j = (int)((t >> log2nc) & (nc - 1)), i = (int)(t >> (2 * log2nc));
+        const int ii = 2 * i, jj = 2 * j, kk = 2 * k;
+        const int m1 = ii - 1, p1 = ii + 1, p2 = ii + 2, jm1 = jj - 1, jp1 = jj + 1, jp2 = jj + 2, km1 = kk - 1,
+                  kp1 = kk + 1, kp2 = kk + 2;
+        const float s = +X(m1, jj, kk) + X(m1, jj, kp1) + X(m1, jp1, kk) + X(m1, jp1, kp1) + X(ii, jm1, kk) +
+                        X(ii, jm1, kp1) + X(ii, jj, km1) + X(ii, jj, kp2) + X(ii, jp1, km1) + X(ii, jp1, kp2) +
+                        X(ii, jp2, kk) + X(ii, jp2, kp1) + X(p1, jm1, kk) + X(p1, jm1, kp1) + X(p1, jj, km1) +
+                        X(p1, jj, kp2) + X(p1, jp1, km1) + X(p1, jp1, kp2) + X(p1, jp2, kk) + X(p1, jp2, kp1) +
+                        X(p2, jj, kk) + X(p2, jj, kp1) + X(p2, jp1, kk) + X(p2, jp1, kp1) -
+                        3.0f * (X(ii, jj, kk) + X(ii, jj, kp1) + X(ii, jp1, kk) + X(ii, jp1, kp1) + X(p1, jj, kk) +
+                                X(p1, jj, kp1) + X(p1, jp1, kk) + X(p1, jp1, kp1));
+        out[t] = 0.125f * (-(s)*invh2 + B(ii, jj, kk) + B(ii, jj, kp1) + B(ii, jp1, kk) + B(ii, jp1, kp1) +
+                           B(p1, jj, kk) + B(p1, jj, kp1) + B(p1, jp1, kk) + B(p1, jp1, kp1));
+    }
+#undef X
+#undef B
+}
+
+extern "C" int pm_lap_restrict_residual(pm_ctx *c, const float *d_x, const float *d_b, int n, float *d_out) {
+    PM_REQUIRE(c && d_x && d_b && d_out, "NULL argument");
+    PM_CHECK_GRID(n);
+    const int64_t total = (int64_t)(n / 2) * (n / 2) * (n / 2);
+    hipLaunchKernelGGL(lap_restrict_residual_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_x,
+                       d_b, ilog2(n), (float)((double)n * n), d_out);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// block-level fp64 sum -> one atomicAdd(double) per workgroup
+__device__ __forceinline__ void block_sum_to(double v, double *result) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __shared__ double ws[BLK / 64];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BLK / 64; ++w) v += ws[w];
+        atomicAdd(result, v);
+    }
+}
+
+static int read_norm(pm_ctx *c, float *h_out) {
+    double s = 0;
+    PM_HIP(hipMemcpyAsync(&s, c->d_hist, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
+    *h_out = (float)sqrt(s);
+    return PM_OK;
+}
+
+// laplacian.py:327-381 residual_error = sqrt(sum (b - Ax)^2)
+__global__ __launch_bounds__(BLK) void lap_residual_error_kernel(const float *__restrict__ x,
+                                                                 const float *__restrict__ b, int log2n, float invh2,
+                                                                 double *__restrict__ result) {
+    const int n = 1 << log2n, m = n - 1;
+    const int64_t total = (int64_t)n * n * n;
+    double acc = 0;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t & m), j = (int)((t >> log2n) & m), i = (int)(t >> (2 * log2n));
+        const float s = +x[cidx((i - 1) & m, j, k, log2n)] + x[cidx(i, j, (k - 1) & m, log2n)] +
+                        x[cidx(i, j, (k + 1) & m, log2n)] + x[cidx(i, (j - 1) & m, k, log2n)] - 6.0f * x[t] +
+                        x[cidx(i, (j + 1) & m, k, log2n)] + x[cidx((i + 1) & m, j, k, log2n)];
+        const float r = -(s)*invh2 + b[t];
+        acc += (double)(r * r);
+    }
+    block_sum_to(acc, result);
+}
+
+extern "C" int pm_lap_residual_error(pm_ctx *c, const float *d_x, const float *d_b, int n, float *h_out) {
+    PM_REQUIRE(c && d_x && d_b && h_out, "NULL argument");
+    PM_CHECK_GRID(n);
+    PM_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(double), c->stream));
+    const int64_t total = (int64_t)n * n * n;
+    int blocks = pm_stream_blocks(total, BLK * 4);
+    hipLaunchKernelGGL(lap_residual_error_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n),
+                       (float)((double)n * n), c->d_hist);
+    PM_LAUNCH_CHECK();
+    return read_norm(c, h_out);
+}
+
+// sqrt(sum (f*a - b)^2): tail of laplacian.truncation_error :529-532 (f=1), cubic.truncation_error :1057-1061 (f=4)
+__global__ __launch_bounds__(BLK) void diff_norm_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                        float f, int64_t count, double *__restrict__ result) {
+    double acc = 0;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < count; t += (int64_t)gridDim.x * BLK) {
+        const float d = f * a[t] - b[t];
+        acc += (double)(d * d);
+    }
+    block_sum_to(acc, result);
+}
+
+extern "C" int pm_diff_norm(pm_ctx *c, const float *d_a, const float *d_b, float f, int64_t count, float *h_out) {
+    PM_REQUIRE(c && d_a && d_b && h_out && count > 0, "bad argument");
+    PM_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(double), c->stream));
+    hipLaunchKernelGGL(diff_norm_kernel, dim3(pm_stream_blocks(count, BLK * 4)), dim3(BLK), 0, c->stream, d_a, d_b, f,
+                       count, c->d_hist);
+    PM_LAUNCH_CHECK();
+    return read_norm(c, h_out);
+}
+
+// laplacian.py:844-1022 gauss_seidel.  One launch per colour (the reference warns that its two
+// colour loops must never fuse, laplacian.py:870-871).  Thread = one 2x2x2 block; it updates the
+// four cells of the launch's colour, each with the reference's own summation order for that
+// parity class (dirs: 0 xm, 1 xp, 2 ym, 3 yp, 4 zm, 5 zp, 6 -h2*b).
+template <int O0, int O1, int O2, int O3, int O4, int O5, int O6>
+__device__ __forceinline__ void gs_cell(float *__restrict__ x, const float *__restrict__ b, int i, int j, int k, int m,
+                                        int log2n, float h2, float invsix, float f_relax) {
+    const int64_t c = cidx(i, j, k, log2n);
+    float t[7];
+    t[0] = x[cidx((i - 1) & m, j, k, log2n)];
+    t[1] = x[cidx((i + 1) & m, j, k, log2n)];
+    t[2] = x[cidx(i, (j - 1) & m, k, log2n)];
+    t[3] = x[cidx(i, (j + 1) & m, k, log2n)];
+    t[4] = x[cidx(i, j, (k - 1) & m, log2n)];
+    t[5] = x[cidx(i, j, (k + 1) & m, log2n)];
+    t[6] = -(h2 * b[c]);
+    const float s = (((((t[O0] + t[O1]) + t[O2]) + t[O3]) + t[O4]) + t[O5]) + t[O6];
+    const float xc = x[c];
+    x[c] = xc + f_relax * (s * invsix - xc);
+}
+
+template <int COLOUR>
+__global__ __launch_bounds__(BLK) void lap_gauss_seidel_kernel(float *__restrict__ x, const float *__restrict__ b,
+                                                               int log2n, float h2, float invsix, float f_relax) {
+    const int n = 1 << log2n, m = n - 1, log2nc = log2n - 1, nc = n >> 1;
+    const int64_t total = (int64_t)nc * nc * nc;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = 2 * (int)(t & (nc - 1)), j = 2 * (int)((t >> log2nc) & (nc - 1)), i = 2 * (int)(t >> (2 * log2nc));
+        if (COLOUR == 1) {  // red: i+j+k odd
+            gs_cell<5, 3, 1, 0, 2, 4, 6>(x, b, i + 1, j + 1, k + 1, m, log2n, h2, invsix, f_relax);  // 111
+            gs_cell<2, 4, 1, 0, 6, 5, 3>(x, b, i + 1, j, k, m, log2n, h2, invsix, f_relax);          // 100
+            gs_cell<0, 3, 4, 1, 2, 5, 6>(x, b, i, j + 1, k, m, log2n, h2, invsix, f_relax);          // 010
+            gs_cell<0, 2, 5, 4, 6, 3, 1>(x, b, i, j, k + 1, m, log2n, h2, invsix, f_relax);          // 001
+        } else {  // black: even
+            gs_cell<4, 3, 1, 0, 2, 6, 5>(x, b, i + 1, j + 1, k, m, log2n, h2, invsix, f_relax);      // 110
+            gs_cell<2, 5, 1, 0, 4, 6, 3>(x, b, i + 1, j, k + 1, m, log2n, h2, invsix, f_relax);      // 101
+            gs_cell<0, 5, 3, 2, 4, 6, 1>(x, b, i, j + 1, k + 1, m, log2n, h2, invsix, f_relax);      // 011
+            gs_cell<0, 2, 4, 6, 5, 3, 1>(x, b, i, j, k, m, log2n, h2, invsix, f_relax);              // 000
+        }
+    }
+}
+
+extern "C" int pm_lap_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, int n, float f_relax) {
+    PM_REQUIRE(c && d_x && d_b, "NULL argument");
+    PM_CHECK_GRID(n);
+    const int64_t total = (int64_t)(n / 2) * (n / 2) * (n / 2);
+    const int blocks = pm_stream_blocks(total, BLK);
+    const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
+    hipLaunchKernelGGL((lap_gauss_seidel_kernel<1>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), h2,
+                       invsix, f_relax);
+    hipLaunchKernelGGL((lap_gauss_seidel_kernel<0>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), h2,
+                       invsix, f_relax);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// f(R) n = 1 (cubic.py)
+
+// cubic.py:162-207 solution_cubic_equation: fp64, same branch structure (NaNs included)
+__device__ __forceinline__ double cubic_root(float pf, float d1f) {
+    const double inv3 = 1.0 / 3;
+    const double d1 = (double)d1f, p = (double)pf;
+    double d = d1 * d1 + 108.0 * (p * p * p);
+    if (d > 0.0) {
+        d = d1 + sqrt(d);
+        if (d == 0.0) return -inv3 * pow(d1, inv3);
+        const double C = pow(0.5 * d, inv3);
+        return -inv3 * (C - 3.0 * p / C);
+    } else if (d < 0.0) {
+        const double d0 = -3.0 * p;
+        d = d1 / (2.0 * pow(d0, 1.5));
+        if (fabs(d) < 1.0) {
+            const double theta = acos(d);
+            return (double)(float)(-2.0 * inv3 * sqrt(d0) * cos(inv3 * (theta + 2.0 * 3.14159265358979323846)));
+        }
+        return -inv3 * pow(d1, inv3);
+    }
+    return -inv3 * pow(d1, inv3);
+}
+
+__device__ __forceinline__ float cubic_p(const float *__restrict__ x, const float *__restrict__ b, int i, int j, int k,
+                                         int m, int log2n, float h2, float invsix) {
+    const float a0 = x[cidx((i - 1) & m, j, k, log2n)], a1 = x[cidx(i, (j - 1) & m, k, log2n)],
+                a2 = x[cidx(i, j, (k - 1) & m, log2n)], a3 = x[cidx(i, j, (k + 1) & m, log2n)],
+                a4 = x[cidx(i, (j + 1) & m, k, log2n)], a5 = x[cidx((i + 1) & m, j, k, log2n)];
+    return h2 * b[cidx(i, j, k, log2n)] - invsix * (a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5);
+}
+
+// cubic.py:23-86 operator / :90-158 residual_with_rhs (mode 1) / :844-900 residual_error (mode 2)
+template <int MODE>
+__global__ __launch_bounds__(BLK) void cubic_operator_kernel(const float *__restrict__ x, const float *__restrict__ b,
+                                                             float qh2, const float *__restrict__ rhs, int log2n,
+                                                             float h2, float invsix, float *__restrict__ out,
+                                                             double *__restrict__ result) {
+    const int n = 1 << log2n, m = n - 1;
+    const int64_t total = (int64_t)n * n * n;
+    double acc = 0;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t & m), j = (int)((t >> log2n) & m), i = (int)(t >> (2 * log2n));
+        const float p = cubic_p(x, b, i, j, k, m, log2n, h2, invsix);
+        const float xt = x[t];
+        if (MODE == 0) out[t] = xt * xt * xt + p * xt + qh2;
+        if (MODE == 1) out[t] = -(xt * xt * xt) - p * xt - qh2 + rhs[t];
+        if (MODE == 2) {
+            const float r = xt * xt * xt + p * xt + qh2;
+            acc += (double)(r * r);
+        }
+    }
+    if (MODE == 2) block_sum_to(acc, result);
+}
+
+extern "C" int pm_cubic_operator(pm_ctx *c, const float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                                 float *d_out) {
+    PM_REQUIRE(c && d_x && d_b && d_out, "NULL argument");
+    PM_CHECK_GRID(n);
+    const int64_t total = (int64_t)n * n * n;
+    const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
+    const int blocks = pm_stream_blocks(total, BLK);
+    if (d_rhs)
+        hipLaunchKernelGGL((cubic_operator_kernel<1>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, q * h2, d_rhs,
+                           ilog2(n), h2, invsix, d_out, (double *)nullptr);
+    else
+        hipLaunchKernelGGL((cubic_operator_kernel<0>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, q * h2, d_rhs,
+                           ilog2(n), h2, invsix, d_out, (double *)nullptr);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+extern "C" int pm_cubic_residual_error(pm_ctx *c, const float *d_x, const float *d_b, float q, int n, float *h_out) {
+    PM_REQUIRE(c && d_x && d_b && h_out, "NULL argument");
+    PM_CHECK_GRID(n);
+    PM_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(double), c->stream));
+    const int64_t total = (int64_t)n * n * n;
+    const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
+    hipLaunchKernelGGL((cubic_operator_kernel<2>), dim3(pm_stream_blocks(total, BLK * 4)), dim3(BLK), 0, c->stream, d_x,
+                       d_b, q * h2, (const float *)nullptr, ilog2(n), h2, invsix, (float *)nullptr, c->d_hist);
+    PM_LAUNCH_CHECK();
+    return read_norm(c, h_out);
+}
+
+// cubic.py:217-265 initialise_potential (fp64 per cell under Numba's typing)
+__global__ __launch_bounds__(BLK) void cubic_init_kernel(const float *__restrict__ b, double threeh2, double d1,
+                                                         int64_t count, float *__restrict__ out) {
+    const double inv3 = 1.0 / 3;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < count; t += (int64_t)gridDim.x * BLK) {
+        const double d0 = -threeh2 * (double)b[t];
+        const double C = pow(0.5 * (d1 + sqrt(d1 * d1 - 4.0 * (d0 * d0 * d0))), inv3);
+        out[t] = (float)(-inv3 * (C + d0 / C));
+    }
+}
+
+extern "C" int pm_cubic_initialise_potential(pm_ctx *c, const float *d_b, float q, int n, float *d_out) {
+    PM_REQUIRE(c && d_b && d_out, "NULL argument");
+    PM_CHECK_GRID(n);
+    const int64_t total = (int64_t)n * n * n;
+    const float h2 = (float)(1.0 / ((double)n * n));
+    hipLaunchKernelGGL(cubic_init_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_b,
+                       3.0 * (double)h2, 27.0 * (double)h2 * (double)q, total, d_out);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// cubic.py:269-442 gauss_seidel / :446-668 gauss_seidel_with_rhs: one launch per colour, one thread
+// per cell of that colour
+template <int COLOUR, bool WITH_RHS>
+__global__ __launch_bounds__(BLK) void cubic_gauss_seidel_kernel(float *__restrict__ x, const float *__restrict__ b,
+                                                                 float d1_q, const float *__restrict__ rhs, int log2n,
+                                                                 float h2, float invsix, float f_relax) {
+    const int n = 1 << log2n, m = n - 1, nh = n >> 1, log2nh = log2n - 1;
+    const int64_t total = (int64_t)n * n * nh;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int kh = (int)(t & (nh - 1)), j = (int)((t >> log2nh) & m), i = (int)(t >> (log2nh + log2n));
+        const int k = 2 * kh + ((i + j + COLOUR) & 1);
+        const int64_t c = cidx(i, j, k, log2n);
+        const float p = cubic_p(x, b, i, j, k, m, log2n, h2, invsix);
+        const float d1 = WITH_RHS ? d1_q - 27.0f * rhs[c] : d1_q;
+        const float sol = (float)cubic_root(p, d1);
+        const float xc = x[c];
+        x[c] = xc + f_relax * (sol - xc);
+    }
+}
+
+extern "C" int pm_cubic_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                                     float f_relax) {
+    PM_REQUIRE(c && d_x && d_b, "NULL argument");
+    PM_CHECK_GRID(n);
+    const int64_t total = (int64_t)n * n * (n / 2);
+    const int blocks = pm_stream_blocks(total, BLK);
+    const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
+    const int l2 = ilog2(n);
+    if (d_rhs) {
+        const float d1_q = 27.0f * h2 * q;  // cubic.py:487 (all fp32)
+        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, true>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, d1_q,
+                           d_rhs, l2, h2, invsix, f_relax);
+        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, true>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, d1_q,
+                           d_rhs, l2, h2, invsix, f_relax);
+    } else {
+        const float d1_q = (float)(27.0 * (double)h2 * (double)q);  // cubic.py:305 (int * f4 -> f8, then f4)
+        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, false>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, d1_q,
+                           d_rhs, l2, h2, invsix, f_relax);
+        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, false>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, d1_q,
+                           d_rhs, l2, h2, invsix, f_relax);
+    }
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// QUMOND (mond.py)
+
+// mond.py:16-162; kind: 0 simple, 1 n, 2 beta, 3 gamma, 4 delta
+template <int KIND>
+__device__ __forceinline__ float mond_nu(float y, float alpha) {
+    if (KIND == 0) return 0.5f + sqrtf(0.25f + 1.0f / y);
+    if (KIND == 1) {
+        const int n = (int)alpha;
+        return powf(0.5f + sqrtf(0.25f + powf(y, (float)(-n))), (float)(1.0 / n));
+    }
+    if (KIND == 2) {
+        const float e = expf(-y);
+        float nu = alpha * e;
+        const float om = 1.0f - e;
+        if (om > 0) nu += powf(om, -0.5f);
+        return nu;
+    }
+    if (KIND == 3) {
+        const float e = expf(-powf(y, (float)(0.5 * alpha)));
+        return powf(1.0f - e, (float)(-1.0 / alpha)) + (1.0f - (float)(1.0 / alpha)) * e;
+    }
+    return powf(1.0f - expf(-powf(y, (float)(0.5 * alpha))), (float)(-1.0 / alpha));
+}
+
+// mond.py:171-316 rhs_simple and its four siblings
+template <int KIND>
+__global__ __launch_bounds__(BLK) void mond_rhs_kernel(const float *__restrict__ pot, float *__restrict__ out,
+                                                       int log2n, float inv_g0, float alpha) {
+    const int n = 1 << log2n, m = n - 1;
+    const float invh = (float)n, inv4h = (float)(0.25 * n);
+    const int64_t total = (int64_t)n * n * n;
+#define P(a, b, c) pot[cidx((a)&m, (b)&m, (c)&m, log2n)]
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t & m), j = (int)((t >> log2n) & m), i = (int)(t >> (2 * log2n));
+        const int im1 = i - 1, ip1 = i + 1, jm1 = j - 1, jp1 = j + 1, km1 = k - 1, kp1 = k + 1;
+        const float p000 = P(i, j, k);
+        const float Axx = invh * (p000 - P(im1, j, k));
+        const float Axy = inv4h * (P(i, jp1, k) - P(i, jm1, k) + P(im1, jp1, k) - P(im1, jm1, k));
+        const float Axz = inv4h * (P(i, j, kp1) - P(i, j, km1) + P(im1, j, kp1) - P(im1, j, km1));
+        const float fAx = sqrtf(Axx * Axx + Axy * Axy + Axz * Axz);
+        const float Bxx = invh * (-p000 + P(ip1, j, k));
+        const float Bxy = inv4h * (P(ip1, jp1, k) - P(ip1, jm1, k) + P(i, jp1, k) - P(i, jm1, k));
+        const float Bxz = inv4h * (P(ip1, j, kp1) - P(ip1, j, km1) + P(i, j, kp1) - P(i, j, km1));
+        const float fBx = sqrtf(Bxx * Bxx + Bxy * Bxy + Bxz * Bxz);
+        const float Ayy = invh * (p000 - P(i, jm1, k));
+        const float Ayx = inv4h * (P(ip1, j, k) - P(im1, j, k) + P(ip1, jm1, k) - P(im1, jm1, k));
+        const float Ayz = inv4h * (P(i, j, kp1) - P(i, j, km1) + P(i, jm1, kp1) - P(i, jm1, km1));
+        const float fAy = sqrtf(Ayx * Ayx + Ayy * Ayy + Ayz * Ayz);
+        const float Byy = invh * (-p000 + P(i, jp1, k));
+        const float Byx = inv4h * (P(ip1, jp1, k) - P(im1, jp1, k) + P(ip1, j, k) - P(im1, j, k));
+        const float Byz = inv4h * (P(i, jp1, kp1) - P(i, jp1, km1) + P(i, j, kp1) - P(i, j, km1));
+        const float fBy = sqrtf(Byx * Byx + Byy * Byy + Byz * Byz);
+        const float Azz = invh * (p000 - P(i, j, km1));
+        const float Azx = inv4h * (P(ip1, j, k) - P(im1, j, k) + P(ip1, j, km1) - P(im1, j, km1));
+        const float Azy = inv4h * (P(i, jp1, k) - P(i, jm1, k) + P(i, jp1, km1) - P(i, jm1, km1));
+        const float fAz = sqrtf(Azx * Azx + Azy * Azy + Azz * Azz);
+        const float Bzz = invh * (-p000 + P(i, j, kp1));
+        const float Bzx = inv4h * (P(ip1, j, kp1) - P(im1, j, kp1) + P(ip1, j, k) - P(im1, j, k));
+        const float Bzy = inv4h * (P(i, jp1, kp1) - P(i, jm1, kp1) + P(i, jp1, k) - P(i, jm1, k));
+        const float fBz = sqrtf(Bzx * Bzx + Bzy * Bzy + Bzz * Bzz);
+        const float nAx = mond_nu<KIND>(fAx * inv_g0, alpha), nAy = mond_nu<KIND>(fAy * inv_g0, alpha),
+                    nAz = mond_nu<KIND>(fAz * inv_g0, alpha), nBx = mond_nu<KIND>(fBx * inv_g0, alpha),
+                    nBy = mond_nu<KIND>(fBy * inv_g0, alpha), nBz = mond_nu<KIND>(fBz * inv_g0, alpha);
+        out[t] = invh * (nBx * Bxx - nAx * Axx + nBy * Byy - nAy * Ayy + nBz * Bzz - nAz * Azz);
+    }
+#undef P
+}
+
+extern "C" int pm_mond_rhs(pm_ctx *c, const float *d_pot, float *d_out, int n, float g0, int kind, float alpha) {
+    PM_REQUIRE(c && d_pot && d_out && d_pot != d_out, "bad argument");
+    PM_CHECK_GRID(n);
+    const int64_t total = (int64_t)n * n * n;
+    const int blocks = pm_stream_blocks(total, BLK);
+    const float inv_g0 = (float)(1.0 / (double)g0);
+    const int l2 = ilog2(n);
+    switch (kind) {
+        case 0: hipLaunchKernelGGL((mond_rhs_kernel<0>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha); break;
+        case 1: hipLaunchKernelGGL((mond_rhs_kernel<1>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha); break;
+        case 2: hipLaunchKernelGGL((mond_rhs_kernel<2>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha); break;
+        case 3: hipLaunchKernelGGL((mond_rhs_kernel<3>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha); break;
+        case 4: hipLaunchKernelGGL((mond_rhs_kernel<4>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha); break;
+        default:
+            pm_set_error("MOND function %d, should be 0..4 (simple, n, beta, gamma, delta)", kind);
+            return PM_EINVAL;
+    }
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}

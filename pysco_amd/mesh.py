@@ -131,3 +131,50 @@ def derivative_fR(a, b, f, fR_n: int, gradient_order: int):
     ctx.call("pm_gradient_fr", int(gradient_order), int(fR_n), float(np.float32(f)), L.ptr(phi),
                                    L.ptr(u), L.ptr(out))
     return L.like_input(out, a)
+
+
+# ---- multigrid transfer operators (reference mesh.py:14-551) ----------------------------------------
+
+
+def _restrict(x, scale: float):
+    torch = L.require_gpu()
+    xd = L.to_device(x, torch.float32)
+    nf = xd.shape[0]
+    ctx = L.context(4)
+    out = torch.empty((nf // 2,) * 3, dtype=torch.float32, device=xd.device)
+    ctx.call("pm_restriction", L.ptr(xd), nf, scale, L.ptr(out))
+    return L.like_input(out, x)
+
+
+def restriction(x):
+    """Average of the 8 children: [n]^3 -> [n/2]^3 (mesh.py:14)."""
+    return _restrict(x, 0.125)
+
+
+def minus_restriction(x):
+    """-restriction(x) (mesh.py:63)."""
+    return _restrict(x, -0.125)
+
+
+def prolongation(x):
+    """Tri-linear interpolation [n]^3 -> [2n]^3 (mesh.py:206)."""
+    torch = L.require_gpu()
+    xd = L.to_device(x, torch.float32)
+    nc = xd.shape[0]
+    ctx = L.context(4)
+    y = torch.empty((2 * nc,) * 3, dtype=torch.float32, device=xd.device)
+    ctx.call("pm_prolongation", L.ptr(y), L.ptr(xd), nc, 0)
+    return L.like_input(y, x)
+
+
+def add_prolongation(y, x) -> None:
+    """y += prolongation(x), in place (mesh.py:334)."""
+    torch = L.require_gpu()
+    xd = L.to_device(x, torch.float32)
+    ctx = L.context(4)
+    if L.is_device_array(y):
+        ctx.call("pm_prolongation", L.ptr(y), L.ptr(xd), xd.shape[0], 1)
+    else:
+        yd = L.to_device(y, torch.float32)
+        ctx.call("pm_prolongation", L.ptr(yd), L.ptr(xd), xd.shape[0], 1)
+        y[...] = yd.cpu().numpy()

@@ -35,7 +35,7 @@ def zeldovich_particles(n: int, seed: int = 42, rms_cells: float = 0.5, vel_fact
     delta_k = (rng.normal(size=k2.shape) + 1j * rng.normal(size=k2.shape)) * np.sqrt(amp)
     psi = np.empty((n, n, n, 3), dtype=np.float64)
     for ax, K in enumerate((KX, KY, KZ)):
-        psi[..., ax] = np.fft.irfftn(1j * K / k2 * delta_k, s=(n, n, n))
+        psi[..., ax] = np.fft.irfftn(1j * K / k2 * delta_k, s=(n, n, n), axes=(0, 1, 2))
     psi = psi.reshape(-1, 3)
     psi *= (rms_cells / n) / np.sqrt((psi**2).sum(axis=1).mean())
     g = (np.arange(n, dtype=np.float64) + 0.5) / n

@@ -1,0 +1,208 @@
+"""GPU parity tests for the grid solvers: linear multigrid, f(R) cubic FAS, QUMOND, and solver.pm
+for those theories -- HIP kernels (through the C ABI) vs the CPU oracle and the reference goldens."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pysco_oracle as orc  # noqa: E402  (checker only)
+from tests.helpers import param_from_json, synth_tables  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from pysco_amd import cubic, laplacian, mesh, mond, multigrid, solver, utils
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.cubic, ns.laplacian, ns.mesh, ns.mond, ns.multigrid, ns.solver, ns.utils, ns.torch = (
+        cubic, laplacian, mesh, mond, multigrid, solver, utils, torch)
+    return ns
+
+
+def _scale(x):
+    return float(np.abs(x).max())
+
+
+def test_transfer_and_laplacian_bit_exact(amd, golden):
+    g = golden("multigrid_n16")
+    x, b, xc = g["x"], g["b"], g["xc"]
+    np.testing.assert_array_equal(amd.mesh.restriction(x), g["restriction"])
+    np.testing.assert_array_equal(amd.mesh.minus_restriction(x), g["minus_restriction"])
+    np.testing.assert_array_equal(amd.mesh.prolongation(xc), g["prolongation"])
+    y = x.copy()
+    amd.mesh.add_prolongation(y, xc)
+    np.testing.assert_array_equal(y, g["add_prolongation"])
+    np.testing.assert_array_equal(amd.laplacian.operator(x), g["operator"])
+    np.testing.assert_array_equal(amd.laplacian.residual(x, b), g["residual"])
+    np.testing.assert_array_equal(amd.laplacian.restrict_residual(x, b), g["restrict_residual"])
+    np.testing.assert_array_equal(amd.laplacian.initialise_potential(b), g["initialise_potential"])
+    y = x.copy()
+    amd.laplacian.gauss_seidel(y, b, np.float32(1.25))
+    np.testing.assert_array_equal(y, g["gauss_seidel_1"])
+    y = x.copy()
+    amd.laplacian.smoothing(y, b, 3)
+    np.testing.assert_array_equal(y, g["smoothing_3"])
+    np.testing.assert_allclose(amd.laplacian.residual_error(x, b), g["residual_error"], rtol=2e-6)
+    np.testing.assert_allclose(amd.laplacian.truncation_error(x), g["truncation_error"], rtol=2e-6)
+    for m in (4, 8):  # coarsest levels of the V-cycle
+        y = g[f"small{m}_x"].copy()
+        amd.laplacian.gauss_seidel(y, g[f"small{m}_b"], np.float32(1.25))
+        np.testing.assert_array_equal(y, g[f"small{m}_gs"])
+    np.testing.assert_array_equal(amd.laplacian.restrict_residual(g["small8_x"], g["small8_b"]),
+                                  g["small8_restrict_residual"])
+    y = g["small8_x"].copy()
+    amd.mesh.add_prolongation(y, g["small4_x"])
+    np.testing.assert_array_equal(y, g["small8_add_prolongation"])
+
+
+def test_linear_multigrid_bit_exact(amd, golden):
+    g = golden("multigrid_n16")
+    param = param_from_json(g["lin_param_json"])
+    param.pop("tolerance", None)
+    phi = amd.torch.from_numpy(g["vc_phi0"].copy()).cuda()
+    rhs = amd.torch.from_numpy(g["vc_rhs"]).cuda()
+    amd.multigrid.V_cycle(phi, rhs, param)
+    np.testing.assert_array_equal(phi.cpu().numpy(), g["vc_phi1"])
+    phi = amd.torch.from_numpy(g["vc_phi0"].copy()).cuda()
+    out = amd.multigrid.linear(phi, rhs, param)
+    assert out is phi  # relaxed in place, same object returned (multigrid.py:77, 83)
+    np.testing.assert_allclose(param["tolerance"], g["lin_tolerance"], rtol=1e-5)
+    np.testing.assert_array_equal(phi.cpu().numpy(), g["lin_phi"])  # same cycle count, same bits
+    with pytest.raises(ValueError):
+        amd.multigrid.linear(phi, rhs, dict(param, theory="fr", compute_additional_field=True))
+
+
+def test_multigrid_random_64_vs_oracle(amd):
+    """64^3 random problem: every level of the V-cycle against the oracle, bit for bit."""
+    rng = np.random.default_rng(5)
+    n = 64
+    b = rng.normal(size=(n, n, n)).astype(np.float32)
+    b -= b.mean()
+    param = {"theory": "newton", "compute_additional_field": False, "ncoarse": 6, "Npre": 2, "Npost": 1,
+             "epsrel": 1e-2, "nsteps": 0}
+    x_ref = orc.lap_initialise_potential(b)
+    x = amd.torch.from_numpy(x_ref.copy()).cuda()
+    orc.V_cycle(x_ref, b, dict(param))
+    amd.multigrid.V_cycle(x, amd.torch.from_numpy(b).cuda(), dict(param))
+    np.testing.assert_array_equal(x.cpu().numpy(), x_ref)
+
+
+def test_cubic(amd, golden):
+    g = golden("cubic_n16")
+    u, b, rhs, q = g["u"], g["b"], g["rhs"], np.float32(g["q"])
+    s = _scale(g["operator"])
+    np.testing.assert_array_equal(amd.cubic.operator(u, b, q), orc.cubic_operator(u, b, q))
+    np.testing.assert_array_equal(amd.cubic.residual_with_rhs(u, b, q, rhs), orc.cubic_residual_with_rhs(u, b, q, rhs))
+    np.testing.assert_allclose(amd.cubic.operator(u, b, q), g["operator"], rtol=0, atol=3e-6 * s)
+    np.testing.assert_allclose(amd.cubic.initialise_potential(b, q), g["initialise_potential"], rtol=2e-5)
+    np.testing.assert_allclose(amd.cubic.initialise_potential(b, q), orc.cubic_initialise_potential(b, q), rtol=3e-7)
+    for with_rhs in (False, True):
+        y, yo = u.copy(), u.copy()
+        if with_rhs:
+            amd.cubic.gauss_seidel_with_rhs(y, b, q, rhs, np.float32(1.25))
+            orc.cubic_gauss_seidel(yo, b, q, np.float32(1.25), rhs)
+            ref = g["gauss_seidel_with_rhs"]
+        else:
+            amd.cubic.gauss_seidel(y, b, q, np.float32(1.25))
+            orc.cubic_gauss_seidel(yo, b, q, np.float32(1.25))
+            ref = g["gauss_seidel"]
+        np.testing.assert_allclose(y, yo, rtol=0, atol=3e-7)  # device pow/acos/cos vs libm: <= 1-2 ulp of u ~ 1
+        np.testing.assert_allclose(y, ref, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(amd.cubic.residual_error(u, b, q), g["residual_error"], rtol=1e-5)
+    np.testing.assert_allclose(amd.cubic.truncation_error(u, b, q), g["truncation_error"], rtol=1e-4)
+
+
+def test_cubic_root_branches(amd):
+    """All three branches of solution_cubic_equation (incl. the NaN one) through a 1-sweep GS on a
+    grid engineered so that cell (1,1,1) sees the requested (p, d1)."""
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "cubic_n16.npz"))
+    pd_, ref = g["root_pd"], g["root"]
+    got = np.array([orc.solution_cubic_equation(p, d) for p, d in pd_], dtype=np.float32)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    # device: u = 0 everywhere -> p = h2*b, d1 = 27*h2*q - 27*rhs; relax with f=1 from x=0 -> x = root
+    n = 16
+    h2 = np.float32(1.0 / n**2)
+    sel = np.arange(0, len(pd_), 7)[: n**3 // 2]
+    b = np.zeros((n, n, n), np.float32)
+    rhs = np.zeros((n, n, n), np.float32)
+    cells = [(i, j, k) for i in range(n) for j in range(n) for k in range(n) if (i + j + k) % 2 == 1][: len(sel)]
+    for (i, j, k), s in zip(cells, sel):
+        b[i, j, k] = pd_[s, 0] / h2
+        rhs[i, j, k] = -pd_[s, 1] / np.float32(27)
+    x = np.zeros((n, n, n), np.float32)
+    xo = x.copy()
+    amd.cubic.gauss_seidel_with_rhs(x, b, np.float32(0), rhs, np.float32(1))
+    orc.cubic_gauss_seidel(xo, b, np.float32(0), np.float32(1), rhs)
+    red = np.array([x[c] for c in cells])
+    red_o = np.array([xo[c] for c in cells])
+    assert np.array_equal(np.isnan(red), np.isnan(red_o))
+    ok = ~np.isnan(red_o)
+    np.testing.assert_allclose(red[ok], red_o[ok], rtol=3e-6, atol=1e-6)
+    assert ok.sum() > 100 and (~ok).sum() > 0
+
+
+def test_mond(amd, golden):
+    g = golden("mond_n16")
+    for name, fn, kw, alpha in (("simple", amd.mond.rhs_simple, {}, 1), ("n", amd.mond.rhs_n, {"n": 2}, 2),
+                                ("beta", amd.mond.rhs_beta, {"beta": 1.3}, 1.3),
+                                ("gamma", amd.mond.rhs_gamma, {"gamma": 1.3}, 1.3),
+                                ("delta", amd.mond.rhs_delta, {"delta": 1.3}, 1.3)):
+        out = np.empty_like(g["pot"])
+        fn(g["pot"], out, np.float32(g["g0"]), **kw)
+        ref = g["rhs_" + name]
+        np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5 * _scale(ref), err_msg=name)
+        oo = np.empty_like(out)
+        orc.mond_rhs(g["pot"], oo, np.float32(g["g0"]), name, alpha)
+        np.testing.assert_allclose(out, oo, rtol=0, atol=4e-6 * _scale(ref), err_msg=name + " vs oracle")
+
+
+PM_MG = ["newton_multigrid", "fr_multigrid", "mond_multigrid", "mond_fft7pt"]
+
+
+@pytest.mark.parametrize("tag", PM_MG)
+@pytest.mark.parametrize("resident", [False, True])
+def test_pm_theories_vs_golden(amd, golden, tag, resident):
+    g = golden("pm_" + tag)
+    tables = synth_tables()
+    param = param_from_json(g["param0_json"])
+    up = (lambda a: amd.torch.from_numpy(np.ascontiguousarray(a)).cuda()) if resident else (lambda a: a)
+    host = (lambda t: t.cpu().numpy()) if resident else (lambda t: t)
+    acc, pot, extra = amd.solver.pm(up(g["pos"]), param, tables=tables)
+    sa, sp = _scale(g["acc1"]), _scale(g["pot1"])
+    np.testing.assert_allclose(host(pot), g["pot1"], rtol=0, atol=2e-4 * sp)
+    np.testing.assert_allclose(host(acc), g["acc1"], rtol=0, atol=1e-3 * sa)
+    if g["extra1"].size:
+        np.testing.assert_allclose(host(extra), g["extra1"], rtol=0, atol=2e-4 * _scale(g["extra1"]))
+    else:
+        assert host(extra).size == 0
+    ref1 = param_from_json(g["param1_json"])
+    for key in ("tolerance", "tolerance_FAS", "tolerance_mond", "fR_q"):
+        if key in ref1:
+            np.testing.assert_allclose(float(param[key]), float(ref1[key]), rtol=1e-3, err_msg=key)
+    # second call: warm start from the previous potential / extra field (solver.py:273-280)
+    param["nsteps"], param["aexp_old"], param["aexp"] = 1, param["aexp"], 0.51
+    amd.utils.set_units(param)
+    acc, pot, extra = amd.solver.pm(up(g["pos2"]), param, pot, extra, tables)
+    np.testing.assert_allclose(host(pot), g["pot2"], rtol=0, atol=5e-4 * sp)
+    np.testing.assert_allclose(host(acc), g["acc2"], rtol=0, atol=2e-3 * sa)
+
+
+def test_pm_theory_errors(amd, golden):
+    g = golden("pm_mond_multigrid")
+    base = param_from_json(g["param0_json"])
+    p = dict(base, mond_function="zeta")
+    with pytest.raises(NotImplementedError):
+        amd.solver.pm(g["pos"], p, tables=synth_tables())
+    p = dict(base, linear_newton_solver="fft")
+    with pytest.raises(NotImplementedError):
+        amd.solver.pm(g["pos"], p, tables=synth_tables())
+    gf = golden("pm_fr_multigrid")
+    p = dict(param_from_json(gf["param0_json"]), fR_n=3)
+    with pytest.raises(NotImplementedError):
+        amd.solver.pm(gf["pos"], p, tables=synth_tables())
