@@ -140,9 +140,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
-        raise SystemExit("bench.py: the slab-decomposed multi-GPU step is not wired in yet (see DESIGN.md)")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from pysco_amd import _lib as L
     from pysco_amd import integration, solver, utils
@@ -151,8 +156,18 @@ def main():
     npart = n**3
     pos, vel = zeldovich_device(n, rms_cells=args.rms_cells)
     utils.periodic_wrap(pos)
+    if world > 1:  # x-slab decomposition: keep the lattice planes of this rank, then hand strays to their owners
+        from pysco_amd import slab
+
+        sl = slab.get(n)
+        lo, hi = sl.x_lo * n * n, (sl.x_lo + sl.nx) * n * n
+        pos, vel = pos[lo:hi].clone(), vel[lo:hi].clone()
+        torch.cuda.empty_cache()
+        pos, vel = sl.migrate(pos, vel)
     pos, vel = utils.reorder_particles(pos, vel)  # Morton-sorted once before timing
     L._ctxs.clear()  # drop the sort workspace
+    if world > 1:
+        slab._slabs.clear()
     torch.cuda.empty_cache()
     param, tables = make_param(n, npart)
     acc, phi, extra = solver.pm(pos, param, tables=tables)
@@ -160,20 +175,36 @@ def main():
     for _ in range(args.warmup):
         pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, t_far)
 
+    if dist is not None:
+        dist.barrier()
     torch.cuda.synchronize()
     L.profile_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, t_far)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     wall = time.perf_counter() - t0
     stages = L.profile_stop()
+    if dist is not None:  # the step is over when the slowest rank is
+        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
 
     ms_per_step = wall / args.steps * 1e3
     value = npart * args.steps / wall
     assert bool(torch.isfinite(pos).all()) and bool(torch.isfinite(vel).all())
 
-    ab = alg_bytes(n, npart)
+    ab = alg_bytes(n, npart / world)
+    for k in ab:  # per-rank share of the grid stages in slab mode
+        if k not in ("pm_kick_drift_wrap", "pm_deposit", "pm_interp", "pm_interp_kick", "pm_axpy", "pm_max_abs"):
+            ab[k] /= world
+    if world > 1:
+        cells, spec = float(n) ** 3 / world, float(n) * n * (n // 2 + 1) * 8.0 / world
+        ab.update({"pm_deposit": 12.0 * npart / world + 4.0 * cells, "pm_interp_kick": 48.0 * npart / world + 12.0 * cells,
+                   "pm_fft2d_r2c": 16.0 * cells, "pm_fft2d_c2r": 16.0 * cells, "pm_fft1d_x": 2.0 * spec,
+                   "pm_greens_slab": 2.0 * spec, "pm_gradient_slab": 16.0 * cells})
     table = []
     for name, (calls, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):
         avg = ms / calls
@@ -185,23 +216,27 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom["stage"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved / (HBM_PEAK / 1e9), 4), "traffic": None,
                 "alg_bytes_per_launch": ab.get(dom["stage"]),
-                "step_frac": round(B_ALG_PER_PARTICLE * npart / (wall / args.steps) / HBM_PEAK, 4),
+                "step_frac": round(B_ALG_PER_PARTICLE * npart / (wall / args.steps) / (HBM_PEAK * world), 4),
                 "step_alg_bytes_per_particle": B_ALG_PER_PARTICLE, "stages": table}
 
     out = {"metric": "particles pushed/sec (one PM step), Newtonian TSC+FFT, fp32", "value": value,
-           "unit": "particles/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"Newton {n}^3 mesh / {n}^3 particles, TSC, FFT Poisson (compensated), "
                                   f"order-5 gradient, leapfrog KDK, Zel'dovich ICs rms {args.rms_cells} cell, "
-                                  "Morton-sorted once", "ncells_1d": n, "npart": npart, "parallelism": "1 GPU"},
+                                  "Morton-sorted once", "ncells_1d": n, "npart": npart,
+                      "parallelism": "1 GPU" if world == 1 else f"{world} x-slabs, RCCL all-to-all FFT transposes + ring halos"},
            "roofline": roofline}
-    if not args.no_cpu_baseline and rank == 0:
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
         del pos, vel, acc, phi, extra
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(args.cpu_ncells)
     if rank == 0:
         print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -145,6 +145,26 @@ int pm_cubic_gauss_seidel(pm_ctx *ctx, float *d_x, const float *d_b, float q, co
  * (kind 0..4; alpha = n, beta, gamma or delta): d_out = div[nu(|grad pot|/g0) grad pot] */
 int pm_mond_rhs(pm_ctx *ctx, const float *d_pot, float *d_out, int n, float g0, int kind, float alpha);
 
+/* ---- slab decomposition (multi-GPU; no reference counterpart: PySCo is single-process) ------------
+ * A rank owns nx_own = n/G consecutive x-planes and the particles inside them.  Its local grids are
+ * [nx, n, n] with ghost planes; pm_set_slab tells the particle<->mesh kernels (pm_deposit, pm_interp,
+ * pm_interp_kick) that local plane 0 is global plane x0 (periodic) and that there are nx planes.
+ * Default (single GPU): nx = n, x0 = 0. */
+int pm_set_slab(pm_ctx *ctx, int nx, int x0);
+/* gradient on a slab: d_phi holds nx_phi planes from global plane x0_phi, d_force receives nx_force
+ * planes from x0_force; needs phi on [x0_force - R, x0_force + nx_force + R), R = 1, 1, 2, 3 for order 2, 3, 5, 7 */
+int pm_gradient_slab(pm_ctx *ctx, int order, const float *d_phi, int nx_phi, int x0_phi, float *d_force,
+                     int nx_force, int x0_force);
+/* slab FFT pieces: batched 2-D r2c / c2r over (y,z) on nplanes x-planes ([np,n,n] <-> [np,n,n/2+1]; the
+ * c2r carries 1/n^3), and the in-place strided 1-D c2c along x of an [n, ncolumns] complex array
+ * (the layout after the all-to-all transpose, ncolumns = (n/G)*(n/2+1)). */
+int pm_fft2d_r2c(pm_ctx *ctx, const float *d_x, void *d_xk, int nplanes);
+int pm_fft2d_c2r(pm_ctx *ctx, void *d_xk, float *d_x, int nplanes);
+int pm_fft1d_x(pm_ctx *ctx, void *d_data, int64_t ncolumns, int inverse);
+/* pm_greens on the transposed layout x[i, j0:j0+nj, k] */
+int pm_greens_slab(pm_ctx *ctx, int kind, int p, void *d_xk, const float *h_k2, const float *h_s, float c0, int j0,
+                   int nj);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,12 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_cubic_initialise_potential": (_vp, _vp, _f, _i, _vp),
     "pm_cubic_gauss_seidel": (_vp, _vp, _vp, _f, _vp, _i, _f),
     "pm_mond_rhs": (_vp, _vp, _vp, _i, _f, _i, _f),
+    "pm_set_slab": (_vp, _i, _i),
+    "pm_gradient_slab": (_vp, _i, _vp, _i, _i, _vp, _i, _i),
+    "pm_fft2d_r2c": (_vp, _vp, _vp, _i),
+    "pm_fft2d_c2r": (_vp, _vp, _vp, _i),
+    "pm_fft1d_x": (_vp, _vp, _i64, _i),
+    "pm_greens_slab": (_vp, _i, _i, _vp, _vp, _vp, _f, _i, _i),
 }
 _RESTYPES = {"pm_last_error": C.c_char_p}
 

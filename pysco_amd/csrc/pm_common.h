@@ -47,9 +47,28 @@ void pm_set_error(const char *fmt, ...);
 
 #define PM_LAUNCH_CHECK() PM_HIP(hipGetLastError())
 
+// Grid geometry seen by the particle/stencil kernels.  y and z are always the full periodic
+// n = 2^log2n cells; x is either the full periodic axis (nx == n, x0 == 0) or, in slab mode, the
+// nx local planes (ghosts included) that start at global plane x0 (periodic origin).
+struct pm_geom {
+    int n, log2n, mask;
+    int nx, x0;
+};
+
+#ifdef __HIPCC__
+// linear index of global cell (gi, gj, gk) in the local array [nx, n, n]; out-of-slab planes are
+// clamped (memory safety only: callers keep particles inside their slab + ghosts)
+__device__ __forceinline__ int64_t pm_cell(const pm_geom &g, int gi, int gj, int gk) {
+    int li = (gi - g.x0) & g.mask;
+    li = li < g.nx ? li : g.nx - 1;
+    return ((((int64_t)li << g.log2n) + (gj & g.mask)) << g.log2n) + (gk & g.mask);
+}
+#endif
+
 struct pm_ctx {
     int n;          // cells per side
     int log2n;
+    int slab_nx, slab_x0;  // geometry of the particle <-> mesh kernels (pm_set_slab); default n, 0
     hipStream_t stream;
     // rocFFT
     rocfft_plan plan_r2c, plan_c2r;
@@ -57,6 +76,11 @@ struct pm_ctx {
     void *fft_work;
     size_t fft_work_bytes;
     void *d_spec;  // lazily allocated half-spectrum scratch for pm_poisson_fft
+    // slab-decomposed FFT pieces (multi-GPU): batched 2-D r2c/c2r over (y,z), strided 1-D c2c over x
+    rocfft_plan plan_s[4];            // 0: 2-D r2c, 1: 2-D c2r, 2: 1-D forward, 3: 1-D backward
+    rocfft_execution_info info_s[4];
+    void *work_s[4];
+    long long key_s[4];               // batch (2-D) or stride (1-D) the cached plan was built for
     // small device scratch: [0..63] words for reductions / flags, then 3 tables of n floats
     unsigned *d_scratch;
     float *d_tab;      // 3*n floats (k2, s, spare)
@@ -66,6 +90,12 @@ struct pm_ctx {
     void *sort_tmp;
     size_t sort_tmp_bytes;
 };
+
+static inline pm_geom pm_ctx_geom(const pm_ctx *c) {
+    pm_geom g;
+    g.n = c->n, g.log2n = c->log2n, g.mask = c->n - 1, g.nx = c->slab_nx, g.x0 = c->slab_x0;
+    return g;
+}
 
 static inline bool pm_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -54,6 +54,8 @@ extern "C" int pm_ctx_create(pm_ctx **out, int n, void *stream) {
     memset(c, 0, sizeof(*c));
     c->n = n;
     c->log2n = __builtin_ctz((unsigned)n);
+    c->slab_nx = n;
+    c->slab_x0 = 0;
     c->stream = (hipStream_t)stream;
     PM_HIP(hipMalloc((void **)&c->d_scratch, 64 * sizeof(unsigned)));
     PM_HIP(hipMemset(c->d_scratch, 0, 64 * sizeof(unsigned)));
@@ -74,6 +76,11 @@ extern "C" int pm_ctx_destroy(pm_ctx *c) {
     if (c->info_c2r) rocfft_execution_info_destroy(c->info_c2r);
     if (c->fft_work) hipFree(c->fft_work);
     if (c->d_spec) hipFree(c->d_spec);
+    for (int i = 0; i < 4; ++i) {
+        if (c->plan_s[i]) rocfft_plan_destroy(c->plan_s[i]);
+        if (c->info_s[i]) rocfft_execution_info_destroy(c->info_s[i]);
+        if (c->work_s[i]) hipFree(c->work_s[i]);
+    }
     if (c->sort_tmp) hipFree(c->sort_tmp);
     hipFree(c->d_scratch);
     hipFree(c->d_tab);
@@ -91,6 +98,16 @@ extern "C" int pm_ctx_set_stream(pm_ctx *c, void *stream) {
         PM_FFT(rocfft_execution_info_set_stream(c->info_r2c, c->stream));
         PM_FFT(rocfft_execution_info_set_stream(c->info_c2r, c->stream));
     }
+    for (int i = 0; i < 4; ++i)
+        if (c->info_s[i]) PM_FFT(rocfft_execution_info_set_stream(c->info_s[i], c->stream));
+    return PM_OK;
+}
+
+extern "C" int pm_set_slab(pm_ctx *c, int nx, int x0) {
+    PM_REQUIRE(c != nullptr, "ctx is NULL");
+    PM_REQUIRE(nx >= 1 && nx <= c->n + 16 && x0 >= -c->n && x0 < c->n, "bad slab geometry");
+    c->slab_nx = nx;
+    c->slab_x0 = ((x0 % c->n) + c->n) % c->n;
     return PM_OK;
 }
 
@@ -144,4 +161,89 @@ extern "C" int pm_poisson_fft(pm_ctx *c, int kind, int p, const float *d_rhs, fl
     rc = pm_greens(c, kind, p, c->d_spec, h_k2, h_s, c0);
     if (rc) return rc;
     return pm_fft_c2r(c, c->d_spec, d_phi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Slab-decomposed FFT pieces.  A rank owns nb x-planes: (1) batched 2-D r2c over (y,z) on its planes,
+// (2) all-to-all transpose done by the caller (RCCL), after which the rank holds all n x-planes of
+// m = (n/G)*(n/2+1) (y,kz) columns, (3) strided 1-D c2c along x.  The inverse mirrors it; the 1/n^3
+// of ifft_3D_real is folded into the 2-D c2r plan.
+
+static int slab_plan(pm_ctx *c, int which, long long key) {
+    if (c->plan_s[which] && c->key_s[which] == key) return PM_OK;
+    std::call_once(g_fft_once, [] { rocfft_setup(); });
+    if (c->plan_s[which]) {
+        PM_HIP(hipStreamSynchronize(c->stream));
+        rocfft_plan_destroy(c->plan_s[which]);
+        c->plan_s[which] = nullptr;
+    }
+    if (c->info_s[which]) {
+        rocfft_execution_info_destroy(c->info_s[which]);
+        c->info_s[which] = nullptr;
+    }
+    if (c->work_s[which]) {
+        PM_HIP(hipFree(c->work_s[which]));
+        c->work_s[which] = nullptr;
+    }
+    const size_t n = (size_t)c->n;
+    rocfft_plan_description d = nullptr;
+    PM_FFT(rocfft_plan_description_create(&d));
+    if (which == 0 || which == 1) {
+        const size_t len[2] = {n, n};  // z fastest, then y
+        if (which == 1) PM_FFT(rocfft_plan_description_set_scale_factor(d, 1.0 / ((double)n * n * n)));
+        PM_FFT(rocfft_plan_create(&c->plan_s[which], rocfft_placement_notinplace,
+                                  which == 0 ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse,
+                                  rocfft_precision_single, 2, len, (size_t)key, d));
+    } else {
+        const size_t len[1] = {n};
+        const size_t stride[1] = {(size_t)key};
+        PM_FFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_complex_interleaved,
+                                                       rocfft_array_type_complex_interleaved, nullptr, nullptr, 1,
+                                                       stride, 1, 1, stride, 1));
+        PM_FFT(rocfft_plan_create(&c->plan_s[which], rocfft_placement_inplace,
+                                  which == 2 ? rocfft_transform_type_complex_forward
+                                             : rocfft_transform_type_complex_inverse,
+                                  rocfft_precision_single, 1, len, (size_t)key, d));
+    }
+    PM_FFT(rocfft_plan_description_destroy(d));
+    size_t w = 0;
+    PM_FFT(rocfft_plan_get_work_buffer_size(c->plan_s[which], &w));
+    PM_FFT(rocfft_execution_info_create(&c->info_s[which]));
+    if (w) {
+        PM_HIP(hipMalloc(&c->work_s[which], w));
+        PM_FFT(rocfft_execution_info_set_work_buffer(c->info_s[which], c->work_s[which], w));
+    }
+    PM_FFT(rocfft_execution_info_set_stream(c->info_s[which], c->stream));
+    c->key_s[which] = key;
+    return PM_OK;
+}
+
+extern "C" int pm_fft2d_r2c(pm_ctx *c, const float *d_x, void *d_xk, int nplanes) {
+    PM_REQUIRE(c && d_x && d_xk && nplanes >= 1, "bad argument");
+    int rc = slab_plan(c, 0, nplanes);
+    if (rc) return rc;
+    void *in[1] = {const_cast<float *>(d_x)};
+    void *out[1] = {d_xk};
+    PM_FFT(rocfft_execute(c->plan_s[0], in, out, c->info_s[0]));
+    return PM_OK;
+}
+
+extern "C" int pm_fft2d_c2r(pm_ctx *c, void *d_xk, float *d_x, int nplanes) {
+    PM_REQUIRE(c && d_x && d_xk && nplanes >= 1, "bad argument");
+    int rc = slab_plan(c, 1, nplanes);
+    if (rc) return rc;
+    void *in[1] = {d_xk};
+    void *out[1] = {d_x};
+    PM_FFT(rocfft_execute(c->plan_s[1], in, out, c->info_s[1]));
+    return PM_OK;
+}
+
+extern "C" int pm_fft1d_x(pm_ctx *c, void *d_data, int64_t ncolumns, int inverse) {
+    PM_REQUIRE(c && d_data && ncolumns >= 1, "bad argument");
+    const int which = inverse ? 3 : 2;
+    int rc = slab_plan(c, which, ncolumns);
+    if (rc) return rc;
+    void *in[1] = {d_data};
+    PM_FFT(rocfft_execute(c->plan_s[which], in, nullptr, c->info_s[which]));
+    return PM_OK;
 }

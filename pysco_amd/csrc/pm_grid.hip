@@ -225,22 +225,26 @@ struct Stencil {
     }
 };
 
+// Slab form: phi (and u) hold nxp planes starting at global plane x0p, the output holds nxf planes
+// starting at x0f; plane lookups go through the periodic origin (single GPU: nxp = nxf = n, 0, 0).
 template <int ORDER, int FRN>
 __global__ __launch_bounds__(BLK) void gradient_kernel(const float *__restrict__ phi, const float *__restrict__ u,
-                                                       float f, float scale, int n, int log2n,
-                                                       float *__restrict__ out) {
+                                                       float f, float scale, int n, int log2n, int nxp, int x0p,
+                                                       int nxf, int x0f, float *__restrict__ out) {
     constexpr int R = (ORDER == 2) ? 1 : (ORDER == 3 ? 1 : (ORDER == 5 ? 2 : 3));  // stencil reach
     const int nq = n >> 2;                                                        // float4 per row
-    const int64_t total = (int64_t)n * n * nq;
+    const int64_t total = (int64_t)nxf * n * nq;
     const int mask = n - 1;
     for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
         const int kq = (int)(t % nq);
-        const int64_t ij = t / nq;
+        const int64_t ij = t / nq;  // local output plane * n + j
         const int j = (int)(ij & mask);
-        const int i = (int)(ij >> log2n);
+        const int i = x0f + (int)(ij >> log2n);  // global plane index (may exceed n: wrapped below)
         const int k0 = kq << 2;
         auto row = [&](const float *g, int ii, int jj) -> const float * {
-            return g + (((int64_t)(ii & mask) << log2n) + (jj & mask)) * n;
+            int li = (ii - x0p) & mask;
+            li = li < nxp ? li : nxp - 1;
+            return g + (((int64_t)li << log2n) + (jj & mask)) * n;
         };
         // gather lines: x[-R..R], y[-R..R] as float4 at k0; z as 12 floats k0-4..k0+7
         float ax[7][4], ay[7][4], az[12];
@@ -297,31 +301,32 @@ __global__ __launch_bounds__(BLK) void gradient_kernel(const float *__restrict__
 }
 
 template <int FRN>
-static int gradient_dispatch(pm_ctx *c, int order, float f, const float *phi, const float *u, float *out) {
+static int gradient_dispatch(pm_ctx *c, int order, float f, const float *phi, const float *u, float *out, int nxp,
+                             int x0p, int nxf, int x0f) {
     const int n = c->n;
-    const int64_t total = (int64_t)n * n * (n >> 2);
+    const int64_t total = (int64_t)nxf * n * (n >> 2);
     const int blocks = pm_stream_blocks(total, BLK);
     float scale;
     switch (order) {
         case 2:
             scale = (float)n;  // invh (mesh.py:656)
             hipLaunchKernelGGL((gradient_kernel<2, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, phi, u, f, scale, n,
-                               c->log2n, out);
+                               c->log2n, nxp, x0p, nxf, x0f, out);
             break;
         case 3:
             scale = (float)(0.5 * n);  // inv2h (mesh.py:698)
             hipLaunchKernelGGL((gradient_kernel<3, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, phi, u, f, scale, n,
-                               c->log2n, out);
+                               c->log2n, nxp, x0p, nxf, x0f, out);
             break;
         case 5:
             scale = (float)(n / 12.0);  // inv12h (mesh.py:743)
             hipLaunchKernelGGL((gradient_kernel<5, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, phi, u, f, scale, n,
-                               c->log2n, out);
+                               c->log2n, nxp, x0p, nxf, x0f, out);
             break;
         case 7:
             scale = (float)(n / 60.0);  // inv60h (mesh.py:801)
             hipLaunchKernelGGL((gradient_kernel<7, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, phi, u, f, scale, n,
-                               c->log2n, out);
+                               c->log2n, nxp, x0p, nxf, x0f, out);
             break;
         default:
             pm_set_error("gradient order %d, should be 2, 3, 5 or 7", order);
@@ -335,7 +340,17 @@ extern "C" int pm_gradient(pm_ctx *c, int order, const float *d_phi, float *d_fo
     PM_REQUIRE(c && d_phi && d_force, "NULL argument");
     PM_REQUIRE(pm_aligned16(d_phi) && pm_aligned16(d_force), "grids must be 16-byte aligned");
     PM_REQUIRE(c->n >= 8, "gradient kernels need n >= 8");
-    return gradient_dispatch<0>(c, order, 0.f, d_phi, nullptr, d_force);
+    return gradient_dispatch<0>(c, order, 0.f, d_phi, nullptr, d_force, c->n, 0, c->n, 0);
+}
+
+extern "C" int pm_gradient_slab(pm_ctx *c, int order, const float *d_phi, int nx_phi, int x0_phi, float *d_force,
+                                int nx_force, int x0_force) {
+    PM_REQUIRE(c && d_phi && d_force, "NULL argument");
+    PM_REQUIRE(pm_aligned16(d_phi) && pm_aligned16(d_force), "grids must be 16-byte aligned");
+    PM_REQUIRE(c->n >= 8 && nx_phi >= 1 && nx_force >= 1, "bad slab geometry");
+    const int n = c->n;
+    return gradient_dispatch<0>(c, order, 0.f, d_phi, nullptr, d_force, nx_phi, ((x0_phi % n) + n) % n, nx_force,
+                                ((x0_force % n) + n) % n);
 }
 
 extern "C" int pm_gradient_fr(pm_ctx *c, int order, int fr_n, float f, const float *d_phi, const float *d_u,
@@ -343,8 +358,8 @@ extern "C" int pm_gradient_fr(pm_ctx *c, int order, int fr_n, float f, const flo
     PM_REQUIRE(c && d_phi && d_u && d_force, "NULL argument");
     PM_REQUIRE(pm_aligned16(d_phi) && pm_aligned16(d_u) && pm_aligned16(d_force), "grids must be 16-byte aligned");
     PM_REQUIRE(c->n >= 8, "gradient kernels need n >= 8");
-    if (fr_n == 1) return gradient_dispatch<1>(c, order, f, d_phi, d_u, d_force);
-    if (fr_n == 2) return gradient_dispatch<2>(c, order, f, d_phi, d_u, d_force);
+    if (fr_n == 1) return gradient_dispatch<1>(c, order, f, d_phi, d_u, d_force, c->n, 0, c->n, 0);
+    if (fr_n == 2) return gradient_dispatch<2>(c, order, f, d_phi, d_u, d_force, c->n, 0, c->n, 0);
     pm_set_error("Only f(R) with n = 1 and 2, currently fR_n=%d", fr_n);
     return PM_ENOSUP;
 }
@@ -352,18 +367,19 @@ extern "C" int pm_gradient_fr(pm_ctx *c, int order, int fr_n, float f, const flo
 // ------------------------------------------------------------------------------------------------
 // k-space Green's functions (fourier.py:460-595): one thread per complex element, per-axis tables.
 
+// The array holds x[i, j0:j0+nj, k] (nj == n, j0 == 0 for the single-GPU layout; a y-range in the
+// transposed slab layout).
 template <int KIND>
-__global__ __launch_bounds__(BLK) void greens_kernel(float2 *__restrict__ x, int n, int log2n, int p,
+__global__ __launch_bounds__(BLK) void greens_kernel(float2 *__restrict__ x, int n, int j0, int nj, int p,
                                                      const float *__restrict__ k2, const float *__restrict__ s,
                                                      float c0) {
     const int nh = (n >> 1) + 1;
-    const int64_t total = (int64_t)n * n * nh;
-    const int mask = n - 1;
+    const int64_t total = (int64_t)n * nj * nh;
     for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
         const int k = (int)(t % nh);
         const int64_t ij = t / nh;
-        const int j = (int)(ij & mask);
-        const int i = (int)(ij >> log2n);
+        const int j = j0 + (int)(ij % nj);
+        const int i = (int)(ij / nj);
         float g;
         if (KIND == PM_GREEN_7PT) {
             g = c0 / ((s[i] + s[j]) + s[k]);
@@ -377,7 +393,7 @@ __global__ __launch_bounds__(BLK) void greens_kernel(float2 *__restrict__ x, int
             }
         }
         float2 v = x[t];
-        if (t == 0) {
+        if (i == 0 && j == 0 && k == 0) {
             v = make_float2(0.f, 0.f);  // x[0,0,0] = 0 (fourier.py:491, 544, 595)
         } else {
             v.x *= g;
@@ -388,25 +404,31 @@ __global__ __launch_bounds__(BLK) void greens_kernel(float2 *__restrict__ x, int
 }
 
 extern "C" int pm_greens(pm_ctx *c, int kind, int p, void *d_xk, const float *h_k2, const float *h_s, float c0) {
+    return pm_greens_slab(c, kind, p, d_xk, h_k2, h_s, c0, 0, c ? c->n : 0);
+}
+
+extern "C" int pm_greens_slab(pm_ctx *c, int kind, int p, void *d_xk, const float *h_k2, const float *h_s, float c0,
+                              int j0, int nj) {
     PM_REQUIRE(c && d_xk && h_k2 && h_s, "NULL argument");
     const int n = c->n;
+    PM_REQUIRE(j0 >= 0 && nj >= 1 && j0 + nj <= n, "bad y range");
     // tables are tiny (n floats): staged through pageable memcpy on the stream
     PM_HIP(hipMemcpyAsync(c->d_tab, h_k2, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     PM_HIP(hipMemcpyAsync(c->d_tab + n, h_s, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    const int64_t total = (int64_t)n * n * (n / 2 + 1);
+    const int64_t total = (int64_t)n * nj * (n / 2 + 1);
     const int blocks = pm_stream_blocks(total, BLK * 2);
     float2 *x = reinterpret_cast<float2 *>(d_xk);
     switch (kind) {
         case PM_GREEN_PLAIN:
-            hipLaunchKernelGGL((greens_kernel<PM_GREEN_PLAIN>), dim3(blocks), dim3(BLK), 0, c->stream, x, n, c->log2n,
-                               p, c->d_tab, c->d_tab + n, c0);
+            hipLaunchKernelGGL((greens_kernel<PM_GREEN_PLAIN>), dim3(blocks), dim3(BLK), 0, c->stream, x, n, j0, nj, p,
+                               c->d_tab, c->d_tab + n, c0);
             break;
         case PM_GREEN_COMPENSATED:
-            hipLaunchKernelGGL((greens_kernel<PM_GREEN_COMPENSATED>), dim3(blocks), dim3(BLK), 0, c->stream, x, n,
-                               c->log2n, p, c->d_tab, c->d_tab + n, c0);
+            hipLaunchKernelGGL((greens_kernel<PM_GREEN_COMPENSATED>), dim3(blocks), dim3(BLK), 0, c->stream, x, n, j0,
+                               nj, p, c->d_tab, c->d_tab + n, c0);
             break;
         case PM_GREEN_7PT:
-            hipLaunchKernelGGL((greens_kernel<PM_GREEN_7PT>), dim3(blocks), dim3(BLK), 0, c->stream, x, n, c->log2n, p,
+            hipLaunchKernelGGL((greens_kernel<PM_GREEN_7PT>), dim3(blocks), dim3(BLK), 0, c->stream, x, n, j0, nj, p,
                                c->d_tab, c->d_tab + n, c0);
             break;
         default:

@@ -49,14 +49,12 @@ __device__ __forceinline__ void cic_weights(float xp, int i, float &w0, float &w
 // deposit, order-independent fallback: one particle per thread, global atomics
 
 template <int SCHEME>
-__device__ __forceinline__ void deposit_global(float x, float y, float z, int n, int log2n, float *rho) {
+__device__ __forceinline__ void deposit_global(float x, float y, float z, const pm_geom &geo, float *rho) {
+    const int n = geo.n;
     const float nf = (float)n;
-    const int mask = n - 1;
     const float xp = x * nf, yp = y * nf, zp = z * nf;
     const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
-    auto at = [&](int ii, int jj, int kk) -> float * {
-        return rho + ((((int64_t)(ii & mask) << log2n) + (jj & mask)) << log2n) + (kk & mask);
-    };
+    auto at = [&](int ii, int jj, int kk) -> float * { return rho + pm_cell(geo, ii, jj, kk); };
     if (SCHEME == PM_NGP) {
         unsafeAtomicAdd(at(i, j, k), 1.0f);
     } else if (SCHEME == PM_CIC) {
@@ -89,10 +87,10 @@ __device__ __forceinline__ void deposit_global(float x, float y, float z, int n,
 }
 
 template <int SCHEME>
-__global__ __launch_bounds__(BLK) void deposit_atomic_kernel(const float *__restrict__ pos, int64_t np, int n,
-                                                             int log2n, float *__restrict__ rho) {
+__global__ __launch_bounds__(BLK) void deposit_atomic_kernel(const float *__restrict__ pos, int64_t np, pm_geom geo,
+                                                             float *__restrict__ rho) {
     for (int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x; p < np; p += (int64_t)gridDim.x * BLK)
-        deposit_global<SCHEME>(pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], n, log2n, rho);
+        deposit_global<SCHEME>(pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], geo, rho);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -140,12 +138,10 @@ __device__ __forceinline__ bool next_anchor(unsigned todo, const float *chunk_po
 }
 
 // global cell index of tile-local cell c (with halo, periodic)
-__device__ __forceinline__ int64_t tile_cell_global(int c, const TileId &t, int mask, int log2n) {
+__device__ __forceinline__ int64_t tile_cell_global(int c, const TileId &t, const pm_geom &geo) {
     const int lk = c % PM_HK, lij = c / PM_HK;
     const int lj = lij % PM_HJ, li = lij / PM_HJ;
-    const int gi = (t.ti * PM_TI - 1 + li) & mask, gj = (t.tj * PM_TJ - 1 + lj) & mask,
-              gk = (t.tk * PM_TK - 1 + lk) & mask;
-    return ((((int64_t)gi << log2n) + gj) << log2n) + gk;
+    return pm_cell(geo, t.ti * PM_TI - 1 + li, t.tj * PM_TJ - 1 + lj, t.tk * PM_TK - 1 + lk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -189,13 +185,13 @@ __device__ __forceinline__ void deposit_lds(float xp, float yp, float zp, int i,
 }
 
 template <int SCHEME>
-__global__ __launch_bounds__(BLK) void deposit_tiled_kernel(const float *__restrict__ pos, int64_t np, int n,
-                                                            int log2n, float *__restrict__ rho) {
+__global__ __launch_bounds__(BLK) void deposit_tiled_kernel(const float *__restrict__ pos, int64_t np, pm_geom geo,
+                                                            float *__restrict__ rho) {
     __shared__ double tile[PM_TILE];  // 25.9 KB
     __shared__ int s_first;
     __shared__ int s_anchor[3];
     const int tid = threadIdx.x;
-    const int mask = n - 1;
+    const int n = geo.n;
     const float nf = (float)n;
     for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0.0;
 
@@ -228,7 +224,7 @@ __global__ __launch_bounds__(BLK) void deposit_tiled_kernel(const float *__restr
         for (int c = tid; c < PM_TILE; c += BLK) {
             const double v = tile[c];
             if (v != 0.0) {
-                unsafeAtomicAdd(rho + tile_cell_global(c, t, mask, log2n), (float)v);
+                unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), (float)v);
                 tile[c] = 0.0;
             }
         }
@@ -238,7 +234,7 @@ __global__ __launch_bounds__(BLK) void deposit_tiled_kernel(const float *__restr
     for (int r = 0; r < PM_PPT; ++r)
         if (todo >> r & 1u) {
             const float *q = pos + 3 * (base + r * BLK + tid);
-            deposit_global<SCHEME>(q[0], q[1], q[2], n, log2n, rho);
+            deposit_global<SCHEME>(q[0], q[1], q[2], geo, rho);
         }
 }
 
@@ -247,12 +243,12 @@ static int deposit_launch(pm_ctx *c, const float *pos, int64_t np, float *rho, i
     const int n = c->n;
     if (sorted_hint && n >= 16) {
         const int64_t blocks = (np + PM_CHUNK - 1) / PM_CHUNK;
-        hipLaunchKernelGGL((deposit_tiled_kernel<SCHEME>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, pos, np, n,
-                           c->log2n, rho);
+        hipLaunchKernelGGL((deposit_tiled_kernel<SCHEME>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, pos, np,
+                           pm_ctx_geom(c), rho);
     } else {
         const int blocks = pm_stream_blocks(np, BLK);
-        hipLaunchKernelGGL((deposit_atomic_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, np, n,
-                           c->log2n, rho);
+        hipLaunchKernelGGL((deposit_atomic_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, np,
+                           pm_ctx_geom(c), rho);
     }
     PM_LAUNCH_CHECK();
     return PM_OK;
@@ -261,7 +257,7 @@ static int deposit_launch(pm_ctx *c, const float *pos, int64_t np, float *rho, i
 extern "C" int pm_deposit(pm_ctx *c, int scheme, const float *d_pos, int64_t np, float *d_rho, int sorted_hint) {
     PM_REQUIRE(c && d_rho && np >= 0 && (d_pos || np == 0), "bad argument");
     PM_REQUIRE((np + PM_CHUNK - 1) / PM_CHUNK < 2147483647LL, "too many particles for one launch");
-    const size_t cells = (size_t)c->n * c->n * c->n;
+    const size_t cells = (size_t)c->slab_nx * c->n * c->n;
     PM_HIP(hipMemsetAsync(d_rho, 0, cells * sizeof(float), c->stream));  // utils.initialise_zero
     if (np == 0) return PM_OK;
     switch (scheme) {
@@ -280,15 +276,13 @@ extern "C" int pm_deposit(pm_ctx *c, int scheme, const float *d_pos, int64_t np,
 
 template <int SCHEME, int NCOMP>
 __global__ __launch_bounds__(BLK) void interp_kernel(const float *__restrict__ grid, const float *__restrict__ pos,
-                                                     int64_t np, int n, int log2n, float *__restrict__ out) {
+                                                     int64_t np, pm_geom geo, float *__restrict__ out) {
+    const int n = geo.n;
     const float nf = (float)n;
-    const int mask = n - 1;
     for (int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x; p < np; p += (int64_t)gridDim.x * BLK) {
         const float xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
         const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
-        auto at = [&](int ii, int jj, int kk) -> const float * {
-            return grid + NCOMP * (((((int64_t)(ii & mask) << log2n) + (jj & mask)) << log2n) + (kk & mask));
-        };
+        auto at = [&](int ii, int jj, int kk) -> const float * { return grid + NCOMP * pm_cell(geo, ii, jj, kk); };
         float acc[NCOMP];
         if (SCHEME == PM_NGP) {
             const float *g = at(i, j, k);
@@ -345,15 +339,15 @@ static int interp_launch(pm_ctx *c, int scheme, const float *grid, const float *
     switch (scheme) {
         case PM_NGP:
             hipLaunchKernelGGL((interp_kernel<PM_NGP, NCOMP>), dim3(blocks), dim3(BLK), 0, c->stream, grid, pos, np,
-                               c->n, c->log2n, out);
+                               pm_ctx_geom(c), out);
             break;
         case PM_CIC:
             hipLaunchKernelGGL((interp_kernel<PM_CIC, NCOMP>), dim3(blocks), dim3(BLK), 0, c->stream, grid, pos, np,
-                               c->n, c->log2n, out);
+                               pm_ctx_geom(c), out);
             break;
         case PM_TSC:
             hipLaunchKernelGGL((interp_kernel<PM_TSC, NCOMP>), dim3(blocks), dim3(BLK), 0, c->stream, grid, pos, np,
-                               c->n, c->log2n, out);
+                               pm_ctx_geom(c), out);
             break;
         default:
             pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme);
@@ -436,10 +430,8 @@ __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, 
 
 template <int SCHEME>
 __device__ __forceinline__ void gather_global(const float *__restrict__ grid, float xp, float yp, float zp, int i,
-                                              int j, int k, int mask, int log2n, float acc[3]) {
-    auto at = [&](int ii, int jj, int kk) -> const float * {
-        return grid + 3 * (((((int64_t)(ii & mask) << log2n) + (jj & mask)) << log2n) + (kk & mask));
-    };
+                                              int j, int k, const pm_geom &geo, float acc[3]) {
+    auto at = [&](int ii, int jj, int kk) -> const float * { return grid + 3 * pm_cell(geo, ii, jj, kk); };
     if (SCHEME == PM_NGP) {
         const float *g = at(i, j, k);
         acc[0] = g[0], acc[1] = g[1], acc[2] = g[2];
@@ -487,7 +479,7 @@ __device__ __forceinline__ void gather_global(const float *__restrict__ grid, fl
 
 template <int SCHEME, bool KICK>
 __global__ __launch_bounds__(BLK) void interp_tiled_kernel(const float *__restrict__ grid,
-                                                           const float *__restrict__ pos, int64_t np, int n, int log2n,
+                                                           const float *__restrict__ pos, int64_t np, pm_geom geo,
                                                            float *__restrict__ out, float *__restrict__ vel,
                                                            float mhalf_dt, unsigned *__restrict__ maxbits) {
     __shared__ float4 tile[PM_TILE];  // 51.8 KB
@@ -495,7 +487,7 @@ __global__ __launch_bounds__(BLK) void interp_tiled_kernel(const float *__restri
     __shared__ int s_anchor[3];
     __shared__ unsigned s_max[2][BLK / 64];
     const int tid = threadIdx.x;
-    const int mask = n - 1;
+    const int n = geo.n;
     const float nf = (float)n;
     const int64_t base = (int64_t)blockIdx.x * PM_CHUNK;
     unsigned todo = 0;
@@ -530,7 +522,7 @@ __global__ __launch_bounds__(BLK) void interp_tiled_kernel(const float *__restri
             for (int q = 0; q < NQ; ++q) {
                 const int c = q * BLK + tid;
                 if (c < PM_TILE) {
-                    const float *g = grid + 3 * tile_cell_global(c, t, mask, log2n);
+                    const float *g = grid + 3 * tile_cell_global(c, t, geo);
                     gx[q] = g[0], gy[q] = g[1], gz[q] = g[2];
                 }
             }
@@ -563,7 +555,7 @@ __global__ __launch_bounds__(BLK) void interp_tiled_kernel(const float *__restri
             const float xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
             const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
             float a[3];
-            gather_global<SCHEME>(grid, xp, yp, zp, i, j, k, mask, log2n, a);
+            gather_global<SCHEME>(grid, xp, yp, zp, i, j, k, geo, a);
             finish(p, a);
         }
     // workgroup max -> two global atomics
@@ -587,10 +579,10 @@ static int interp_kick_launch(pm_ctx *c, const float *grid, const float *pos, in
     unsigned *mb = c->d_scratch + 8;
     if (vel)
         hipLaunchKernelGGL((interp_tiled_kernel<SCHEME, true>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, grid,
-                           pos, np, c->n, c->log2n, out, vel, -half_dt, mb);
+                           pos, np, pm_ctx_geom(c), out, vel, -half_dt, mb);
     else
         hipLaunchKernelGGL((interp_tiled_kernel<SCHEME, false>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, grid,
-                           pos, np, c->n, c->log2n, out, vel, 0.f, mb);
+                           pos, np, pm_ctx_geom(c), out, vel, 0.f, mb);
     PM_LAUNCH_CHECK();
     return PM_OK;
 }

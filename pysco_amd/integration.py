@@ -17,6 +17,11 @@ from . import solver, utils
 def integrate(position, velocity, acceleration, potential, additional_field, tables: List, param,
               t_snap_next=np.float32(0)):
     """One step: dt = min(free-fall, CFL, scale-factor criterion), then leapfrog or euler."""
+    from . import slab
+
+    if slab.active():  # slab-decomposed step: same logic with all-reduced maxima + particle migration
+        return slab.get(2 ** int(param["ncoarse"])).integrate(position, velocity, acceleration, potential,
+                                                              additional_field, tables, param, t_snap_next)
     dt1 = dt_CFL_maxacc(acceleration, param)
     dt2 = dt_CFL_maxvel(velocity, param)
     dt3 = dt_weak_variation(tables[1], param)

@@ -1,0 +1,384 @@
+"""Slab-decomposed PM step across the GPUs of one node (one process per GPU, torch.distributed).
+
+PySCo itself is single-process ("no MPI parallelization"), so this layer has no reference
+counterpart; parity is defined against the single-GPU result.  Decomposition: rank r owns the
+x-planes [r*n/G, (r+1)*n/G) of every grid and the particles inside them.  Exchanges per step
+(RCCL over xGMI with backend "nccl"; "gloo" stages through the host and is used by the CPU tests):
+
+  deposit   1 ghost plane each way, added into the neighbour's edge plane      (send/recv, ring)
+  FFT       2 all-to-all transposes per solve ([x_local, y, kz] <-> [x, y_local, kz])
+  gradient  H = reach+1 ghost planes of phi each way (3 for the order-5 stencil + TSC gather)
+  particles all-to-all of the particles that left the slab after the drift
+  scalars   max|a|, max|v| all-reduce(MAX) for dt
+
+Only the Newtonian FFT path is decomposed so far; multigrid / f(R) / MOND raise in multi-GPU mode.
+All compute goes through an `ops` provider: `HipOps` (libpmstep, the product path).  The CPU tests
+inject their own provider built on the oracle -- nothing in this package falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib as L
+from . import fourier
+
+_REACH = {2: 1, 3: 1, 5: 2, 7: 3}
+_SCHEME = {"cic": L.CIC, "tsc": L.TSC}
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist
+
+
+def active() -> bool:
+    """True when running under torch.distributed with more than one rank."""
+    try:
+        dist = _dist()
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:
+        return False
+
+
+# ------------------------------------------------------------------------------------------------
+# compute provider (product): thin wrappers over the C ABI
+
+
+class HipOps:
+    def __init__(self, n: int):
+        self.torch = L.require_gpu()
+        self.n = n
+        self.ctx = L.context(n)
+
+    # particles
+    def kick_drift_wrap(self, pos, vel, acc, half_dt, dt):
+        self.ctx.call("pm_kick_drift_wrap", L.ptr(pos), L.ptr(vel), L.ptr(acc), float(half_dt), float(dt), pos.shape[0])
+
+    def deposit(self, scheme, pos, nx, x0):
+        n = self.n
+        rho = self.torch.empty((nx, n, n), dtype=self.torch.float32, device=pos.device)
+        self.ctx.call("pm_set_slab", nx, x0)
+        try:
+            self.ctx.call("pm_deposit", scheme, L.ptr(pos), pos.shape[0], L.ptr(rho), 1)
+        finally:
+            self.ctx.call("pm_set_slab", n, 0)
+        return rho
+
+    def interp_kick(self, scheme, force, nx, x0, pos, vel, half_dt):
+        out = self.torch.empty_like(pos)
+        self.ctx.call("pm_set_slab", nx, x0)
+        try:
+            self.ctx.call("pm_interp_kick", scheme, L.ptr(force), L.ptr(pos), pos.shape[0], L.ptr(out),
+                          L.ptr(vel) if vel is not None else None, float(half_dt))
+        finally:
+            self.ctx.call("pm_set_slab", self.n, 0)
+        a, v = C.c_float(0), C.c_float(0)
+        self.ctx.call("pm_last_maxabs", C.byref(a), C.byref(v))
+        return out, float(a.value), float(v.value)
+
+    def max_abs(self, x) -> float:
+        if x.numel() == 0:
+            return 0.0
+        out = C.c_float(0)
+        self.ctx.call("pm_max_abs", L.ptr(x), x.numel(), C.byref(out))
+        return float(out.value)
+
+    def axpy(self, y, x, a):
+        self.ctx.call("pm_axpy", L.ptr(y), L.ptr(x), float(a), y.numel())
+
+    # grids
+    def linear_operator_inplace(self, x, f1, f2):
+        self.ctx.call("pm_linear_operator", L.ptr(x), L.ptr(x), float(f1), float(f2), x.numel())
+
+    def scale_inplace(self, x, a):
+        self.ctx.call("pm_scale", L.ptr(x), float(a), x.numel())
+
+    def fft2d_r2c(self, x):
+        nb, n = x.shape[0], self.n
+        out = self.torch.empty((nb, n, n // 2 + 1), dtype=self.torch.complex64, device=x.device)
+        self.ctx.call("pm_fft2d_r2c", L.ptr(x), L.ptr(out), nb)
+        return out
+
+    def fft2d_c2r(self, xk):
+        nb, n = xk.shape[0], self.n
+        out = self.torch.empty((nb, n, n), dtype=self.torch.float32, device=xk.device)
+        self.ctx.call("pm_fft2d_c2r", L.ptr(xk), L.ptr(out), nb)
+        return out
+
+    def fft1d_x(self, data, inverse: bool):
+        ncol = data.numel() // self.n
+        self.ctx.call("pm_fft1d_x", L.ptr(data), ncol, int(inverse))
+
+    def greens(self, kind, p, data, j0, nj):
+        k2, s, c0 = fourier.green_tables(self.n, kind)
+        self.ctx.call("pm_greens_slab", kind, int(p), L.ptr(data), L.hptr(k2), L.hptr(s), c0, j0, nj)
+
+    def gradient(self, order, phi_ext, x0_phi, nx_force, x0_force):
+        n = self.n
+        out = self.torch.empty((nx_force, n, n, 3), dtype=self.torch.float32, device=phi_ext.device)
+        self.ctx.call("pm_gradient_slab", int(order), L.ptr(phi_ext), phi_ext.shape[0], x0_phi, L.ptr(out), nx_force,
+                      x0_force)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# communication helpers (device tensors over nccl/RCCL; host staging when the backend is gloo)
+
+
+def _stage(t):
+    return t.cpu() if (t.is_cuda and _dist().get_backend() == "gloo") else t
+
+
+def _unstage(t, like):
+    return t.to(like.device) if t.device != like.device else t
+
+
+def all_to_all(send, out_splits: Optional[List[int]] = None, in_splits: Optional[List[int]] = None):
+    """all_to_all_single along dim 0; equal splits when both lists are None."""
+    import torch
+
+    dist = _dist()
+    s = _stage(send.contiguous())
+    if out_splits is None:
+        out = torch.empty_like(s)
+    else:
+        out = torch.empty((int(sum(out_splits)),) + tuple(s.shape[1:]), dtype=s.dtype, device=s.device)
+    if s.is_complex():  # gloo has no complex support; reinterpret as float pairs
+        dist.all_to_all_single(torch.view_as_real(out), torch.view_as_real(s), out_splits, in_splits)
+    else:
+        dist.all_to_all_single(out, s, out_splits, in_splits)
+    return _unstage(out, send)
+
+
+def exchange_planes(to_left, to_right):
+    """Send `to_left` to rank-1 and `to_right` to rank+1 (periodic); returns (from_left, from_right)."""
+    import torch
+
+    dist = _dist()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    left, right = (rank - 1) % world, (rank + 1) % world
+    sl, sr = _stage(to_left.contiguous()), _stage(to_right.contiguous())
+    from_right, from_left = torch.empty_like(sl), torch.empty_like(sr)
+    # order matters when left == right (2 ranks): a rank's first send (to its left) is its peer's
+    # "from my right", so receives are posted in the order [from_right, from_left]
+    ops = [dist.P2POp(dist.isend, sl, left), dist.P2POp(dist.isend, sr, right),
+           dist.P2POp(dist.irecv, from_right, right), dist.P2POp(dist.irecv, from_left, left)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    return _unstage(from_left, to_left), _unstage(from_right, to_left)
+
+
+def all_reduce_max(values: List[float], device) -> List[float]:
+    import torch
+
+    dist = _dist()
+    t = torch.tensor(values, dtype=torch.float32, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
+
+
+# ------------------------------------------------------------------------------------------------
+
+
+class Slab:
+    """Geometry of this rank's slab and the distributed PM step."""
+
+    def __init__(self, n: int, ops=None):
+        dist = _dist()
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.n = n
+        if n % self.world or (n // self.world) < 8:
+            raise ValueError(f"slab decomposition needs n/G >= 8 planes per rank (n={n}, G={self.world})")
+        self.nx = n // self.world
+        self.x_lo = self.rank * self.nx
+        self.ops = ops if ops is not None else HipOps(n)
+        self.carry = ()  # extra per-particle arrays ([Np, ...]) that migrate with the particles (e.g. IDs)
+
+    # ---- particles ------------------------------------------------------------------------------
+    def owner_of(self, pos):
+        """Rank that owns each particle (by its x coordinate in [0,1))."""
+        return (pos[:, 0] * self.world).long().clamp_(0, self.world - 1)
+
+    def migrate(self, *arrays):
+        """Move particles to the rank that owns their x-plane.  arrays[0] is the position [Np,3];
+        all arrays are permuted alike.  Stayers keep their order, arrivals are appended."""
+        import torch
+
+        pos = arrays[0]
+        owner = self.owner_of(pos)
+        leaving = owner != self.rank
+        n_leave = int(leaving.sum())
+        counts_out = torch.zeros(self.world, dtype=torch.int64, device=pos.device)
+        if n_leave:
+            idx = torch.nonzero(leaving, as_tuple=False).squeeze(1)
+            dest = owner[idx]
+            order = torch.argsort(dest, stable=True)
+            idx = idx[order]
+            counts_out = torch.bincount(dest, minlength=self.world)
+        counts_in = all_to_all(counts_out)
+        out_splits = [int(c) for c in counts_out.tolist()]
+        in_splits = [int(c) for c in counts_in.tolist()]
+        any_move = sum(in_splits) + sum(out_splits)
+        result = []
+        keep = ~leaving if n_leave else None
+        for a in arrays:
+            send = a[idx] if n_leave else a[:0]
+            recv = all_to_all(send, in_splits, out_splits)
+            if not any_move:
+                result.append(a)
+            else:
+                stay = a[keep] if n_leave else a
+                result.append(torch.cat([stay, recv], dim=0) if recv.shape[0] else stay.contiguous())
+        return tuple(result)
+
+    # ---- the PM solve (solver.py:30-215, Newtonian FFT branch) -------------------------------------
+    def pm(self, position, param, potential=None, additional_field=None, tables=(), kick=None):
+        import torch
+
+        n, ops = self.n, self.ops
+        if n != 2 ** int(param["ncoarse"]):
+            raise ValueError("slab was built for a different grid size")
+        MASS_SCHEME = param["mass_scheme"].casefold()
+        THEORY = param["theory"].casefold()
+        if MASS_SCHEME == "cic":
+            param["MAS_index"] = 2
+        elif MASS_SCHEME == "tsc":
+            param["MAS_index"] = 3
+        else:
+            raise NotImplementedError(f"{param['mass_scheme']=}, should be 'CIC' or 'TSC'")
+        if THEORY not in ("newton",):
+            raise NotImplementedError(f"multi-GPU slabs: theory {THEORY!r} is single-GPU only for now")
+        LINEAR_NEWTON_SOLVER = param["linear_newton_solver"].casefold()
+        if LINEAR_NEWTON_SOLVER not in ("fft", "fft_7pt"):
+            raise NotImplementedError(
+                f"multi-GPU slabs: linear_newton_solver {LINEAR_NEWTON_SOLVER!r} is single-GPU only for now")
+        SAVE = param["save_power_spectrum"].casefold()
+        if SAVE not in ("yes", "z_out", "no"):
+            raise NotImplementedError(f"SAVE_POWER_SPECTRUM={SAVE!r}, should be 'yes', 'z_out' or 'no'")
+        param["save_pk"] = SAVE == "yes" or (SAVE == "z_out" and bool(param["write_snapshot"]))
+        if param["save_pk"]:
+            raise NotImplementedError("multi-GPU slabs: P(k) output is single-GPU only for now")
+        param["parametrized_mu_z"] = np.float32(1)
+        scheme = _SCHEME[MASS_SCHEME]
+        nx = self.nx
+
+        # deposit into the slab + one ghost plane each side, then fold the ghosts into the neighbours
+        rho_ext = ops.deposit(scheme, position, nx + 2, self.x_lo - 1)
+        from_left, from_right = exchange_planes(rho_ext[0], rho_ext[nx + 1])
+        rho_ext[1] += from_left       # left neighbour's right ghost is my first plane
+        rho_ext[nx] += from_right     # right neighbour's left ghost is my last plane
+        rho = rho_ext[1:nx + 1]       # contiguous view of the owned planes
+        if n**3 != param["npart"]:
+            ops.scale_inplace(rho, np.float32(n**3 / param["npart"]))
+        param["compute_additional_field"] = False
+        f1 = np.float32(1.5 * param["aexp"] * param["Om_m"] * param["parametrized_mu_z"])
+        ops.linear_operator_inplace(rho, f1, -f1)     # solver.rhs_poisson
+
+        phi = self.poisson_fft(rho, param)
+        del rho_ext, rho
+
+        # phi ghosts: gradient reach + 1 plane for the TSC/CIC gather of the force
+        order = param["gradient_stencil_order"]
+        if order not in _REACH:
+            raise ValueError(f"gradient_order={order}, should be 2, 3, 5 or 7")
+        H = _REACH[order] + 1
+        from_left, from_right = exchange_planes(phi[:H], phi[nx - H:])
+        phi_ext = torch.cat([from_left, phi, from_right], dim=0)
+        force = ops.gradient(order, phi_ext, self.x_lo - H, nx + 2, self.x_lo - 1)
+        del phi_ext
+        vel, half_dt = (kick if kick is not None else (None, 0.0))
+        acc, ma, mv = ops.interp_kick(scheme, force, nx + 2, self.x_lo - 1, position, vel, half_dt)
+        self.local_max = (ma, mv)
+        empty = torch.empty(0, dtype=torch.float32, device=position.device)
+        return acc, phi, empty
+
+    def poisson_fft(self, rhs, param):
+        """solver.fft (solver.py:453-522) on slabs: 2-D r2c, transpose, 1-D c2c, Green's function in
+        the transposed layout, and back."""
+        n, nx, G, ops = self.n, self.nx, self.world, self.ops
+        nh, ny = n // 2 + 1, n // self.world
+        MAS_index = param["MAS_index"]
+        solver = param["linear_newton_solver"].casefold()
+        if solver == "fft":
+            kind, p = (L.GREEN_PLAIN, 0) if MAS_index == 0 else (L.GREEN_COMPENSATED, int(MAS_index))
+        else:
+            kind, p = L.GREEN_7PT, 0
+        spec = ops.fft2d_r2c(rhs)                                              # [nx, n, nh]
+        send = spec.view(nx, G, ny, nh).permute(1, 0, 2, 3).contiguous()       # [G(dst), nx, ny, nh]
+        del spec
+        t = all_to_all(send).view(n, ny, nh)                                   # [x (src-major), ny, nh]
+        del send
+        ops.fft1d_x(t, inverse=False)
+        ops.greens(kind, p, t, self.rank * ny, ny)
+        ops.fft1d_x(t, inverse=True)
+        back = all_to_all(t.view(G, nx, ny, nh))                               # [G(src = y block), nx, ny, nh]
+        del t
+        spec = back.permute(1, 0, 2, 3).contiguous().view(nx, n, nh)
+        del back
+        return ops.fft2d_c2r(spec)
+
+    # ---- one integrator step (integration.py:17-264) ---------------------------------------------
+    def integrate(self, position, velocity, acceleration, potential, additional_field, tables, param,
+                  t_snap_next=np.float32(0)):
+        from . import utils
+
+        ops = self.ops
+        if getattr(self, "_max_for", None) == (id(acceleration), id(velocity)):
+            ma, mv = self.local_max
+        else:
+            ma, mv = ops.max_abs(acceleration), ops.max_abs(velocity)
+        ma, mv = all_reduce_max([ma, mv], position.device)
+        dx = np.float32(0.5 ** param["ncoarse"])
+        with np.errstate(divide="ignore"):
+            dt1 = np.float32(param["Courant_factor"]) * np.sqrt(dx / np.float32(ma))      # integration.py:267
+            dt2 = np.float32(param["Courant_factor"]) * dx / np.float32(mv)                # :298
+        aexp_factor = 1.0 + 0.01 * param["max_aexp_stepping"]
+        dt3 = np.float32(tables[1](np.log(aexp_factor * param["aexp"])) - tables[1](np.log(param["aexp"])))
+        dt = np.min([dt1, dt2, dt3])
+        if (param["t"] + dt) > t_snap_next:
+            dt = t_snap_next - param["t"]
+            param["write_snapshot"] = True
+        else:
+            param["write_snapshot"] = False
+        INTEGRATOR = param["integrator"].casefold()
+        if INTEGRATOR not in ("leapfrog", "euler"):
+            raise NotImplementedError("ERROR: Integrator must be 'leapfrog' or 'euler'")
+
+        def advance_clock():
+            param["t"] += dt
+            param["aexp_old"] = param["aexp"]
+            param["aexp"] = np.exp(tables[0](param["t"]))
+            utils.set_units(param)
+
+        if INTEGRATOR == "leapfrog":
+            half_dt = np.float32(0.5 * dt)
+            ops.kick_drift_wrap(position, velocity, acceleration, half_dt, np.float32(dt))
+            advance_clock()
+            position, velocity, *carry = self.migrate(position, velocity, *self.carry)
+            self.carry = tuple(carry)
+            acceleration, potential, additional_field = self.pm(position, param, potential, additional_field, tables,
+                                                                kick=(velocity, half_dt))
+        else:
+            ops.kick_drift_wrap(position, velocity, acceleration, np.float32(0), np.float32(dt))  # drift + wrap only
+            advance_clock()
+            ops.axpy(velocity, acceleration, -np.float32(dt))
+            position, velocity, *carry = self.migrate(position, velocity, *self.carry)
+            self.carry = tuple(carry)
+            acceleration, potential, additional_field = self.pm(position, param, potential, additional_field, tables)
+            self.local_max = (self.local_max[0], ops.max_abs(velocity))
+        self._max_for = (id(acceleration), id(velocity))
+        return position, velocity, acceleration, potential, additional_field
+
+
+_slabs = {}
+
+
+def get(n: int, ops=None) -> Slab:
+    key = (n, id(ops))
+    if key not in _slabs:
+        _slabs[key] = Slab(n, ops)
+    return _slabs[key]

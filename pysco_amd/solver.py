@@ -34,6 +34,11 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     `_kick=(velocity, half_dt)` is the private hook integration.leapfrog uses to fuse its second
     kick (integration.py:262) into the interpolation kernel; not part of the reference API.
     """
+    from . import slab
+
+    if slab.active():  # one process per GPU: x-slab decomposition (no reference counterpart)
+        return slab.get(2 ** int(param["ncoarse"])).pm(position, param, potential, additional_field, tables,
+                                                       kick=_kick)
     L.require_gpu()
     if potential is None:
         potential = _empty(position)

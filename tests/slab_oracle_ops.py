@@ -1,0 +1,90 @@
+"""TEST-ONLY compute provider for pysco_amd.slab: the same interface as slab.HipOps, implemented with
+the CPU oracle on CPU torch tensors, so that the multi-rank orchestration (partition, ghost
+exchange, FFT transposes, particle migration) can be exercised with gloo and no GPU."""
+import numpy as np
+import torch
+
+from oracle import pysco_oracle as orc
+from pysco_amd import _lib as L
+
+
+class OracleOps:
+    def __init__(self, n):
+        self.n = n
+
+    @staticmethod
+    def _np(t):
+        return t.numpy()
+
+    def _planes(self, nx, x0):
+        return [(x0 + l) % self.n for l in range(nx)]
+
+    def kick_drift_wrap(self, pos, vel, acc, half_dt, dt):
+        p, v, a = self._np(pos), self._np(vel), self._np(acc)
+        orc.add_vector_scalar_inplace(v, a, -np.float32(half_dt))
+        orc.add_vector_scalar_inplace(p, v, np.float32(dt))
+        orc.periodic_wrap(p)
+
+    def deposit(self, scheme, pos, nx, x0):
+        fn = {L.TSC: orc.TSC, L.CIC: orc.CIC, L.NGP: orc.NGP}[scheme]
+        full = fn(self._np(pos), self.n) if pos.shape[0] else np.zeros((self.n,) * 3, np.float32)
+        return torch.from_numpy(np.ascontiguousarray(full[self._planes(nx, x0)]))
+
+    def interp_kick(self, scheme, force, nx, x0, pos, vel, half_dt):
+        full = np.zeros((self.n, self.n, self.n, 3), np.float32)
+        full[self._planes(nx, x0)] = self._np(force)
+        fn = {L.TSC: orc.invTSC_vec, L.CIC: orc.invCIC_vec, L.NGP: orc.invNGP_vec}[scheme]
+        acc = fn(full, self._np(pos)) if pos.shape[0] else np.zeros((0, 3), np.float32)
+        mv = 0.0
+        if vel is not None:
+            v = self._np(vel)
+            orc.add_vector_scalar_inplace(v, acc, -np.float32(half_dt))
+            mv = float(np.abs(v).max()) if v.size else 0.0
+        ma = float(np.abs(acc).max()) if acc.size else 0.0
+        return torch.from_numpy(acc), ma, mv
+
+    def max_abs(self, x):
+        return float(x.abs().max()) if x.numel() else 0.0
+
+    def axpy(self, y, x, a):
+        orc.add_vector_scalar_inplace(self._np(y), self._np(x), np.float32(a))
+
+    def linear_operator_inplace(self, x, f1, f2):
+        a = np.ascontiguousarray(self._np(x))
+        orc.linear_operator_inplace(a, f1, f2)
+        x.copy_(torch.from_numpy(a))
+
+    def scale_inplace(self, x, a):
+        x.mul_(float(a))
+
+    def fft2d_r2c(self, x):
+        return torch.from_numpy(np.fft.rfft2(self._np(x).astype(np.float64), axes=(1, 2)).astype(np.complex64))
+
+    def fft2d_c2r(self, xk):
+        n = self.n
+        r = np.fft.irfft2(self._np(xk).astype(np.complex128), s=(n, n), axes=(1, 2)) / n  # 1/n^3 in total
+        return torch.from_numpy(np.ascontiguousarray(r.astype(np.float32)))
+
+    def fft1d_x(self, data, inverse):
+        a = self._np(data).astype(np.complex128)
+        r = np.fft.ifft(a, axis=0) * self.n if inverse else np.fft.fft(a, axis=0)  # both unnormalised
+        data.copy_(torch.from_numpy(r.astype(np.complex64)))
+
+    def greens(self, kind, p, data, j0, nj):
+        n = self.n
+        full = np.zeros((n, n, n // 2 + 1), np.complex64)
+        full[:, j0:j0 + nj] = self._np(data)
+        if kind == L.GREEN_PLAIN:
+            orc.inverse_laplacian(full)
+        elif kind == L.GREEN_COMPENSATED:
+            orc.inverse_laplacian_compensated(full, p)
+        else:
+            orc.inverse_laplacian_7pt(full)
+        data.copy_(torch.from_numpy(np.ascontiguousarray(full[:, j0:j0 + nj])))
+
+    def gradient(self, order, phi_ext, x0_phi, nx_force, x0_force):
+        n = self.n
+        full = np.zeros((n, n, n), np.float32)
+        full[self._planes(phi_ext.shape[0], x0_phi)] = self._np(phi_ext)
+        F = orc.derivative(full, order)
+        return torch.from_numpy(np.ascontiguousarray(F[self._planes(nx_force, x0_force)]))
