@@ -50,8 +50,10 @@ int pm_timer_stop_ms(pm_ctx *ctx, float *h_ms); /* synchronises */
 
 /* ---- mesh.py ------------------------------------------------------------------------------ */
 /* mesh.NGP :2240 / mesh.CIC :2284 / mesh.TSC :2468 (and TSC_seq :2363): d_rho is overwritten.
- * `sorted_hint` != 0 selects the LDS-tiled kernel that is fast when consecutive particles are
- * spatially close (Morton-sorted streams); the result does not depend on it. */
+ * `sorted_hint` picks the kernel, never the result: 0 = one global atomic per contribution (any
+ * order), 1 = one workgroup per LDS tile over the tile's range of a Morton-sorted stream
+ * (utils.reorder_particles order; drifted / unsorted particles fall back per particle),
+ * 2 = one workgroup per 2048-particle chunk with a re-anchored LDS tile. */
 int pm_deposit(pm_ctx *ctx, int scheme, const float *d_pos, int64_t np, float *d_rho, int sorted_hint);
 /* mesh.invNGP_vec :2639 / invCIC_vec :2752 / invTSC_vec :2960  (ncomp = 3, grid [n,n,n,3])
  * mesh.invNGP :2600 / invCIC :2679 / invTSC :2827             (ncomp = 1, grid [n,n,n])      */
@@ -113,6 +115,8 @@ int pm_interp_kick(pm_ctx *ctx, int scheme, const float *d_force, const float *d
 /* utils.max_abs of the acc / vel arrays written by the last pm_interp_kick (syncs).  *h_max_vel is 0
  * if that call had d_vel == NULL. */
 int pm_last_maxabs(pm_ctx *ctx, float *h_max_acc, float *h_max_vel);
+/* kernel choice for pm_interp_kick, same meaning as pm_deposit's sorted_hint 1 / 2 (default 1) */
+int pm_set_gather_mode(pm_ctx *ctx, int mode);
 
 /* ---- multigrid pieces (laplacian.py, cubic.py, mond.py, mesh.py transfer operators) --------------
  * The V-cycle recursion stays on the host (multigrid.py:474-579); every function takes the grid

@@ -12,7 +12,7 @@ from typing import Dict, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpmstep.so")
+LIB_PATH = os.environ.get("PMSTEP_LIB", os.path.join(_HERE, "libpmstep.so"))  # override: diagnostic builds only
 
 NGP, CIC, TSC = 1, 2, 3
 GREEN_PLAIN, GREEN_COMPENSATED, GREEN_7PT = 0, 1, 2
@@ -52,6 +52,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_kick_drift_wrap": (_vp, _vp, _vp, _vp, _f, _f, _i64),
     "pm_interp_kick": (_vp, _i, _vp, _vp, _i64, _vp, _vp, _f),
     "pm_last_maxabs": (_vp, C.POINTER(_f), C.POINTER(_f)),
+    "pm_set_gather_mode": (_vp, _i),
     "pm_restriction": (_vp, _vp, _i, _f, _vp),
     "pm_prolongation": (_vp, _vp, _vp, _i, _i),
     "pm_lap_operator": (_vp, _vp, _vp, _i, _i, _vp),

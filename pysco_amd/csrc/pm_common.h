@@ -86,6 +86,10 @@ struct pm_ctx {
     float *d_tab;      // 3*n floats (k2, s, spare)
     double *d_hist;    // 3*n doubles (P(k) bins)
     hipEvent_t ev0, ev1;
+    // tile-range table of the one-workgroup-per-tile kernels (grown on demand)
+    void *tile_tmp;
+    size_t tile_tmp_bytes;
+    int gather_mode;  // 1: tile-range gather (default), 2: chunk/anchor gather
     // sort workspace (grown on demand)
     void *sort_tmp;
     size_t sort_tmp_bytes;

@@ -56,6 +56,7 @@ extern "C" int pm_ctx_create(pm_ctx **out, int n, void *stream) {
     c->log2n = __builtin_ctz((unsigned)n);
     c->slab_nx = n;
     c->slab_x0 = 0;
+    c->gather_mode = 1;
     c->stream = (hipStream_t)stream;
     PM_HIP(hipMalloc((void **)&c->d_scratch, 64 * sizeof(unsigned)));
     PM_HIP(hipMemset(c->d_scratch, 0, 64 * sizeof(unsigned)));
@@ -82,6 +83,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *c) {
         if (c->work_s[i]) hipFree(c->work_s[i]);
     }
     if (c->sort_tmp) hipFree(c->sort_tmp);
+    if (c->tile_tmp) hipFree(c->tile_tmp);
     hipFree(c->d_scratch);
     hipFree(c->d_tab);
     hipFree(c->d_hist);
@@ -108,6 +110,12 @@ extern "C" int pm_set_slab(pm_ctx *c, int nx, int x0) {
     PM_REQUIRE(nx >= 1 && nx <= c->n + 16 && x0 >= -c->n && x0 < c->n, "bad slab geometry");
     c->slab_nx = nx;
     c->slab_x0 = ((x0 % c->n) + c->n) % c->n;
+    return PM_OK;
+}
+
+extern "C" int pm_set_gather_mode(pm_ctx *c, int mode) {
+    PM_REQUIRE(c != nullptr && (mode == 1 || mode == 2), "mode must be 1 (tile ranges) or 2 (chunk/anchor)");
+    c->gather_mode = mode;
     return PM_OK;
 }
 

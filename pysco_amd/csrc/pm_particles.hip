@@ -238,37 +238,6 @@ __global__ __launch_bounds__(BLK) void deposit_tiled_kernel(const float *__restr
         }
 }
 
-template <int SCHEME>
-static int deposit_launch(pm_ctx *c, const float *pos, int64_t np, float *rho, int sorted_hint) {
-    const int n = c->n;
-    if (sorted_hint && n >= 16) {
-        const int64_t blocks = (np + PM_CHUNK - 1) / PM_CHUNK;
-        hipLaunchKernelGGL((deposit_tiled_kernel<SCHEME>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, pos, np,
-                           pm_ctx_geom(c), rho);
-    } else {
-        const int blocks = pm_stream_blocks(np, BLK);
-        hipLaunchKernelGGL((deposit_atomic_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, np,
-                           pm_ctx_geom(c), rho);
-    }
-    PM_LAUNCH_CHECK();
-    return PM_OK;
-}
-
-extern "C" int pm_deposit(pm_ctx *c, int scheme, const float *d_pos, int64_t np, float *d_rho, int sorted_hint) {
-    PM_REQUIRE(c && d_rho && np >= 0 && (d_pos || np == 0), "bad argument");
-    PM_REQUIRE((np + PM_CHUNK - 1) / PM_CHUNK < 2147483647LL, "too many particles for one launch");
-    const size_t cells = (size_t)c->slab_nx * c->n * c->n;
-    PM_HIP(hipMemsetAsync(d_rho, 0, cells * sizeof(float), c->stream));  // utils.initialise_zero
-    if (np == 0) return PM_OK;
-    switch (scheme) {
-        case PM_NGP: return deposit_launch<PM_NGP>(c, d_pos, np, d_rho, sorted_hint);
-        case PM_CIC: return deposit_launch<PM_CIC>(c, d_pos, np, d_rho, sorted_hint);
-        case PM_TSC: return deposit_launch<PM_TSC>(c, d_pos, np, d_rho, sorted_hint);
-    }
-    pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme);
-    return PM_EINVAL;
-}
-
 // ------------------------------------------------------------------------------------------------
 // inverse interpolation (gather).  One particle per thread; the 27 (8, 1) cell values come through
 // L1/L2, which the Morton-sorted stream keeps warm.  The sum keeps the reference's left-to-right
@@ -381,6 +350,9 @@ __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, 
                                            const float4 *tile, float acc[3]) {
     const int li = i - t.ti * PM_TI + 1, lj = j - t.tj * PM_TJ + 1, lk = k - t.tk * PM_TK + 1;
     auto at = [&](int a, int b, int c) -> float4 { return tile[((li + a) * PM_HJ + (lj + b)) * PM_HK + (lk + c)]; };
+    // The running sums start from +0 (0 + w*g == w*g exactly) and add the terms in the reference's
+    // left-to-right order (mesh.py:3058-3086).
+    acc[0] = acc[1] = acc[2] = 0.f;
     if (SCHEME == PM_NGP) {
         const float4 g = at(0, 0, 0);
         acc[0] = g.x, acc[1] = g.y, acc[2] = g.z;
@@ -390,7 +362,6 @@ __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, 
         cic_weights(xp, i, wx[0], wx[1], sx);
         cic_weights(yp, j, wy[0], wy[1], sy);
         cic_weights(zp, k, wz[0], wz[1], sz);
-        bool first = true;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -399,39 +370,44 @@ __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, 
                 for (int c = 0; c < 2; ++c) {
                     const float w = wx[a] * wy[b] * wz[c];
                     const float4 g = at(a * sx, b * sy, c * sz);
-                    acc[0] = first ? w * g.x : acc[0] + w * g.x;
-                    acc[1] = first ? w * g.y : acc[1] + w * g.y;
-                    acc[2] = first ? w * g.z : acc[2] + w * g.z;
-                    first = false;
+                    acc[0] = acc[0] + w * g.x;
+                    acc[1] = acc[1] + w * g.y;
+                    acc[2] = acc[2] + w * g.z;
                 }
     } else {
         float wx[3], wy[3], wz[3];
         tsc_weights(xp, i, wx);
         tsc_weights(yp, j, wy);
         tsc_weights(zp, k, wz);
-        bool first = true;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
+        // the x-plane loop stays rolled: nine 16-byte LDS reads in flight instead of 27 keeps the
+        // kernel under 128 VGPRs (3 workgroups per CU)
+#pragma unroll 1
+        for (int a = 0; a < 3; ++a) {
+            const float wxa = a == 0 ? wx[0] : (a == 1 ? wx[1] : wx[2]);
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-                const float wxy = wx[a] * wy[b];
+                const float wxy = wxa * wy[b];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float w = wxy * wz[c];
                     const float4 g = at(a - 1, b - 1, c - 1);
-                    acc[0] = first ? w * g.x : acc[0] + w * g.x;
-                    acc[1] = first ? w * g.y : acc[1] + w * g.y;
-                    acc[2] = first ? w * g.z : acc[2] + w * g.z;
-                    first = false;
+                    acc[0] = acc[0] + w * g.x;
+                    acc[1] = acc[1] + w * g.y;
+                    acc[2] = acc[2] + w * g.z;
                 }
             }
+        }
     }
 }
 
+// Same sum straight from global memory: the path of particles that are not inside the staged tile
+// (unsorted or drifted streams).  Deliberately compact (rolled loops, not inlined): it is the rare
+// path and must not set the register budget of the kernels that call it.
 template <int SCHEME>
-__device__ __forceinline__ void gather_global(const float *__restrict__ grid, float xp, float yp, float zp, int i,
-                                              int j, int k, const pm_geom &geo, float acc[3]) {
+__device__ __noinline__ void gather_global(const float *__restrict__ grid, float xp, float yp, float zp, int i, int j,
+                                           int k, const pm_geom &geo, float acc[3]) {
     auto at = [&](int ii, int jj, int kk) -> const float * { return grid + 3 * pm_cell(geo, ii, jj, kk); };
+    acc[0] = acc[1] = acc[2] = 0.f;
     if (SCHEME == PM_NGP) {
         const float *g = at(i, j, k);
         acc[0] = g[0], acc[1] = g[1], acc[2] = g[2];
@@ -441,39 +417,37 @@ __device__ __forceinline__ void gather_global(const float *__restrict__ grid, fl
         cic_weights(xp, i, wx[0], wx[1], sx);
         cic_weights(yp, j, wy[0], wy[1], sy);
         cic_weights(zp, k, wz[0], wz[1], sz);
-        bool first = true;
-#pragma unroll
+#pragma unroll 1
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const float w = wx[a] * wy[b] * wz[c];
+                    const float w = (a ? wx[1] : wx[0]) * wy[b] * wz[c];
                     const float *g = at(i + a * sx, j + b * sy, k + c * sz);
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) acc[m] = first ? w * g[m] : acc[m] + w * g[m];
-                    first = false;
+                    for (int m = 0; m < 3; ++m) acc[m] = acc[m] + w * g[m];
                 }
     } else {
         float wx[3], wy[3], wz[3];
         tsc_weights(xp, i, wx);
         tsc_weights(yp, j, wy);
         tsc_weights(zp, k, wz);
-        bool first = true;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
+#pragma unroll 1
+        for (int a = 0; a < 3; ++a) {
+            const float wxa = a == 0 ? wx[0] : (a == 1 ? wx[1] : wx[2]);
+#pragma unroll 1
             for (int b = 0; b < 3; ++b) {
-                const float wxy = wx[a] * wy[b];
+                const float wxy = wxa * (b == 0 ? wy[0] : (b == 1 ? wy[1] : wy[2]));
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float w = wxy * wz[c];
                     const float *g = at(i + a - 1, j + b - 1, k + c - 1);
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) acc[m] = first ? w * g[m] : acc[m] + w * g[m];
-                    first = false;
+                    for (int m = 0; m < 3; ++m) acc[m] = acc[m] + w * g[m];
                 }
             }
+        }
     }
 }
 
@@ -572,11 +546,363 @@ __global__ __launch_bounds__(BLK) void interp_tiled_kernel(const float *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tile-range kernels: one workgroup per LDS tile, one pass, no anchor search.
+//
+// In a Morton-sorted stream (utils.reorder_particles: x is the most significant axis) the particles
+// of one 8x16x16 tile form one contiguous range.  pm_tile_ranges finds, for every tile key t, the
+// first particle whose key is >= t by bisection on the CURRENT positions and makes the table
+// monotone with a running maximum, so [start[t], start[t+1]) is always a valid partition of
+// [0, np) whatever the particle order is: when the stream is sorted the ranges are the tiles;
+// particles that have drifted out of the tile they are filed under (or an unsorted stream) take
+// the direct global-memory path inside the same kernel.  Correctness never depends on the order.
+
+__device__ __forceinline__ unsigned spread3_10(unsigned v) {  // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__device__ __forceinline__ unsigned compact3_10(unsigned v) {
+    v &= 0x09249249u;
+    v = (v | (v >> 2)) & 0x030c30c3u;
+    v = (v | (v >> 4)) & 0x0300f00fu;
+    v = (v | (v >> 8)) & 0x030000ffu;
+    v = (v | (v >> 16)) & 0x3ffu;
+    return v;
+}
+
+// key of tile (ti, tj, tk) in stream order: cell-level Morton code (x most significant) >> 11
+__device__ __forceinline__ unsigned tile_key(int ti, int tj, int tk) {
+    return (unsigned)(ti & 1) |
+           ((spread3_10((unsigned)tk) | (spread3_10((unsigned)tj) << 1) | (spread3_10((unsigned)(ti >> 1)) << 2)) << 1);
+}
+
+__device__ __forceinline__ TileId tile_of_key(unsigned key) {
+    const unsigned rest = key >> 1;
+    TileId t;
+    t.tk = (int)compact3_10(rest);
+    t.tj = (int)compact3_10(rest >> 1);
+    t.ti = (int)((compact3_10(rest >> 2) << 1) | (key & 1u));
+    return t;
+}
+
+__device__ __forceinline__ unsigned tile_key_of_pos(const float *__restrict__ q, float nf, int n) {
+    const int i = cell_of(q[0] * nf, n), j = cell_of(q[1] * nf, n), k = cell_of(q[2] * nf, n);
+    return tile_key(i >> PM_LI, j >> PM_LJ, k >> PM_LK);
+}
+
+__global__ __launch_bounds__(BLK) void tile_bounds_kernel(const float *__restrict__ pos, int64_t np, int n,
+                                                          unsigned ntiles, int64_t *__restrict__ start) {
+    const unsigned t = blockIdx.x * BLK + threadIdx.x;
+    if (t > ntiles) return;
+    const float nf = (float)n;
+    int64_t lo = 0, hi = np;  // first p with key(p) >= t
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (tile_key_of_pos(pos + 3 * mid, nf, n) < t)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    start[t] = (t == 0) ? 0 : (t == ntiles ? np : lo);
+}
+
+// A tile's range is processed PM_RANGE_CHUNK particles per workgroup: workgroup t < ntiles takes the
+// first chunk of tile t, and the (rare) further chunks of over-full tiles -- clustered regions, or any
+// range at all when the stream is not sorted -- are dealt to the surplus workgroups through a prefix
+// table, so no workgroup ever loops over more than one chunk.
+constexpr int PM_RANGE_CHUNK = 4096;
+
+__global__ __launch_bounds__(BLK) void tile_extra_kernel(const int64_t *__restrict__ start, unsigned ntiles,
+                                                         int64_t *__restrict__ extra) {
+    const unsigned t = blockIdx.x * BLK + threadIdx.x;
+    if (t > ntiles) return;
+    int64_t x = 0;
+    if (t < ntiles) {
+        const int64_t len = start[t + 1] - start[t];
+        x = len > PM_RANGE_CHUNK ? (len - 1) / PM_RANGE_CHUNK : 0;
+    }
+    extra[t] = x;
+}
+
+struct TileWork {
+    const int64_t *start;   // [ntiles + 1] monotone particle offsets
+    const int64_t *xstart;  // [ntiles + 1] exclusive prefix of the extra chunks per tile
+    unsigned ntiles;
+};
+
+// work item of this workgroup: tile key and particle range [s, e); false if it has none
+__device__ __forceinline__ bool tile_work_item(const TileWork &w, unsigned &key, int64_t &s, int64_t &e) {
+    const unsigned b = blockIdx.x;
+    if (b < w.ntiles) {
+        key = b;
+        s = w.start[b];
+        e = min(w.start[b + 1], s + PM_RANGE_CHUNK);
+    } else {
+        const int64_t x = (int64_t)(b - w.ntiles);
+        if (x >= w.xstart[w.ntiles]) return false;
+        unsigned lo = 0, hi = w.ntiles;  // largest key with xstart[key] <= x
+        while (hi - lo > 1) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (w.xstart[mid] <= x)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        key = lo;
+        s = w.start[lo] + (x - w.xstart[lo] + 1) * PM_RANGE_CHUNK;
+        e = min(w.start[lo + 1], s + PM_RANGE_CHUNK);
+    }
+    return s < e;
+}
+
+static int tile_ranges(pm_ctx *c, const float *pos, int64_t np, TileWork *out, unsigned *out_blocks) {
+    const int n = c->n;
+    const unsigned ntiles = (unsigned)(((int64_t)n * n * n) >> (PM_LI + PM_LJ + PM_LK));
+    const size_t bytes = ((size_t)(ntiles + 1) * sizeof(int64_t) + 255) & ~(size_t)255;
+    size_t tmp_bytes = 0, tmp2 = 0;
+    int64_t *nullp = nullptr;
+    PM_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, nullp, nullp, (size_t)ntiles + 1, rocprim::maximum<int64_t>(),
+                                   c->stream));
+    PM_HIP(rocprim::exclusive_scan(nullptr, tmp2, nullp, nullp, (int64_t)0, (size_t)ntiles + 1,
+                                   rocprim::plus<int64_t>(), c->stream));
+    if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
+    const size_t need = 4 * bytes + tmp_bytes;
+    if (c->tile_tmp_bytes < need) {
+        if (c->tile_tmp) PM_HIP(hipFree(c->tile_tmp));
+        c->tile_tmp = nullptr;
+        c->tile_tmp_bytes = 0;
+        PM_HIP(hipMalloc(&c->tile_tmp, need));
+        c->tile_tmp_bytes = need;
+    }
+    char *base = (char *)c->tile_tmp;
+    int64_t *raw = (int64_t *)base, *start = (int64_t *)(base + bytes), *extra = (int64_t *)(base + 2 * bytes),
+            *xstart = (int64_t *)(base + 3 * bytes);
+    void *scan_tmp = base + 4 * bytes;
+    const unsigned tb = (ntiles + 1 + BLK - 1) / BLK;
+    hipLaunchKernelGGL(tile_bounds_kernel, dim3(tb), dim3(BLK), 0, c->stream, pos, np, n, ntiles, raw);
+    PM_LAUNCH_CHECK();
+    PM_HIP(rocprim::inclusive_scan(scan_tmp, tmp_bytes, raw, start, (size_t)ntiles + 1, rocprim::maximum<int64_t>(),
+                                   c->stream));
+    hipLaunchKernelGGL(tile_extra_kernel, dim3(tb), dim3(BLK), 0, c->stream, start, ntiles, extra);
+    PM_LAUNCH_CHECK();
+    PM_HIP(rocprim::exclusive_scan(scan_tmp, tmp_bytes, extra, xstart, (int64_t)0, (size_t)ntiles + 1,
+                                   rocprim::plus<int64_t>(), c->stream));
+    out->start = start, out->xstart = xstart, out->ntiles = ntiles;
+    // sum over tiles of ceil(len/CHUNK) <= ntiles + np/CHUNK: surplus workgroups exit at once
+    const int64_t blocks = (int64_t)ntiles + np / PM_RANGE_CHUNK + 1;
+    if (blocks > 2147483647LL) {
+        pm_set_error("too many particles for one launch");
+        return PM_EINVAL;
+    }
+    *out_blocks = (unsigned)blocks;
+    return PM_OK;
+}
+
+// Rolling depth-4 prefetch of the positions a thread will process (p, p+BLK, p+2BLK, ...): the
+// particle loop stays rolled (register budget) while four loads per lane are always in flight.
+struct PosQueue {
+    float x[4], y[4], z[4];
+    const float *pos;
+    int64_t last;
+    __device__ __forceinline__ void load(int slot, int64_t p) {
+        p = p < last ? p : last;  // clamp: harmless reload of the range's last particle
+        x[slot] = pos[3 * p], y[slot] = pos[3 * p + 1], z[slot] = pos[3 * p + 2];
+    }
+    __device__ __forceinline__ void prime(const float *pos_, int64_t p0, int64_t end) {
+        pos = pos_, last = end - 1;
+        load(0, p0), load(1, p0 + BLK), load(2, p0 + 2 * BLK), load(3, p0 + 3 * BLK);
+    }
+    __device__ __forceinline__ void pop(int64_t p, float &px, float &py, float &pz) {  // p = particle being popped
+        px = x[0], py = y[0], pz = z[0];
+        x[0] = x[1], y[0] = y[1], z[0] = z[1];
+        x[1] = x[2], y[1] = y[2], z[1] = z[2];
+        x[2] = x[3], y[2] = y[3], z[2] = z[3];
+        load(3, p + 4 * BLK);
+    }
+};
+
+template <int SCHEME>
+__global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__restrict__ pos, TileWork work,
+                                                             pm_geom geo, float *__restrict__ rho) {
+    unsigned key;
+    int64_t s, e;
+    if (!tile_work_item(work, key, s, e)) return;
+    __shared__ double tile[PM_TILE];  // 25.9 KB
+    const int tid = threadIdx.x;
+    const int n = geo.n;
+    const float nf = (float)n;
+    const TileId t = tile_of_key(key);
+    PosQueue q;
+    q.prime(pos, s + tid, e);
+    for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0.0;
+    __syncthreads();
+#pragma unroll 1
+    for (int64_t p = s + tid; p < e; p += BLK) {
+        float x, y, z;
+        q.pop(p, x, y, z);
+        const float xp = x * nf, yp = y * nf, zp = z * nf;
+        const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+        if (in_tile(i, j, k, t))
+            deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
+        else
+            deposit_global<SCHEME>(x, y, z, geo, rho);  // filed under another tile: drifted / unsorted
+    }
+    __syncthreads();
+    for (int c = tid; c < PM_TILE; c += BLK) {
+        const double v = tile[c];
+        if (v != 0.0) unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), (float)v);
+    }
+}
+
+template <int SCHEME, bool KICK>
+__global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restrict__ grid,
+                                                            const float *__restrict__ pos, TileWork work, pm_geom geo,
+                                                            float *__restrict__ out, float *__restrict__ vel,
+                                                            float mhalf_dt, unsigned *__restrict__ maxbits) {
+    unsigned key;
+    int64_t s, e;
+    if (!tile_work_item(work, key, s, e)) return;
+    __shared__ float4 tile[PM_TILE];  // 51.8 KB
+    __shared__ unsigned s_max[2][BLK / 64];
+    const int tid = threadIdx.x;
+    const int n = geo.n;
+    const float nf = (float)n;
+    const TileId t = tile_of_key(key);
+    PosQueue q;
+    q.prime(pos, s + tid, e);
+    {   // tile fill: all loads in flight before the first LDS write
+        constexpr int NQ = (PM_TILE + BLK - 1) / BLK;
+        float gx[NQ], gy[NQ], gz[NQ];
+#pragma unroll
+        for (int c4 = 0; c4 < NQ; ++c4) {
+            const int c = c4 * BLK + tid;
+            if (c < PM_TILE) {
+                const float *g = grid + 3 * tile_cell_global(c, t, geo);
+                gx[c4] = g[0], gy[c4] = g[1], gz[c4] = g[2];
+            }
+        }
+#pragma unroll
+        for (int c4 = 0; c4 < NQ; ++c4) {
+            const int c = c4 * BLK + tid;
+            if (c < PM_TILE) tile[c] = make_float4(gx[c4], gy[c4], gz[c4], 0.f);
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int64_t p = s + tid; p < e; p += BLK) {
+        float x, y, z;
+        q.pop(p, x, y, z);
+        const float xp = x * nf, yp = y * nf, zp = z * nf;
+        const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+        float a[3];
+        if (in_tile(i, j, k, t))
+            gather_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile, a);
+        else
+            gather_global<SCHEME>(grid, xp, yp, zp, i, j, k, geo, a);
+        out[3 * p] = a[0], out[3 * p + 1] = a[1], out[3 * p + 2] = a[2];
+    }
+    __syncthreads();  // the range's accelerations are visible to the whole workgroup (same CU)
+
+    // kick + maxima over the contiguous float range [3s, 3e): coalesced dword streams, 4 in flight
+    unsigned ma = 0, mv = 0;  // bit patterns of max|a|, max|v| (integer order == float order, NaN on top)
+    const int64_t f0 = 3 * s, f1 = 3 * e;
+    for (int64_t i = f0 + tid; i < f1; i += 4 * BLK) {
+        float a[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t ii = i + u * BLK;
+            a[u] = ii < f1 ? out[ii] : 0.f;
+            v[u] = (KICK && ii < f1) ? vel[ii] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t ii = i + u * BLK;
+            ma = max(ma, __float_as_uint(a[u]) & 0x7fffffffu);
+            if (KICK && ii < f1) {
+                const float w = v[u] + mhalf_dt * a[u];  // y += a*x (utils.py:297)
+                vel[ii] = w;
+                mv = max(mv, __float_as_uint(w) & 0x7fffffffu);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        ma = max(ma, (unsigned)__shfl_down((int)ma, off, 64));
+        mv = max(mv, (unsigned)__shfl_down((int)mv, off, 64));
+    }
+    if ((tid & 63) == 0) s_max[0][tid >> 6] = ma, s_max[1][tid >> 6] = mv;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < BLK / 64; ++w) ma = max(ma, s_max[0][w]), mv = max(mv, s_max[1][w]);
+        atomicMax(maxbits, ma);
+        if (KICK) atomicMax(maxbits + 1, mv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+
+template <int SCHEME>
+static int deposit_launch(pm_ctx *c, const float *pos, int64_t np, float *rho, int sorted_hint) {
+    const int n = c->n;
+    if (sorted_hint == 1 && n >= 16 && c->slab_nx == n) {  // one workgroup per tile (Morton-sorted streams)
+        TileWork work;
+        unsigned blocks = 0;
+        int rc = tile_ranges(c, pos, np, &work, &blocks);
+        if (rc) return rc;
+        hipLaunchKernelGGL((deposit_ranges_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, work,
+                           pm_ctx_geom(c), rho);
+    } else if (sorted_hint && n >= 16) {
+        const int64_t blocks = (np + PM_CHUNK - 1) / PM_CHUNK;
+        hipLaunchKernelGGL((deposit_tiled_kernel<SCHEME>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, pos, np,
+                           pm_ctx_geom(c), rho);
+    } else {
+        const int blocks = pm_stream_blocks(np, BLK);
+        hipLaunchKernelGGL((deposit_atomic_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, np,
+                           pm_ctx_geom(c), rho);
+    }
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+extern "C" int pm_deposit(pm_ctx *c, int scheme, const float *d_pos, int64_t np, float *d_rho, int sorted_hint) {
+    PM_REQUIRE(c && d_rho && np >= 0 && (d_pos || np == 0), "bad argument");
+    PM_REQUIRE((np + PM_CHUNK - 1) / PM_CHUNK < 2147483647LL, "too many particles for one launch");
+    const size_t cells = (size_t)c->slab_nx * c->n * c->n;
+    PM_HIP(hipMemsetAsync(d_rho, 0, cells * sizeof(float), c->stream));  // utils.initialise_zero
+    if (np == 0) return PM_OK;
+    switch (scheme) {
+        case PM_NGP: return deposit_launch<PM_NGP>(c, d_pos, np, d_rho, sorted_hint);
+        case PM_CIC: return deposit_launch<PM_CIC>(c, d_pos, np, d_rho, sorted_hint);
+        case PM_TSC: return deposit_launch<PM_TSC>(c, d_pos, np, d_rho, sorted_hint);
+    }
+    pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme);
+    return PM_EINVAL;
+}
+
 template <int SCHEME>
 static int interp_kick_launch(pm_ctx *c, const float *grid, const float *pos, int64_t np, float *out, float *vel,
                               float half_dt) {
     const int64_t blocks = (np + PM_CHUNK - 1) / PM_CHUNK;
     unsigned *mb = c->d_scratch + 8;
+    if (c->gather_mode == 1 && c->slab_nx == c->n) {  // one workgroup per tile
+        TileWork work;
+        unsigned nblk = 0;
+        int rc = tile_ranges(c, pos, np, &work, &nblk);
+        if (rc) return rc;
+        if (vel)
+            hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, true>), dim3(nblk), dim3(BLK), 0, c->stream, grid, pos,
+                               work, pm_ctx_geom(c), out, vel, -half_dt, mb);
+        else
+            hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, false>), dim3(nblk), dim3(BLK), 0, c->stream, grid, pos,
+                               work, pm_ctx_geom(c), out, vel, 0.f, mb);
+        PM_LAUNCH_CHECK();
+        return PM_OK;
+    }
     if (vel)
         hipLaunchKernelGGL((interp_tiled_kernel<SCHEME, true>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, grid,
                            pos, np, pm_ctx_geom(c), out, vel, -half_dt, mb);

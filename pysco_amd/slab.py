@@ -113,8 +113,10 @@ class HipOps:
         ncol = data.numel() // self.n
         self.ctx.call("pm_fft1d_x", L.ptr(data), ncol, int(inverse))
 
-    def greens(self, kind, p, data, j0, nj):
+    def greens(self, kind, p, data, j0, nj, scale=None):
         k2, s, c0 = fourier.green_tables(self.n, kind)
+        if scale is not None:  # rhs scaling folded into the prefactor (see solver.pm)
+            c0 = float(np.float32(c0) * np.float32(scale))
         self.ctx.call("pm_greens_slab", kind, int(p), L.ptr(data), L.hptr(k2), L.hptr(s), c0, j0, nj)
 
     def gradient(self, order, phi_ext, x0_phi, nx_force, x0_force):
@@ -275,10 +277,9 @@ class Slab:
         if n**3 != param["npart"]:
             ops.scale_inplace(rho, np.float32(n**3 / param["npart"]))
         param["compute_additional_field"] = False
+        # solver.rhs_poisson's f1*(rho - 1) is folded into the Green's function (k = 0 is discarded)
         f1 = np.float32(1.5 * param["aexp"] * param["Om_m"] * param["parametrized_mu_z"])
-        ops.linear_operator_inplace(rho, f1, -f1)     # solver.rhs_poisson
-
-        phi = self.poisson_fft(rho, param)
+        phi = self.poisson_fft(rho, param, f1)
         del rho_ext, rho
 
         # phi ghosts: gradient reach + 1 plane for the TSC/CIC gather of the force
@@ -296,7 +297,7 @@ class Slab:
         empty = torch.empty(0, dtype=torch.float32, device=position.device)
         return acc, phi, empty
 
-    def poisson_fft(self, rhs, param):
+    def poisson_fft(self, rhs, param, scale=None):
         """solver.fft (solver.py:453-522) on slabs: 2-D r2c, transpose, 1-D c2c, Green's function in
         the transposed layout, and back."""
         n, nx, G, ops = self.n, self.nx, self.world, self.ops
@@ -313,7 +314,7 @@ class Slab:
         t = all_to_all(send).view(n, ny, nh)                                   # [x (src-major), ny, nh]
         del send
         ops.fft1d_x(t, inverse=False)
-        ops.greens(kind, p, t, self.rank * ny, ny)
+        ops.greens(kind, p, t, self.rank * ny, ny, scale)
         ops.fft1d_x(t, inverse=True)
         back = all_to_all(t.view(G, nx, ny, nh))                               # [G(src = y block), nx, ny, nh]
         del t

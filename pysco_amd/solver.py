@@ -96,7 +96,13 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     param["compute_additional_field"] = True
     additional_field_d = get_additional_field(_dev(additional_field), density, param, tables)
     param["compute_additional_field"] = False
-    rhs_poisson(density, additional_field_d, param)
+    # Newtonian FFT solve without P(k): rhs = f1*(rho - 1) is linear and its k = 0 mode is discarded by
+    # the Green's function (fourier.py:491, 544, 595), so the scaling pass (solver.py:445-449) folds
+    # into the Green's function prefactor: phi_k = (f1 * G) * rho_k.  One full grid pass less.
+    fold_scale = (THEORY in ("newton", "parametrized") and LINEAR_NEWTON_SOLVER in ("fft", "fft_7pt")
+                  and not param["save_pk"])
+    if not fold_scale:
+        rhs_poisson(density, additional_field_d, param)
     rhs = density
     del density
 
@@ -107,7 +113,11 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
 
         potential_d = multigrid.linear(potential_d, rhs, param)
     elif LINEAR_NEWTON_SOLVER in ("fft", "fft_7pt"):
-        potential_d = fft(rhs, param)
+        if fold_scale:
+            f1 = np.float32(1.5 * param["aexp"] * param["Om_m"] * param["parametrized_mu_z"])
+            potential_d = fft(rhs, param, _source_scale=f1)
+        else:
+            potential_d = fft(rhs, param)
     elif LINEAR_NEWTON_SOLVER == "full_fft":
         # The reference passes three arguments to the two-argument fft_force here
         # (solver.py:181,200 vs :526-529) and therefore raises TypeError; same behaviour.
@@ -246,8 +256,9 @@ def rhs_poisson(density, additional_field, param) -> None:
         utils.linear_operator_inplace(density, f1, -f1)
 
 
-def fft(rhs, param):
-    """FFT Poisson solve (solver.py:453-522): r2c -> [P(k)] -> Green's function -> c2r."""
+def fft(rhs, param, _source_scale=None):
+    """FFT Poisson solve (solver.py:453-522): r2c -> [P(k)] -> Green's function -> c2r.
+    `_source_scale` (private) multiplies the Green's function: see the fold in pm()."""
     torch = L.require_gpu()
     MAS_index = param["MAS_index"]
     LINEAR_NEWTON_SOLVER = param["linear_newton_solver"].casefold()
@@ -262,6 +273,8 @@ def fft(rhs, param):
     n = rhs_d.shape[0]
     ctx = L.context(n)
     k2, s, c0 = fourier.green_tables(n, kind)
+    if _source_scale is not None:
+        c0 = float(np.float32(c0) * np.float32(_source_scale))
     want_pk = ("save_pk" in param) and param["save_pk"] and not compute_MOND_potential
     phi = torch.empty_like(rhs_d)
     # three C-ABI calls (== pm_poisson_fft) so that per-stage event timing sees each of them

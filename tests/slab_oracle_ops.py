@@ -70,7 +70,7 @@ class OracleOps:
         r = np.fft.ifft(a, axis=0) * self.n if inverse else np.fft.fft(a, axis=0)  # both unnormalised
         data.copy_(torch.from_numpy(r.astype(np.complex64)))
 
-    def greens(self, kind, p, data, j0, nj):
+    def greens(self, kind, p, data, j0, nj, scale=None):
         n = self.n
         full = np.zeros((n, n, n // 2 + 1), np.complex64)
         full[:, j0:j0 + nj] = self._np(data)
@@ -80,6 +80,8 @@ class OracleOps:
             orc.inverse_laplacian_compensated(full, p)
         else:
             orc.inverse_laplacian_7pt(full)
+        if scale is not None:
+            full *= np.float32(scale)
         data.copy_(torch.from_numpy(np.ascontiguousarray(full[:, j0:j0 + nj])))
 
     def gradient(self, order, phi_ext, x0_phi, nx_force, x0_force):

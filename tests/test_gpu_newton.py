@@ -81,6 +81,36 @@ def test_deposit_order_independent_and_sorted_path(amd):
         np.testing.assert_allclose(fn(pos_sorted, n), ofn(pos_sorted, n), rtol=0, atol=4e-6 * _scale(ref))
 
 
+def test_clustered_tiles_split_across_workgroups(amd):
+    """A tile holding far more than one workgroup chunk (4096) of particles, sorted and unsorted:
+    the surplus-workgroup path of the tile-range kernels, deposit and gather+kick."""
+    rng = np.random.default_rng(9)
+    n = 32
+    blob = (0.37 + 0.01 * rng.normal(size=(60000, 3))).astype(np.float32)      # ~1 tile
+    bg = rng.random((20000, 3), dtype=np.float32)
+    pos = np.mod(np.concatenate([blob, bg]), 1.0).astype(np.float32)
+    pos[pos >= 1.0] = 0.0
+    F = rng.normal(size=(n, n, n, 3)).astype(np.float32)
+    ref_rho, ref_acc = orc.TSC(pos, n), orc.invTSC_vec(F, pos)
+    for p in (amd.utils.reorder_particles(pos), pos):
+        rho = amd.mesh.TSC(p, n)
+        ref = orc.TSC(p, n)
+        # cells holding ~1e4 particles: the oracle's sequential fp32 sum itself carries ~1e-5 relative
+        # round-off there (the kernel accumulates each tile in fp64)
+        np.testing.assert_allclose(rho, ref, rtol=3e-5, atol=4e-6)
+        np.testing.assert_array_equal(amd.mesh.invTSC_vec(F, p), orc.invTSC_vec(F, p))
+    # fused kick on device tensors
+    ps = amd.torch.from_numpy(amd.utils.reorder_particles(pos)).cuda()
+    vel = amd.torch.zeros_like(ps)
+    acc = amd.mesh.interp_vec_kick("tsc", amd.torch.from_numpy(F).cuda(), ps, vel, np.float32(0.5))
+    a_ref = orc.invTSC_vec(F, ps.cpu().numpy())
+    np.testing.assert_array_equal(acc.cpu().numpy(), a_ref)
+    np.testing.assert_array_equal(vel.cpu().numpy(), np.float32(-0.5) * a_ref)
+    assert amd.utils.max_abs(acc) == np.abs(a_ref).max()
+    assert amd.utils.max_abs(vel) == np.abs(np.float32(-0.5) * a_ref).max()
+    assert ref_acc.shape == (80000, 3)
+
+
 def test_gradient_bit_exact(amd, golden):
     g = golden("gradient_n16")
     a, b, f = g["a"], g["b"], np.float32(g["f"])

@@ -54,14 +54,14 @@ def main():
     rows = []
     if want("deposit"):
         for name, sch in (("NGP", 1), ("CIC", 2), ("TSC", 3)):
-            for hint in (1, 0):
+            for hint in (1, 2, 0):
                 t = timeit(lambda: ctx.call("pm_deposit", sch, L.ptr(pos), npart, L.ptr(rho), hint))
                 rows.append((f"deposit {name} sorted_hint={hint}", t, (12 * npart + 4 * n**3) / t / 1e6))
         t = timeit(lambda: rho.zero_())
         rows.append(("memset rho", t, 4 * n**3 / t / 1e6))
         perm = torch.randperm(npart, device="cuda")
         pos_shuf = pos[perm].contiguous()
-        for hint in (1, 0):
+        for hint in (1, 2, 0):
             t = timeit(lambda: ctx.call("pm_deposit", 3, L.ptr(pos_shuf), npart, L.ptr(rho), hint), reps=2)
             rows.append((f"deposit TSC SHUFFLED sorted_hint={hint}", t, (12 * npart + 4 * n**3) / t / 1e6))
         del perm, pos_shuf
@@ -69,9 +69,12 @@ def main():
         for name, sch in (("NGP", 1), ("CIC", 2), ("TSC", 3)):
             t = timeit(lambda: ctx.call("pm_interp", sch, 3, L.ptr(F), L.ptr(pos), npart, L.ptr(acc)))
             rows.append((f"interp {name}", t, (24 * npart + 12 * n**3) / t / 1e6))
-        for name, sch in (("NGP", 1), ("CIC", 2), ("TSC", 3)):
-            t = timeit(lambda: ctx.call("pm_interp_kick", sch, L.ptr(F), L.ptr(pos), npart, L.ptr(acc), L.ptr(vel), 1e-9))
-            rows.append((f"interp_kick {name} (tiled, fused kick+max)", t, (48 * npart + 12 * n**3) / t / 1e6))
+        for mode in (1, 2):
+            ctx.call("pm_set_gather_mode", mode)
+            for name, sch in (("NGP", 1), ("CIC", 2), ("TSC", 3)):
+                t = timeit(lambda: ctx.call("pm_interp_kick", sch, L.ptr(F), L.ptr(pos), npart, L.ptr(acc), L.ptr(vel), 1e-9))
+                rows.append((f"interp_kick {name} mode={mode} (fused kick+max)", t, (48 * npart + 12 * n**3) / t / 1e6))
+        ctx.call("pm_set_gather_mode", 1)
         t = timeit(lambda: ctx.call("pm_interp_kick", 3, L.ptr(F), L.ptr(pos), npart, L.ptr(acc), None, 0.0))
         rows.append(("interp_kick TSC (tiled, no kick)", t, (24 * npart + 12 * n**3) / t / 1e6))
     if want("gradient"):
