@@ -300,6 +300,78 @@ __global__ __launch_bounds__(BLK) void gradient_kernel(const float *__restrict__
     }
 }
 
+// Marching form of the plain gradient (single-GPU layout): a thread owns one column of 4 k-cells
+// and walks SEG consecutive x-planes with the 2R+1 planes of its x-stencil in registers, so phi
+// comes from HBM once (plus 2R/SEG halo) instead of being re-fetched by 2R+1 different workgroups;
+// the y/z neighbours are L1/L2 hits inside the plane.  Same Stencil::eval, same bits.
+template <int ORDER>
+__global__ __launch_bounds__(BLK) void gradient_march_kernel(const float *__restrict__ phi, float scale, int n,
+                                                             int log2n, int seg, float *__restrict__ out) {
+    constexpr int R = (ORDER == 2) ? 1 : (ORDER == 3 ? 1 : (ORDER == 5 ? 2 : 3));
+    const int nq = n >> 2, mask = n - 1;
+    const int64_t ncols = (int64_t)n * nq;
+    const int64_t ncolblocks = (ncols + BLK - 1) / BLK;
+    const int64_t col = (int64_t)(blockIdx.x % ncolblocks) * BLK + threadIdx.x;
+    const int i0 = (int)(blockIdx.x / ncolblocks) * seg;
+    if (col >= ncols) return;
+    const int kq = (int)(col % nq), j = (int)(col / nq), k0 = kq << 2;
+    auto ld = [&](int ii, int jj, int kk) -> float4 {
+        return *reinterpret_cast<const float4 *>(phi + ((((int64_t)(ii & mask) << log2n) + (jj & mask)) << log2n) +
+                                                 (kk & mask));
+    };
+    float4 w[2 * R + 1];
+#pragma unroll
+    for (int o = 0; o < 2 * R; ++o) w[o + 1] = ld(i0 - R + o, j, k0);  // planes i0-R .. i0+R-1 (slot 0 filled below)
+#pragma unroll 1
+    for (int i = i0; i < i0 + seg; ++i) {
+#pragma unroll
+        for (int o = 0; o < 2 * R; ++o) w[o] = w[o + 1];
+        w[2 * R] = ld(i + R, j, k0);
+        float ax[7][4], ay[7][4], az[12];
+#pragma unroll
+        for (int o = -R; o <= R; ++o) {
+            const float4 vx = w[o + R];
+            ax[o + 3][0] = vx.x, ax[o + 3][1] = vx.y, ax[o + 3][2] = vx.z, ax[o + 3][3] = vx.w;
+            if (ORDER == 2 && o < 0) continue;
+            const float4 vy = (o == 0) ? w[R] : ld(i, j + o, k0);
+            ay[o + 3][0] = vy.x, ay[o + 3][1] = vy.y, ay[o + 3][2] = vy.z, ay[o + 3][3] = vy.w;
+        }
+        const float4 zl = ld(i, j, k0 - 4), zr = ld(i, j, k0 + 4);
+        az[0] = zl.x, az[1] = zl.y, az[2] = zl.z, az[3] = zl.w;
+        az[4] = ax[3][0], az[5] = ax[3][1], az[6] = ax[3][2], az[7] = ax[3][3];
+        az[8] = zr.x, az[9] = zr.y, az[10] = zr.z, az[11] = zr.w;
+        float res[12];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float sa[7], sb[7];
+#pragma unroll
+            for (int o = 0; o < 7; ++o) sa[o] = ax[o][c], sb[o] = 0.f;
+            res[3 * c + 0] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+#pragma unroll
+            for (int o = 0; o < 7; ++o) sa[o] = ay[o][c];
+            res[3 * c + 1] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+#pragma unroll
+            for (int o = 0; o < 7; ++o) sa[o] = az[4 + c + o - 3];
+            res[3 * c + 2] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+        }
+        float4 *o4 = reinterpret_cast<float4 *>(out + 3 * (((((int64_t)i << log2n) + j) << log2n) + k0));
+        o4[0] = make_float4(res[0], res[1], res[2], res[3]);
+        o4[1] = make_float4(res[4], res[5], res[6], res[7]);
+        o4[2] = make_float4(res[8], res[9], res[10], res[11]);
+    }
+}
+
+template <int ORDER>
+static int gradient_march_launch(pm_ctx *c, float scale, const float *phi, float *out) {
+    const int n = c->n, seg = 32;
+    const int64_t ncols = (int64_t)n * (n >> 2);
+    const int64_t blocks = ((ncols + BLK - 1) / BLK) * (n / seg);
+    hipLaunchKernelGGL((gradient_march_kernel<ORDER>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, phi, scale, n,
+                       c->log2n, seg, out);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
 template <int FRN>
 static int gradient_dispatch(pm_ctx *c, int order, float f, const float *phi, const float *u, float *out, int nxp,
                              int x0p, int nxf, int x0f) {
@@ -340,6 +412,15 @@ extern "C" int pm_gradient(pm_ctx *c, int order, const float *d_phi, float *d_fo
     PM_REQUIRE(c && d_phi && d_force, "NULL argument");
     PM_REQUIRE(pm_aligned16(d_phi) && pm_aligned16(d_force), "grids must be 16-byte aligned");
     PM_REQUIRE(c->n >= 8, "gradient kernels need n >= 8");
+    if (c->n >= 32) {
+        const int n = c->n;
+        switch (order) {
+            case 2: return gradient_march_launch<2>(c, (float)n, d_phi, d_force);
+            case 3: return gradient_march_launch<3>(c, (float)(0.5 * n), d_phi, d_force);
+            case 5: return gradient_march_launch<5>(c, (float)(n / 12.0), d_phi, d_force);
+            case 7: return gradient_march_launch<7>(c, (float)(n / 60.0), d_phi, d_force);
+        }
+    }
     return gradient_dispatch<0>(c, order, 0.f, d_phi, nullptr, d_force, c->n, 0, c->n, 0);
 }
 

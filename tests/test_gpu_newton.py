@@ -125,6 +125,15 @@ def test_gradient_bit_exact(amd, golden):
         amd.mesh.derivative_fR(a, b, f, 3, 5)
 
 
+@pytest.mark.parametrize("n", [32, 64])
+def test_gradient_marching_kernel_bit_exact(amd, n):
+    """n >= 32 takes the marching (2.5-D) gradient kernel: same bits as the oracle for every order."""
+    rng = np.random.default_rng(n)
+    a = rng.normal(size=(n, n, n)).astype(np.float32)
+    for order in (2, 3, 5, 7):
+        np.testing.assert_array_equal(amd.mesh.derivative(a, order), orc.derivative(a, order))
+
+
 @pytest.mark.parametrize("n", [16, 32])
 def test_kspace(amd, golden, n):
     g = golden(f"kspace_n{n}")
