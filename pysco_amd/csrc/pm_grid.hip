@@ -308,13 +308,13 @@ template <int ORDER>
 __global__ __launch_bounds__(BLK) void gradient_march_kernel(const float *__restrict__ phi, float scale, int n,
                                                              int log2n, int seg, float *__restrict__ out) {
     constexpr int R = (ORDER == 2) ? 1 : (ORDER == 3 ? 1 : (ORDER == 5 ? 2 : 3));
+    // a workgroup owns a patch of 8 rows x 32 float4 (128 k-cells), so most y/z neighbours are
+    // its own threads' loads (L1 hits) rather than lines another XCD's L2 has to fetch again
     const int nq = n >> 2, mask = n - 1;
-    const int64_t ncols = (int64_t)n * nq;
-    const int64_t ncolblocks = (ncols + BLK - 1) / BLK;
-    const int64_t col = (int64_t)(blockIdx.x % ncolblocks) * BLK + threadIdx.x;
-    const int i0 = (int)(blockIdx.x / ncolblocks) * seg;
-    if (col >= ncols) return;
-    const int kq = (int)(col % nq), j = (int)(col / nq), k0 = kq << 2;
+    const int pk = nq >> 5, pj = n >> 3;  // patches along k and j (n >= 128) -- see launcher for small n
+    const int patch = (int)(blockIdx.x % (pk * pj));
+    const int i0 = (int)(blockIdx.x / (pk * pj)) * seg;
+    const int kq = (patch % pk) * 32 + (threadIdx.x & 31), j = (patch / pk) * 8 + (threadIdx.x >> 5), k0 = kq << 2;
     auto ld = [&](int ii, int jj, int kk) -> float4 {
         return *reinterpret_cast<const float4 *>(phi + ((((int64_t)(ii & mask) << log2n) + (jj & mask)) << log2n) +
                                                  (kk & mask));
@@ -364,8 +364,7 @@ __global__ __launch_bounds__(BLK) void gradient_march_kernel(const float *__rest
 template <int ORDER>
 static int gradient_march_launch(pm_ctx *c, float scale, const float *phi, float *out) {
     const int n = c->n, seg = 32;
-    const int64_t ncols = (int64_t)n * (n >> 2);
-    const int64_t blocks = ((ncols + BLK - 1) / BLK) * (n / seg);
+    const int64_t blocks = (int64_t)((n >> 2) >> 5) * (n >> 3) * (n / seg);
     hipLaunchKernelGGL((gradient_march_kernel<ORDER>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, phi, scale, n,
                        c->log2n, seg, out);
     PM_LAUNCH_CHECK();
@@ -412,7 +411,7 @@ extern "C" int pm_gradient(pm_ctx *c, int order, const float *d_phi, float *d_fo
     PM_REQUIRE(c && d_phi && d_force, "NULL argument");
     PM_REQUIRE(pm_aligned16(d_phi) && pm_aligned16(d_force), "grids must be 16-byte aligned");
     PM_REQUIRE(c->n >= 8, "gradient kernels need n >= 8");
-    if (c->n >= 32) {
+    if (c->n >= 128) {
         const int n = c->n;
         switch (order) {
             case 2: return gradient_march_launch<2>(c, (float)n, d_phi, d_force);
