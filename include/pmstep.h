@@ -145,6 +145,14 @@ int pm_cubic_initialise_potential(pm_ctx *ctx, const float *d_b, float q, int n,
 /* cubic.gauss_seidel :269 (d_rhs NULL) / cubic.gauss_seidel_with_rhs :446 */
 int pm_cubic_gauss_seidel(pm_ctx *ctx, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
                           float f_relax);
+/* quartic.py (f(R) n = 2) twins of the four cubic entry points: operator :20 / residual_with_rhs :86,
+ * residual_error :844, initialise_potential :214, gauss_seidel :270 / gauss_seidel_with_rhs :448 */
+int pm_quartic_operator(pm_ctx *ctx, const float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                        float *d_out);
+int pm_quartic_residual_error(pm_ctx *ctx, const float *d_x, const float *d_b, float q, int n, float *h_out);
+int pm_quartic_initialise_potential(pm_ctx *ctx, const float *d_b, float q, int n, float *d_out);
+int pm_quartic_gauss_seidel(pm_ctx *ctx, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                            float f_relax);
 /* mond.rhs_simple :171 / rhs_n :322 / rhs_beta :476 / rhs_gamma :630 / rhs_delta :784
  * (kind 0..4; alpha = n, beta, gamma or delta): d_out = div[nu(|grad pot|/g0) grad pot] */
 int pm_mond_rhs(pm_ctx *ctx, const float *d_pot, float *d_out, int n, float g0, int kind, float alpha);

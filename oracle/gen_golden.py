@@ -386,6 +386,59 @@ def g_cubic():
     save("cubic_n16", **out)
 
 
+def g_quartic():
+    """f(R) n=2 operator pieces (quartic.py), same regime as g_cubic."""
+    n = 16
+    rng = np.random.default_rng(81)
+    u = (1.0 + 0.1 * rng.normal(size=(n, n, n))).astype(np.float32)
+    b = (1415.0 + 170.0 * rng.normal(size=(n, n, n))).astype(np.float32)
+    rhs = (0.05 * rng.normal(size=(n, n, n))).astype(np.float32)
+    q = f32(-1415.0)
+    out = {"u": u, "b": b, "rhs": rhs, "q": q}
+    with np.errstate(all="ignore"):
+        out["operator"] = quartic.operator(u, b, q)
+        out["residual_with_rhs"] = quartic.residual_with_rhs(u, b, q, rhs)
+        out["initialise_potential"] = quartic.initialise_potential(b, q)
+        P, Q = np.meshgrid(np.linspace(-6, 6, 41), np.linspace(-8, 2, 41), indexing="ij")
+        pq = np.stack([P.ravel(), Q.ravel()], axis=1).astype(np.float32)
+        out["root_pq"] = pq
+        out["root"] = np.array([quartic.solution_quartic_equation(f32(p_), f32(q_)) for p_, q_ in pq], dtype=np.float32)
+        y = u.copy()
+        quartic.gauss_seidel(y, b, q, f32(1.25))
+        out["gauss_seidel"] = y
+        y = u.copy()
+        quartic.gauss_seidel_with_rhs(y, b, q, rhs, f32(1.25))
+        out["gauss_seidel_with_rhs"] = y
+        out["residual_error"] = quartic.residual_error(u, b, q)
+        out["truncation_error"] = quartic.truncation_error(u, b, q)
+    save("quartic_n16", **out)
+
+
+def g_pm_fr2():
+    """solver.pm for f(R) n = 2 (quartic.py), two consecutive calls."""
+    n, nc = 32, 5
+    pos, _ = particles_lattice(50, n, 0.8)
+    param = base_param(nc, n**3, theory="fr", fR_n=2, fR_logfR0=5, linear_newton_solver="multigrid", boxlen=1000.0)
+    tables = synth_tables()
+    p0 = np.array(param_to_json(param))
+    with np.errstate(all="ignore"):
+        acc, pot, extra = solver.pm(pos, param, tables=tables)
+        rec = {"pos": pos, "param0_json": p0, "acc1": acc.copy(), "pot1": pot.copy(), "extra1": extra.copy(),
+               "param1_json": np.array(param_to_json(param))}
+        param["nsteps"] = 1
+        param["aexp_old"] = param["aexp"]
+        param["aexp"] = 0.51
+        utils.set_units(param)
+        pos2 = pos.copy()
+        pos2 += f32(0.2 / n) * np.sin(2 * np.pi * pos[:, ::-1]).astype(np.float32)
+        utils.periodic_wrap(pos2)
+        acc, pot, extra = solver.pm(pos2, param, pot, extra, tables)
+    rec.update(pos2=pos2, acc2=acc, pot2=pot, extra2=extra, param2_json=np.array(param_to_json(param)))
+    assert np.isfinite(acc).all()
+    print("    fr n=2 finite; q =", param["fR_q"], "extra range", (extra.min(), extra.max()))
+    save("pm_fr2_multigrid", **rec)
+
+
 def g_mond():
     """G9: QUMOND interpolating functions and source-term stencils (mond.py)."""
     n = 16
@@ -447,6 +500,7 @@ GROUPS = {
     "deposit": g_deposit, "kspace": g_kspace, "gradient": g_gradient, "utils": g_utils,
     "pm_newton": g_pm_newton, "pk_pm": g_pk_pm, "integrate": g_integrate,
     "multigrid": g_multigrid, "cubic": g_cubic, "mond": g_mond, "pm_mg": g_pm_mg,
+    "quartic": g_quartic, "pm_fr2": g_pm_fr2,
 }
 
 if __name__ == "__main__":

@@ -195,7 +195,28 @@ void pmo_lap_gauss_seidel(float *x, const float *b, int n, float f_relax) {
     }
 }
 
-/* ------------------------------------------------------------------ f(R) n = 1 (cubic.py) ---- */
+/* ------------------------------------------------------------------ f(R) n = 1 (cubic.py) and n = 2 (quartic.py) ---- */
+
+/* quartic.py:157-210 solution_quartic_equation (fp64) */
+static inline double quartic_root(float pf, float qf) {
+    const double pp = (double)pf, qq = (double)qf;
+    if (pp == 0.0) return pow(-qq, 0.25);
+    const double d0 = 12.0 * qq, d1 = 27.0 * (pp * pp);
+    const double r = d0 / d1;
+    const double sqrt_term = 1.0 - 4.0 * d0 * (r * r);
+    if (sqrt_term < 0.0) return pow(-qq, 0.25);
+    const double Q = pow(0.5 * d1 * (1.0 + sqrt(sqrt_term)), 1.0 / 3.0);
+    const double Q_d0oQ = Q + d0 / Q;
+    if (Q_d0oQ > 0.0) {
+        const double S = 0.5 * sqrt(Q_d0oQ * (1.0 / 3.0));
+        if (pp > 0.0) return -S + 0.5 * sqrt(-4.0 * (S * S) + pp / S);
+        return S + 0.5 * sqrt(-4.0 * (S * S) - pp / S);
+    }
+    return pow(-qq, 0.25);
+}
+
+float pmo_quartic_solution(float p, float q) { return (float)quartic_root(p, q); }
+
 
 /* cubic.py:162-207 solution_cubic_equation (fp64) */
 static inline double cubic_root(float pf, float d1f) {
@@ -221,42 +242,49 @@ static inline double cubic_root(float pf, float d1f) {
 
 float pmo_cubic_solution(float p, float d1) { return (float)cubic_root(p, d1); }
 
-static inline float cubic_p(const float *x, const float *b, int n, int i, int j, int k, float h2, float invsix) {
+static inline float fr_pw(float a, int fr_n) { return fr_n == 1 ? a * a : a * a * a; } /* u^2 (n=1), u^3 (n=2) */
+
+static inline float cubic_p(const float *x, const float *b, int n, int i, int j, int k, float h2, float invsix,
+                            int fr_n) {
     const int im = wr(i - 1, n), ip = wr(i + 1, n), jm = wr(j - 1, n), jp = wr(j + 1, n), km = wr(k - 1, n),
               kp = wr(k + 1, n);
     const float a0 = x[IDX3(im, j, k, n)], a1 = x[IDX3(i, jm, k, n)], a2 = x[IDX3(i, j, km, n)],
                 a3 = x[IDX3(i, j, kp, n)], a4 = x[IDX3(i, jp, k, n)], a5 = x[IDX3(ip, j, k, n)];
-    return h2 * b[IDX3(i, j, k, n)] - invsix * (a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5);
+    return h2 * b[IDX3(i, j, k, n)] - invsix * (fr_pw(a0, fr_n) + fr_pw(a1, fr_n) + fr_pw(a2, fr_n) + fr_pw(a3, fr_n) +
+                                                 fr_pw(a4, fr_n) + fr_pw(a5, fr_n));
 }
 
-/* cubic.py:23-86 operator (rhs == NULL): u^3 + p u + q h^2 ; :90-158 residual_with_rhs: -(...) + rhs */
-void pmo_cubic_operator(const float *x, const float *b, float q, const float *rhs, int n, float *out) {
+static inline float fr_lead(float xt, int fr_n) { return fr_n == 1 ? xt * xt * xt : (xt * xt) * (xt * xt); }
+
+/* cubic.py:23-86 / quartic.py:20-82 operator (rhs == NULL): u^(n+2) + p u + q h^2 ;
+ * cubic.py:90-158 / quartic.py:86-152 residual_with_rhs: -(...) + rhs */
+void pmo_cubic_operator(const float *x, const float *b, float q, const float *rhs, int n, int fr_n, float *out) {
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
     const float qh2 = q * h2;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j)
             for (int k = 0; k < n; ++k) {
-                const float p = cubic_p(x, b, n, i, j, k, h2, invsix);
+                const float p = cubic_p(x, b, n, i, j, k, h2, invsix, fr_n);
                 const float xt = x[IDX3(i, j, k, n)];
                 if (!rhs)
-                    out[IDX3(i, j, k, n)] = xt * xt * xt + p * xt + qh2;
+                    out[IDX3(i, j, k, n)] = fr_lead(xt, fr_n) + p * xt + qh2;
                 else
-                    out[IDX3(i, j, k, n)] = -(xt * xt * xt) - p * xt - qh2 + rhs[IDX3(i, j, k, n)];
+                    out[IDX3(i, j, k, n)] = -(fr_lead(xt, fr_n)) - p * xt - qh2 + rhs[IDX3(i, j, k, n)];
             }
 }
 
 /* cubic.py:844-900 residual_error: sqrt(sum (u^3 + p u + q h^2)^2) */
-float pmo_cubic_residual_error(const float *x, const float *b, float q, int n) {
+float pmo_cubic_residual_error(const float *x, const float *b, float q, int n, int fr_n) {
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
     const float qh2 = q * h2;
     float result = 0.0f;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j)
             for (int k = 0; k < n; ++k) {
-                const float p = cubic_p(x, b, n, i, j, k, h2, invsix);
+                const float p = cubic_p(x, b, n, i, j, k, h2, invsix, fr_n);
                 const float xt = x[IDX3(i, j, k, n)];
-                const float r = xt * xt * xt + p * xt + qh2;
+                const float r = fr_lead(xt, fr_n) + p * xt + qh2;
                 result += r * r;
             }
     return sqrtf(result);
@@ -277,9 +305,26 @@ void pmo_cubic_initialise_potential(const float *b, float q, int n, float *out) 
     }
 }
 
-/* cubic.py:269-442 gauss_seidel (rhs == NULL) and :446-668 gauss_seidel_with_rhs */
-void pmo_cubic_gauss_seidel(float *x, const float *b, float q, const float *rhs, int n, float f_relax) {
+/* quartic.py:214-266 initialise_potential (fp64 throughout) */
+void pmo_quartic_initialise_potential(const float *b, float q, int n, float *out) {
+    const double h2 = 1.0 / ((double)n * n);
+    const double d0 = 12.0 * h2 * (double)q;
+    const int64_t count = (int64_t)n * n * n;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < count; ++i) {
+        const double p = h2 * (double)b[i];
+        const double d1 = 27.0 * (p * p);
+        const double Q = pow(0.5 * (d1 + sqrt(d1 * d1 - 4.0 * (d0 * d0 * d0))), 1.0 / 3.0);
+        const double S = 0.5 * sqrt((Q + d0 / Q) * (1.0 / 3.0));
+        out[i] = (float)(-S + 0.5 * sqrt(-4.0 * (S * S) + p / S));
+    }
+}
+
+/* cubic.py:269-442 / quartic.py:270-444 gauss_seidel (rhs == NULL) and cubic.py:446-668 /
+ * quartic.py:448-632 gauss_seidel_with_rhs */
+void pmo_cubic_gauss_seidel(float *x, const float *b, float q, const float *rhs, int n, int fr_n, float f_relax) {
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
+    const float qh2 = q * h2; /* quartic.py:306 */
     const float d1_q = rhs ? 27.0f * h2 * q : (float)(27.0 * (double)h2 * (double)q);
     for (int colour = 1; colour >= 0; --colour) {
 #pragma omp parallel for schedule(static)
@@ -288,9 +333,15 @@ void pmo_cubic_gauss_seidel(float *x, const float *b, float q, const float *rhs,
                 for (int k = 0; k < n; ++k) {
                     if (((i + j + k) & 1) != colour) continue;
                     const size_t c = IDX3(i, j, k, n);
-                    const float p = cubic_p(x, b, n, i, j, k, h2, invsix);
-                    const float d1 = rhs ? d1_q - 27.0f * rhs[c] : d1_q;
-                    const float sol = (float)cubic_root(p, d1);
+                    const float p = cubic_p(x, b, n, i, j, k, h2, invsix, fr_n);
+                    float sol;
+                    if (fr_n == 1) {
+                        const float d1 = rhs ? d1_q - 27.0f * rhs[c] : d1_q;
+                        sol = (float)cubic_root(p, d1);
+                    } else {
+                        const float qq = rhs ? qh2 - rhs[c] : qh2;
+                        sol = (float)quartic_root(p, qq);
+                    }
                     x[c] += f_relax * (sol - x[c]);
                 }
     }

@@ -43,7 +43,7 @@ def _lib(omp: bool = False):
         name = "libpm_oracle_omp.so" if omp else "libpm_oracle.so"
         lib = C.CDLL(os.path.join(_HERE, "_build", name))
         for fn in ("pmo_max_abs", "pmo_lap_residual_error", "pmo_diff_norm", "pmo_cubic_residual_error",
-                   "pmo_cubic_solution", "pmo_mond_nu"):
+                   "pmo_cubic_solution", "pmo_quartic_solution", "pmo_mond_nu"):
             getattr(lib, fn).restype = C.c_float
         lib.pmo_num_threads.restype = C.c_int
         _libs[key] = lib
@@ -564,17 +564,28 @@ def lap_smoothing(x, b, n_smoothing) -> None:  # laplacian.py:1026
 # ------------------------------------------------------------------ cubic.py (f(R), n = 1)
 
 
-def cubic_operator(x, b, q) -> np.ndarray:  # cubic.py:23
+def cubic_operator(x, b, q, fr_n: int = 1) -> np.ndarray:  # cubic.py:23 / quartic.py:20
     x, b = _c32(x), _c32(b)
     out = np.empty_like(x)
-    _lib(_use_omp).pmo_cubic_operator(_p(x), _p(b), C.c_float(q), None, C.c_int(x.shape[0]), _p(out))
+    _lib(_use_omp).pmo_cubic_operator(_p(x), _p(b), C.c_float(q), None, C.c_int(x.shape[0]), C.c_int(fr_n), _p(out))
     return out
 
 
-def cubic_residual_with_rhs(x, b, q, rhs) -> np.ndarray:  # cubic.py:90
+def cubic_residual_with_rhs(x, b, q, rhs, fr_n: int = 1) -> np.ndarray:  # cubic.py:90 / quartic.py:86
     x, b, rhs = _c32(x), _c32(b), _c32(rhs)
     out = np.empty_like(x)
-    _lib(_use_omp).pmo_cubic_operator(_p(x), _p(b), C.c_float(q), _p(rhs), C.c_int(x.shape[0]), _p(out))
+    _lib(_use_omp).pmo_cubic_operator(_p(x), _p(b), C.c_float(q), _p(rhs), C.c_int(x.shape[0]), C.c_int(fr_n), _p(out))
+    return out
+
+
+def solution_quartic_equation(p, q) -> np.float32:  # quartic.py:157
+    return np.float32(_lib(False).pmo_quartic_solution(C.c_float(p), C.c_float(q)))
+
+
+def quartic_initialise_potential(b, q) -> np.ndarray:  # quartic.py:214
+    b = _c32(b)
+    out = np.empty_like(b)
+    _lib(_use_omp).pmo_quartic_initialise_potential(_p(b), C.c_float(q), C.c_int(b.shape[0]), _p(out))
     return out
 
 
@@ -589,27 +600,28 @@ def cubic_initialise_potential(b, q) -> np.ndarray:  # cubic.py:217
     return out
 
 
-def cubic_gauss_seidel(x, b, q, f_relax, rhs=None) -> None:  # cubic.py:269 / :446
+def cubic_gauss_seidel(x, b, q, f_relax, rhs=None, fr_n: int = 1) -> None:  # cubic.py:269/:446, quartic.py:270/:448
     assert x.dtype == np.float32 and x.flags.c_contiguous
     b = _c32(b)
     r = None if rhs is None else _c32(rhs)
     _lib(_use_omp).pmo_cubic_gauss_seidel(_p(x), _p(b), C.c_float(q), None if r is None else _p(r),
-                                          C.c_int(x.shape[0]), C.c_float(f_relax))
+                                          C.c_int(x.shape[0]), C.c_int(fr_n), C.c_float(f_relax))
 
 
-def cubic_smoothing(x, b, q, n_smoothing, rhs=None) -> None:  # cubic.py:1065 / :1100
+def cubic_smoothing(x, b, q, n_smoothing, rhs=None, fr_n: int = 1) -> None:  # cubic.py:1065 / :1100
     for _ in range(int(n_smoothing)):
-        cubic_gauss_seidel(x, b, q, np.float32(1.25), rhs)
+        cubic_gauss_seidel(x, b, q, np.float32(1.25), rhs, fr_n)
 
 
-def cubic_residual_error(x, b, q) -> np.float32:  # cubic.py:844
+def cubic_residual_error(x, b, q, fr_n: int = 1) -> np.float32:  # cubic.py:844 / quartic.py:844
     x, b = _c32(x), _c32(b)
-    return np.float32(_lib(False).pmo_cubic_residual_error(_p(x), _p(b), C.c_float(q), C.c_int(x.shape[0])))
+    return np.float32(_lib(False).pmo_cubic_residual_error(_p(x), _p(b), C.c_float(q), C.c_int(x.shape[0]),
+                                                           C.c_int(fr_n)))
 
 
-def cubic_truncation_error(x, b, q) -> np.float32:  # cubic.py:1021
-    RLx = restriction(cubic_operator(x, b, q))
-    LRx = cubic_operator(restriction(x), restriction(b), q)
+def cubic_truncation_error(x, b, q, fr_n: int = 1) -> np.float32:  # cubic.py:1021 / quartic.py:1022
+    RLx = restriction(cubic_operator(x, b, q, fr_n))
+    LRx = cubic_operator(restriction(x), restriction(b), q, fr_n)
     return _diff_norm(RLx, LRx, 4.0)
 
 
@@ -635,9 +647,11 @@ def mond_rhs(potential, out, g0, kind: str, alpha=1.0) -> None:  # mond.py:171-9
 def initialise_potential(potential, rhs, param, tables):  # solver.py:218-282
     if len(potential) == 0:
         if param["compute_additional_field"] and param["theory"].casefold() == "fr":
-            if param["fR_n"] != 1:
-                raise NotImplementedError("oracle: only f(R) n = 1")
-            return cubic_initialise_potential(rhs, param["fR_q"])
+            if param["fR_n"] == 1:
+                return cubic_initialise_potential(rhs, param["fR_q"])
+            if param["fR_n"] == 2:
+                return quartic_initialise_potential(rhs, param["fR_q"])
+            raise NotImplementedError(f"Only f(R) with n = 1 and 2, currently {param['fR_n']=}")
         return lap_initialise_potential(rhs)
     if not param["compute_additional_field"]:
         scaling = (param["aexp"] * tables[3](np.log(param["aexp"]))
@@ -681,38 +695,40 @@ def mg_linear(x, b, param, info: dict | None = None):  # multigrid.py:23-83
     return x
 
 
-def V_cycle_FAS(x, b, param, nlevel=0, rhs=None) -> None:  # multigrid.py:521-579 (f(R) n=1 branch)
-    q = np.float32(param["fR_q"])
-    cubic_smoothing(x, b, q, param["Npre"], rhs)
+def V_cycle_FAS(x, b, param, nlevel=0, rhs=None) -> None:  # multigrid.py:521-579 (f(R) branches)
+    q, m = np.float32(param["fR_q"]), int(param["fR_n"])
+    cubic_smoothing(x, b, q, param["Npre"], rhs, m)
     if rhs is None:
-        res_c = minus_restriction(cubic_operator(x, b, q))
+        res_c = minus_restriction(cubic_operator(x, b, q, m))
     else:
-        res_c = restriction(cubic_residual_with_rhs(x, b, q, rhs))
+        res_c = restriction(cubic_residual_with_rhs(x, b, q, rhs, m))
     x_c = restriction(x)
     x_corr_c = x_c.copy()
     b_c = restriction(b)
-    L_c = cubic_operator(x_c, b_c, q)
+    L_c = cubic_operator(x_c, b_c, q, m)
     linear_operator_vectors_inplace(res_c, np.float32(4), L_c, np.float32(1))
     if nlevel >= (param["ncoarse"] - 3):
-        cubic_smoothing(x_corr_c, b_c, q, param["Npre"], res_c)
+        cubic_smoothing(x_corr_c, b_c, q, param["Npre"], res_c, m)
     else:
         V_cycle_FAS(x_corr_c, b_c, param, nlevel + 1, res_c)
     add_vector_scalar_inplace(x_corr_c, x_c, np.float32(-1))
     add_prolongation(x, x_corr_c)
-    cubic_smoothing(x, b, q, param["Npost"], rhs)
+    cubic_smoothing(x, b, q, param["Npost"], rhs, m)
 
 
 def FAS(x, b, param, info: dict | None = None):  # multigrid.py:88-138
-    q = np.float32(param["fR_q"])
+    q, m = np.float32(param["fR_q"]), int(param["fR_n"])
+    if m not in (1, 2):
+        raise NotImplementedError(f"Only f(R) with n = 1 and 2, currently {param['fR_n']=}")
     if ("tolerance_FAS" not in param) or (param["nsteps"] % 3) == 0:
-        param["tolerance_FAS"] = param["epsrel"] * cubic_truncation_error(x, b, q)
+        param["tolerance_FAS"] = param["epsrel"] * cubic_truncation_error(x, b, q, m)
     tolerance = param["tolerance_FAS"]
     residual_err = 1e30
     cycles = 0
     while residual_err > tolerance:
         V_cycle_FAS(x, b, param)
         cycles += 1
-        tmp = cubic_residual_error(x, b, q)
+        tmp = cubic_residual_error(x, b, q, m)
         if tmp < tolerance or residual_err / tmp < 2:
             break
         residual_err = tmp

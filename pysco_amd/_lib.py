@@ -64,6 +64,10 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_cubic_residual_error": (_vp, _vp, _vp, _f, _i, C.POINTER(_f)),
     "pm_cubic_initialise_potential": (_vp, _vp, _f, _i, _vp),
     "pm_cubic_gauss_seidel": (_vp, _vp, _vp, _f, _vp, _i, _f),
+    "pm_quartic_operator": (_vp, _vp, _vp, _f, _vp, _i, _vp),
+    "pm_quartic_residual_error": (_vp, _vp, _vp, _f, _i, C.POINTER(_f)),
+    "pm_quartic_initialise_potential": (_vp, _vp, _f, _i, _vp),
+    "pm_quartic_gauss_seidel": (_vp, _vp, _vp, _f, _vp, _i, _f),
     "pm_mond_rhs": (_vp, _vp, _vp, _i, _f, _i, _f),
     "pm_set_slab": (_vp, _i, _i),
     "pm_gradient_slab": (_vp, _i, _vp, _i, _i, _vp, _i, _i),

@@ -267,7 +267,35 @@ extern "C" int pm_lap_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// f(R) n = 1 (cubic.py)
+// f(R) n = 1 (cubic.py) and n = 2 (quartic.py): same stencil with u^2 / u^3 neighbour powers and the
+// depressed cubic / quartic root; kernels are templated on FRN = 1, 2.
+
+// quartic.py:157-210 solution_quartic_equation: fp64, same branch structure
+__device__ __forceinline__ double quartic_root(float pf, float qf) {
+    const double pp = (double)pf, qq = (double)qf;
+    if (pp == 0.0) return pow(-qq, 0.25);
+    const double d0 = 12.0 * qq, d1 = 27.0 * (pp * pp);
+    const double r = d0 / d1;
+    const double sqrt_term = 1.0 - 4.0 * d0 * (r * r);
+    if (sqrt_term < 0.0) return pow(-qq, 0.25);
+    const double Q = pow(0.5 * d1 * (1.0 + sqrt(sqrt_term)), 1.0 / 3.0);
+    const double Q_d0oQ = Q + d0 / Q;
+    if (Q_d0oQ > 0.0) {
+        const double S = 0.5 * sqrt(Q_d0oQ * (1.0 / 3.0));
+        if (pp > 0.0) return -S + 0.5 * sqrt(-4.0 * (S * S) + pp / S);
+        return S + 0.5 * sqrt(-4.0 * (S * S) - pp / S);
+    }
+    return pow(-qq, 0.25);
+}
+
+template <int FRN>
+__device__ __forceinline__ float fr_pw(float a) {
+    return FRN == 1 ? a * a : a * a * a;
+}
+template <int FRN>
+__device__ __forceinline__ float fr_lead(float x) {
+    return FRN == 1 ? x * x * x : (x * x) * (x * x);
+}
 
 // cubic.py:162-207 solution_cubic_equation: fp64, same branch structure (NaNs included)
 __device__ __forceinline__ double cubic_root(float pf, float d1f) {
@@ -291,16 +319,18 @@ __device__ __forceinline__ double cubic_root(float pf, float d1f) {
     return -inv3 * pow(d1, inv3);
 }
 
+template <int FRN>
 __device__ __forceinline__ float cubic_p(const float *__restrict__ x, const float *__restrict__ b, int i, int j, int k,
                                          int m, int log2n, float h2, float invsix) {
     const float a0 = x[cidx((i - 1) & m, j, k, log2n)], a1 = x[cidx(i, (j - 1) & m, k, log2n)],
                 a2 = x[cidx(i, j, (k - 1) & m, log2n)], a3 = x[cidx(i, j, (k + 1) & m, log2n)],
                 a4 = x[cidx(i, (j + 1) & m, k, log2n)], a5 = x[cidx((i + 1) & m, j, k, log2n)];
-    return h2 * b[cidx(i, j, k, log2n)] - invsix * (a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5);
+    return h2 * b[cidx(i, j, k, log2n)] - invsix * (fr_pw<FRN>(a0) + fr_pw<FRN>(a1) + fr_pw<FRN>(a2) + fr_pw<FRN>(a3) +
+                                                    fr_pw<FRN>(a4) + fr_pw<FRN>(a5));
 }
 
 // cubic.py:23-86 operator / :90-158 residual_with_rhs (mode 1) / :844-900 residual_error (mode 2)
-template <int MODE>
+template <int MODE, int FRN>
 __global__ __launch_bounds__(BLK) void cubic_operator_kernel(const float *__restrict__ x, const float *__restrict__ b,
                                                              float qh2, const float *__restrict__ rhs, int log2n,
                                                              float h2, float invsix, float *__restrict__ out,
@@ -310,45 +340,61 @@ __global__ __launch_bounds__(BLK) void cubic_operator_kernel(const float *__rest
     double acc = 0;
     for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
         const int k = (int)(t & m), j = (int)((t >> log2n) & m), i = (int)(t >> (2 * log2n));
-        const float p = cubic_p(x, b, i, j, k, m, log2n, h2, invsix);
+        const float p = cubic_p<FRN>(x, b, i, j, k, m, log2n, h2, invsix);
         const float xt = x[t];
-        if (MODE == 0) out[t] = xt * xt * xt + p * xt + qh2;
-        if (MODE == 1) out[t] = -(xt * xt * xt) - p * xt - qh2 + rhs[t];
+        if (MODE == 0) out[t] = fr_lead<FRN>(xt) + p * xt + qh2;
+        if (MODE == 1) out[t] = -(fr_lead<FRN>(xt)) - p * xt - qh2 + rhs[t];
         if (MODE == 2) {
-            const float r = xt * xt * xt + p * xt + qh2;
+            const float r = fr_lead<FRN>(xt) + p * xt + qh2;
             acc += (double)(r * r);
         }
     }
     if (MODE == 2) block_sum_to(acc, result);
 }
 
-extern "C" int pm_cubic_operator(pm_ctx *c, const float *d_x, const float *d_b, float q, const float *d_rhs, int n,
-                                 float *d_out) {
+template <int FRN>
+static int fr_operator(pm_ctx *c, const float *d_x, const float *d_b, float q, const float *d_rhs, int n, float *d_out) {
     PM_REQUIRE(c && d_x && d_b && d_out, "NULL argument");
     PM_CHECK_GRID(n);
     const int64_t total = (int64_t)n * n * n;
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
     const int blocks = pm_stream_blocks(total, BLK);
     if (d_rhs)
-        hipLaunchKernelGGL((cubic_operator_kernel<1>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, q * h2, d_rhs,
-                           ilog2(n), h2, invsix, d_out, (double *)nullptr);
+        hipLaunchKernelGGL((cubic_operator_kernel<1, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, q * h2,
+                           d_rhs, ilog2(n), h2, invsix, d_out, (double *)nullptr);
     else
-        hipLaunchKernelGGL((cubic_operator_kernel<0>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, q * h2, d_rhs,
-                           ilog2(n), h2, invsix, d_out, (double *)nullptr);
+        hipLaunchKernelGGL((cubic_operator_kernel<0, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, q * h2,
+                           d_rhs, ilog2(n), h2, invsix, d_out, (double *)nullptr);
     PM_LAUNCH_CHECK();
     return PM_OK;
 }
 
-extern "C" int pm_cubic_residual_error(pm_ctx *c, const float *d_x, const float *d_b, float q, int n, float *h_out) {
+template <int FRN>
+static int fr_residual_error(pm_ctx *c, const float *d_x, const float *d_b, float q, int n, float *h_out) {
     PM_REQUIRE(c && d_x && d_b && h_out, "NULL argument");
     PM_CHECK_GRID(n);
     PM_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(double), c->stream));
     const int64_t total = (int64_t)n * n * n;
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
-    hipLaunchKernelGGL((cubic_operator_kernel<2>), dim3(pm_stream_blocks(total, BLK * 4)), dim3(BLK), 0, c->stream, d_x,
-                       d_b, q * h2, (const float *)nullptr, ilog2(n), h2, invsix, (float *)nullptr, c->d_hist);
+    hipLaunchKernelGGL((cubic_operator_kernel<2, FRN>), dim3(pm_stream_blocks(total, BLK * 4)), dim3(BLK), 0, c->stream,
+                       d_x, d_b, q * h2, (const float *)nullptr, ilog2(n), h2, invsix, (float *)nullptr, c->d_hist);
     PM_LAUNCH_CHECK();
     return read_norm(c, h_out);
+}
+
+extern "C" int pm_cubic_operator(pm_ctx *c, const float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                                 float *d_out) {
+    return fr_operator<1>(c, d_x, d_b, q, d_rhs, n, d_out);
+}
+extern "C" int pm_quartic_operator(pm_ctx *c, const float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                                   float *d_out) {
+    return fr_operator<2>(c, d_x, d_b, q, d_rhs, n, d_out);
+}
+extern "C" int pm_cubic_residual_error(pm_ctx *c, const float *d_x, const float *d_b, float q, int n, float *h_out) {
+    return fr_residual_error<1>(c, d_x, d_b, q, n, h_out);
+}
+extern "C" int pm_quartic_residual_error(pm_ctx *c, const float *d_x, const float *d_b, float q, int n, float *h_out) {
+    return fr_residual_error<2>(c, d_x, d_b, q, n, h_out);
 }
 
 // cubic.py:217-265 initialise_potential (fp64 per cell under Numba's typing)
@@ -373,9 +419,33 @@ extern "C" int pm_cubic_initialise_potential(pm_ctx *c, const float *d_b, float 
     return PM_OK;
 }
 
-// cubic.py:269-442 gauss_seidel / :446-668 gauss_seidel_with_rhs: one launch per colour, one thread
-// per cell of that colour
-template <int COLOUR, bool WITH_RHS>
+// quartic.py:214-266 initialise_potential (fp64 throughout)
+__global__ __launch_bounds__(BLK) void quartic_init_kernel(const float *__restrict__ b, double h2, double d0,
+                                                           int64_t count, float *__restrict__ out) {
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < count; t += (int64_t)gridDim.x * BLK) {
+        const double p = h2 * (double)b[t];
+        const double d1 = 27.0 * (p * p);
+        const double Q = pow(0.5 * (d1 + sqrt(d1 * d1 - 4.0 * (d0 * d0 * d0))), 1.0 / 3.0);
+        const double S = 0.5 * sqrt((Q + d0 / Q) * (1.0 / 3.0));
+        out[t] = (float)(-S + 0.5 * sqrt(-4.0 * (S * S) + p / S));
+    }
+}
+
+extern "C" int pm_quartic_initialise_potential(pm_ctx *c, const float *d_b, float q, int n, float *d_out) {
+    PM_REQUIRE(c && d_b && d_out, "NULL argument");
+    PM_CHECK_GRID(n);
+    const int64_t total = (int64_t)n * n * n;
+    const double h2 = 1.0 / ((double)n * n);
+    hipLaunchKernelGGL(quartic_init_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_b, h2,
+                       12.0 * h2 * (double)q, total, d_out);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// cubic.py:269-442 / quartic.py:270-444 gauss_seidel and cubic.py:446-668 / quartic.py:448-632
+// gauss_seidel_with_rhs: one launch per colour, one thread per cell of that colour.  `c_q` is 27 h^2 q
+// for the cubic (d1 = c_q - 27 rhs) and q h^2 for the quartic (qq = c_q - rhs).
+template <int COLOUR, bool WITH_RHS, int FRN>
 __global__ __launch_bounds__(BLK) void cubic_gauss_seidel_kernel(float *__restrict__ x, const float *__restrict__ b,
                                                                  float d1_q, const float *__restrict__ rhs, int log2n,
                                                                  float h2, float invsix, float f_relax) {
@@ -385,37 +455,58 @@ __global__ __launch_bounds__(BLK) void cubic_gauss_seidel_kernel(float *__restri
         const int kh = (int)(t & (nh - 1)), j = (int)((t >> log2nh) & m), i = (int)(t >> (log2nh + log2n));
         const int k = 2 * kh + ((i + j + COLOUR) & 1);
         const int64_t c = cidx(i, j, k, log2n);
-        const float p = cubic_p(x, b, i, j, k, m, log2n, h2, invsix);
-        const float d1 = WITH_RHS ? d1_q - 27.0f * rhs[c] : d1_q;
-        const float sol = (float)cubic_root(p, d1);
+        const float p = cubic_p<FRN>(x, b, i, j, k, m, log2n, h2, invsix);
+        float sol;
+        if (FRN == 1) {
+            const float d1 = WITH_RHS ? d1_q - 27.0f * rhs[c] : d1_q;
+            sol = (float)cubic_root(p, d1);
+        } else {
+            const float qq = WITH_RHS ? d1_q - rhs[c] : d1_q;
+            sol = (float)quartic_root(p, qq);
+        }
         const float xc = x[c];
         x[c] = xc + f_relax * (sol - xc);
     }
 }
 
-extern "C" int pm_cubic_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
-                                     float f_relax) {
+template <int FRN>
+static int fr_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                           float f_relax) {
     PM_REQUIRE(c && d_x && d_b, "NULL argument");
     PM_CHECK_GRID(n);
     const int64_t total = (int64_t)n * n * (n / 2);
     const int blocks = pm_stream_blocks(total, BLK);
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
     const int l2 = ilog2(n);
+    float c_q;
+    if (FRN == 2)
+        c_q = q * h2;  // quartic.py:306, 488
+    else if (d_rhs)
+        c_q = 27.0f * h2 * q;  // cubic.py:487 (all fp32)
+    else
+        c_q = (float)(27.0 * (double)h2 * (double)q);  // cubic.py:305 (int * f4 -> f8, then f4)
     if (d_rhs) {
-        const float d1_q = 27.0f * h2 * q;  // cubic.py:487 (all fp32)
-        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, true>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, d1_q,
-                           d_rhs, l2, h2, invsix, f_relax);
-        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, true>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, d1_q,
-                           d_rhs, l2, h2, invsix, f_relax);
+        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, true, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
+                           c_q, d_rhs, l2, h2, invsix, f_relax);
+        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, true, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
+                           c_q, d_rhs, l2, h2, invsix, f_relax);
     } else {
-        const float d1_q = (float)(27.0 * (double)h2 * (double)q);  // cubic.py:305 (int * f4 -> f8, then f4)
-        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, false>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, d1_q,
-                           d_rhs, l2, h2, invsix, f_relax);
-        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, false>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, d1_q,
-                           d_rhs, l2, h2, invsix, f_relax);
+        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, false, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
+                           c_q, d_rhs, l2, h2, invsix, f_relax);
+        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, false, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
+                           c_q, d_rhs, l2, h2, invsix, f_relax);
     }
     PM_LAUNCH_CHECK();
     return PM_OK;
+}
+
+extern "C" int pm_cubic_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                                     float f_relax) {
+    return fr_gauss_seidel<1>(c, d_x, d_b, q, d_rhs, n, f_relax);
+}
+extern "C" int pm_quartic_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                                       float f_relax) {
+    return fr_gauss_seidel<2>(c, d_x, d_b, q, d_rhs, n, f_relax);
 }
 
 // ------------------------------------------------------------------------------------------------

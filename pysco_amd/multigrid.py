@@ -13,7 +13,7 @@ import logging
 import numpy as np
 
 from . import _lib as L
-from . import cubic, laplacian, mesh, utils
+from . import cubic, laplacian, mesh, quartic, utils
 
 
 def _is_fr_field(param) -> bool:
@@ -64,19 +64,21 @@ def V_cycle(x, b, param, nlevel: int = 0) -> None:
 # ---- dispatch helpers (multigrid.py:142-470); only the f(R) n = 1 branch is reachable from pm() --------
 
 
-def _need_cubic(param):
+def _fr(param):
+    """(module, q) of the scalaron operator: cubic for n = 1, quartic for n = 2."""
     if not _is_fr_field(param):
         raise NotImplementedError(
             "FAS for non-f(R) theories (laplacian_reformulated) is never reached from solver.pm() and is not built")
+    if param["fR_n"] == 1:
+        return cubic, np.float32(param["fR_q"])
     if param["fR_n"] == 2:
-        raise NotImplementedError("f(R) n = 2 (quartic.py) is not built yet")
-    if param["fR_n"] != 1:
-        raise NotImplementedError(f"Only f(R) with n = 1 and 2, currently {param['fR_n']=}")
-    return np.float32(param["fR_q"])
+        return quartic, np.float32(param["fR_q"])
+    raise NotImplementedError(f"Only f(R) with n = 1 and 2, currently {param['fR_n']=}")
 
 
 def truncation_error(x, param, b=None) -> np.float32:  # multigrid.py:142
-    return cubic.truncation_error(x, b, _need_cubic(param))
+    mod, q = _fr(param)
+    return mod.truncation_error(x, b, q)
 
 
 def normalisation_residual(param) -> np.float32:  # multigrid.py:192
@@ -84,26 +86,28 @@ def normalisation_residual(param) -> np.float32:  # multigrid.py:192
 
 
 def residual_error(x, b, param) -> np.float32:  # multigrid.py:231
-    return cubic.residual_error(x, b, _need_cubic(param))
+    mod, q = _fr(param)
+    return mod.residual_error(x, b, q)
 
 
 def restrict_residual(x, b, param, rhs=None):  # multigrid.py:282
-    q = _need_cubic(param)
+    mod, q = _fr(param)
     if rhs is None or len(rhs) == 0:
-        return mesh.minus_restriction(cubic.operator(x, b, q))
-    return mesh.restriction(cubic.residual_with_rhs(x, b, q, rhs))
+        return mesh.minus_restriction(mod.operator(x, b, q))
+    return mesh.restriction(mod.residual_with_rhs(x, b, q, rhs))
 
 
 def smoothing(x, b, n_smoothing, param, rhs=None) -> None:  # multigrid.py:350
-    q = _need_cubic(param)
+    mod, q = _fr(param)
     if rhs is None or len(rhs) == 0:
-        cubic.smoothing(x, b, q, n_smoothing)
+        mod.smoothing(x, b, q, n_smoothing)
     else:
-        cubic.smoothing_with_rhs(x, b, q, n_smoothing, rhs)
+        mod.smoothing_with_rhs(x, b, q, n_smoothing, rhs)
 
 
 def operator(x, param, b=None):  # multigrid.py:420
-    return cubic.operator(x, b, _need_cubic(param))
+    mod, q = _fr(param)
+    return mod.operator(x, b, q)
 
 
 def FAS(x, b, param):

@@ -14,7 +14,7 @@ def amd():
     import torch
 
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
-    from pysco_amd import cubic, laplacian, mesh, mond, multigrid, solver, utils
+    from pysco_amd import cubic, laplacian, mesh, mond, multigrid, quartic, solver, utils
 
     class NS:
         pass
@@ -22,6 +22,7 @@ def amd():
     ns = NS()
     ns.cubic, ns.laplacian, ns.mesh, ns.mond, ns.multigrid, ns.solver, ns.utils, ns.torch = (
         cubic, laplacian, mesh, mond, multigrid, solver, utils, torch)
+    ns.quartic = quartic
     return ns
 
 
@@ -147,6 +148,31 @@ def test_cubic_root_branches(amd):
     assert ok.sum() > 100 and (~ok).sum() > 0
 
 
+def test_quartic(amd, golden):
+    g = golden("quartic_n16")
+    u, b, rhs, q = g["u"], g["b"], g["rhs"], np.float32(g["q"])
+    s = _scale(g["operator"])
+    np.testing.assert_array_equal(amd.quartic.operator(u, b, q), orc.cubic_operator(u, b, q, 2))
+    np.testing.assert_array_equal(amd.quartic.residual_with_rhs(u, b, q, rhs), orc.cubic_residual_with_rhs(u, b, q, rhs, 2))
+    np.testing.assert_allclose(amd.quartic.operator(u, b, q), g["operator"], rtol=0, atol=5e-6 * s)
+    np.testing.assert_allclose(amd.quartic.initialise_potential(b, q), g["initialise_potential"], rtol=2e-5)
+    np.testing.assert_allclose(amd.quartic.initialise_potential(b, q), orc.quartic_initialise_potential(b, q), rtol=3e-7)
+    for with_rhs in (False, True):
+        y, yo = u.copy(), u.copy()
+        if with_rhs:
+            amd.quartic.gauss_seidel_with_rhs(y, b, q, rhs, np.float32(1.25))
+            orc.cubic_gauss_seidel(yo, b, q, np.float32(1.25), rhs, 2)
+            ref = g["gauss_seidel_with_rhs"]
+        else:
+            amd.quartic.gauss_seidel(y, b, q, np.float32(1.25))
+            orc.cubic_gauss_seidel(yo, b, q, np.float32(1.25), None, 2)
+            ref = g["gauss_seidel"]
+        np.testing.assert_allclose(y, yo, rtol=0, atol=3e-7)
+        np.testing.assert_allclose(y, ref, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(amd.quartic.residual_error(u, b, q), g["residual_error"], rtol=1e-5)
+    np.testing.assert_allclose(amd.quartic.truncation_error(u, b, q), g["truncation_error"], rtol=1e-4)
+
+
 def test_mond(amd, golden):
     g = golden("mond_n16")
     for name, fn, kw, alpha in (("simple", amd.mond.rhs_simple, {}, 1), ("n", amd.mond.rhs_n, {"n": 2}, 2),
@@ -162,7 +188,7 @@ def test_mond(amd, golden):
         np.testing.assert_allclose(out, oo, rtol=0, atol=4e-6 * _scale(ref), err_msg=name + " vs oracle")
 
 
-PM_MG = ["newton_multigrid", "fr_multigrid", "mond_multigrid", "mond_fft7pt"]
+PM_MG = ["newton_multigrid", "fr_multigrid", "fr2_multigrid", "mond_multigrid", "mond_fft7pt"]
 
 
 @pytest.mark.parametrize("tag", PM_MG)

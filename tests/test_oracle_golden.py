@@ -276,3 +276,29 @@ def test_pm_multigrid_theories(golden, tag):
     acc, pot, extra = orc.pm(g["pos2"], param, pot, extra, tables)
     np.testing.assert_allclose(pot, g["pot2"], rtol=0, atol=5e-4 * sp)
     np.testing.assert_allclose(acc, g["acc2"], rtol=0, atol=2e-3 * sa)
+
+
+def test_quartic(golden):
+    g = golden("quartic_n16")
+    u, b, rhs, q = g["u"], g["b"], g["rhs"], np.float32(g["q"])
+    s = float(np.abs(g["operator"]).max())
+    np.testing.assert_allclose(orc.cubic_operator(u, b, q, 2), g["operator"], rtol=0, atol=5e-6 * s)
+    np.testing.assert_allclose(orc.cubic_residual_with_rhs(u, b, q, rhs, 2), g["residual_with_rhs"], rtol=0, atol=5e-6 * s)
+    np.testing.assert_allclose(orc.quartic_initialise_potential(b, q), g["initialise_potential"], rtol=2e-5)
+    roots = np.array([orc.solution_quartic_equation(p, qq) for p, qq in g["root_pq"]], dtype=np.float32)
+    ref = g["root"]
+    assert np.array_equal(np.isnan(roots), np.isnan(ref))  # same branch structure, NaNs included
+    ok = ~np.isnan(ref)
+    np.testing.assert_allclose(roots[ok], ref[ok], rtol=3e-6, atol=1e-6)
+    y = u.copy()
+    orc.cubic_gauss_seidel(y, b, q, np.float32(1.25), None, 2)
+    np.testing.assert_allclose(y, g["gauss_seidel"], rtol=0, atol=5e-6)
+    y = u.copy()
+    orc.cubic_gauss_seidel(y, b, q, np.float32(1.25), rhs, 2)
+    np.testing.assert_allclose(y, g["gauss_seidel_with_rhs"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(orc.cubic_residual_error(u, b, q, 2), g["residual_error"], rtol=1e-5)
+    np.testing.assert_allclose(orc.cubic_truncation_error(u, b, q, 2), g["truncation_error"], rtol=1e-4)
+
+
+def test_pm_fr_n2(golden):
+    test_pm_multigrid_theories(golden, "fr2_multigrid")
