@@ -97,6 +97,7 @@ def alg_bytes(n, npart):
         "pm_fft_r2c": 24.0 * cells,                  # 3 axis passes, read+write
         "pm_greens": 2.0 * spec,                     # read+write half spectrum (0 in the fused ideal)
         "pm_fft_c2r": 24.0 * cells,
+        "pm_poisson_fft_fused": 48.0 * cells,       # r2c + Green's function + c2r in five LDS-FFT passes
         "pm_gradient": 16.0 * cells,                 # read phi, write F(3)
         "pm_interp": 24.0 * npart + 12.0 * cells,    # read x, F; write a
         "pm_interp_kick": 48.0 * npart + 12.0 * cells,  # gather + second kick + CFL maxima: read x,v,F; write v,a
@@ -231,7 +232,7 @@ def main():
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         del pos, vel, acc, phi, extra
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(args.cpu_ncells)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_ncells, steps=6)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

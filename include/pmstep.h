@@ -102,6 +102,10 @@ int pm_pk(pm_ctx *ctx, int p, void *d_xk, const float *h_sinc, double *h_ksum, d
  * unless d_phi == d_rhs. */
 int pm_poisson_fft(pm_ctx *ctx, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
                    const float *h_s, float c0);
+/* Same result as pm_poisson_fft without rocFFT: five LDS-resident 1-D FFT passes with the Green's
+ * function applied between the forward and inverse x transforms (32 <= n <= 1024). */
+int pm_poisson_fft_fused(pm_ctx *ctx, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
+                         const float *h_s, float c0);
 /* leapfrog first half, integration.py:250-258: v += -half_dt*a ; x += dt*v ; periodic_wrap(x) */
 int pm_kick_drift_wrap(pm_ctx *ctx, float *d_pos, float *d_vel, const float *d_acc, float half_dt, float dt,
                        int64_t np);

@@ -77,6 +77,10 @@ extern "C" int pm_ctx_destroy(pm_ctx *c) {
     if (c->info_c2r) rocfft_execution_info_destroy(c->info_c2r);
     if (c->fft_work) hipFree(c->fft_work);
     if (c->d_spec) hipFree(c->d_spec);
+    if (c->fp_B) hipFree(c->fp_B);
+    if (c->fp_C) hipFree(c->fp_C);
+    if (c->fp_tw) hipFree(c->fp_tw);
+    delete[] c->h_pow;
     for (int i = 0; i < 4; ++i) {
         if (c->plan_s[i]) rocfft_plan_destroy(c->plan_s[i]);
         if (c->info_s[i]) rocfft_execution_info_destroy(c->info_s[i]);

@@ -1,0 +1,397 @@
+// Fused FFT Poisson solve: phi = IFFT( G(k) * FFT(rho) ) in five passes over HBM, no rocFFT.
+//
+// rocFFT's 3-D r2c + Green's function + c2r costs 7 + 1 + 7 kernels at 1024^3 (25 ms), more than half
+// of it in stand-alone transposes.  Here every pass is a batched 1-D FFT done entirely in LDS whose
+// global side is contiguous on one end and transposed (64/128-byte segments) on the other, so the
+// array is never transposed on its own, and the x pass does forward FFT -> Green's function ->
+// inverse FFT on each line while it sits in LDS:
+//
+//   P1  rho[x][y][z] (real)   --z r2c-->            B[kz][x][y]        two real lines per complex FFT
+//   P2  B[kz][x][y]           --y forward-->        C[ky][kz][x]
+//   P3  C[ky][kz][x]          --x forward, *G(k)/n^3, x inverse-->  C   (in place, contiguous lines)
+//   P4  C[ky][kz][x]          --y inverse-->        B[kz][x][y]
+//   P5  B[kz][x][y]           --z c2r-->            phi[x][y][z] (real)
+//
+// 1-D FFTs: in place, radix-4 (+ one radix-2 stage when log2 n is odd); forward = decimation in
+// frequency (natural in, digit-reversed out), inverse = decimation in time (digit-reversed in,
+// natural out), so P3 needs no reordering and the other passes permute on their LDS side.
+// Replaces solver.fft (solver.py:453-522 without the P(k) branch) + fourier.py:104-147, 251-294, 460-595.
+#include "pm_common.h"
+
+#define FBLK 1024
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
+
+// position (after the forward DIF) of frequency k, and its inverse
+__device__ __forceinline__ int pos_of_freq(int k, int log2n) {
+    int pos = 0, L = 1 << log2n;
+    while (L >= 4) {
+        const int d = k & 3;
+        k >>= 2;
+        L >>= 2;
+        pos += d * L;
+    }
+    if (L == 2) pos += (k & 1);
+    return pos;
+}
+__device__ __forceinline__ int freq_of_pos(int pos, int log2n) {
+    int k = 0, mult = 1, L = 1 << log2n;
+    while (L >= 4) {
+        L >>= 2;
+        const int d = pos / L;
+        pos -= d * L;
+        k += d * mult;
+        mult <<= 2;
+    }
+    if (L == 2) k += pos * mult;
+    return k;
+}
+
+// LDS addressing: element e of a line lives at PADI(e) = e + e/32 and lines are NP(n) = n + n/32
+// apart.  The extra slot per 32 elements breaks the power-of-two strides of the small-span stages
+// (span 4 and 16 butterflies are 4-way bank conflicts without it).
+#define PADI(e) ((e) + ((e) >> 5))
+#define NP(n) ((n) + ((n) >> 5))
+
+// forward DIF on `nlines` lines of length n in LDS, all threads of the workgroup.
+// tw[t] = exp(-2 pi i t / n).
+__device__ __forceinline__ void fft_forward_lds(float2 *buf, const float2 *tw, int n, int log2n, int nlines) {
+    const int nq = n >> 2, lnq = log2n - 2;
+    int L = n, lL = log2n;
+    for (; L >= 4; L >>= 2, lL -= 2) {
+        const int q = L >> 2, lq = lL - 2, lts = log2n - lL;
+        for (int b = threadIdx.x; b < nlines * nq; b += FBLK) {
+            const int line = b >> lnq, idx = b & (nq - 1);
+            const int g = (idx >> lq) << lL, j = idx & (q - 1);
+            float2 *ln = buf + line * NP(n);
+            const int e0 = g + j, i0 = PADI(e0), i1 = PADI(e0 + q), i2 = PADI(e0 + 2 * q), i3 = PADI(e0 + 3 * q);
+            const int ts = 1 << lts;
+            const float2 a0 = ln[i0], a1 = ln[i1], a2 = ln[i2], a3 = ln[i3];
+            const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
+            ln[i0] = cadd(s02, s13);
+            ln[i1] = cmul(cadd(d02, d13), tw[j * ts]);
+            ln[i2] = cmul(csub(s02, s13), tw[2 * j * ts]);
+            ln[i3] = cmul(csub(d02, d13), tw[3 * j * ts]);
+        }
+        __syncthreads();
+    }
+    if (L == 2) {
+        const int nh = n >> 1;
+        for (int b = threadIdx.x; b < nlines * nh; b += FBLK) {
+            const int line = b >> (log2n - 1), e = (b & (nh - 1)) << 1;
+            float2 *p = buf + line * NP(n) + PADI(e);  // e even: e and e+1 share a 32-group
+            const float2 a0 = p[0], a1 = p[1];
+            p[0] = cadd(a0, a1);
+            p[1] = csub(a0, a1);
+        }
+        __syncthreads();
+    }
+}
+
+// inverse DIT (unnormalised), digit-reversed in, natural out
+__device__ __forceinline__ void fft_inverse_lds(float2 *buf, const float2 *tw, int n, int log2n, int nlines) {
+    const int nq = n >> 2, lnq = log2n - 2;
+    int L = 4, lL = 2;
+    if (log2n & 1) {
+        const int nh = n >> 1;
+        for (int b = threadIdx.x; b < nlines * nh; b += FBLK) {
+            const int line = b >> (log2n - 1), e = (b & (nh - 1)) << 1;
+            float2 *p = buf + line * NP(n) + PADI(e);  // e even: e and e+1 share a 32-group
+            const float2 a0 = p[0], a1 = p[1];
+            p[0] = cadd(a0, a1);
+            p[1] = csub(a0, a1);
+        }
+        __syncthreads();
+        L = 8, lL = 3;
+    }
+    for (; L <= n; L <<= 2, lL += 2) {
+        const int q = L >> 2, lq = lL - 2, ts = 1 << (log2n - lL);
+        for (int b = threadIdx.x; b < nlines * nq; b += FBLK) {
+            const int line = b >> lnq, idx = b & (nq - 1);
+            const int g = (idx >> lq) << lL, j = idx & (q - 1);
+            float2 *ln = buf + line * NP(n);
+            const int e0 = g + j, i0 = PADI(e0), i1 = PADI(e0 + q), i2 = PADI(e0 + 2 * q), i3 = PADI(e0 + 3 * q);
+            const float2 t0 = ln[i0], t1 = cmul(ln[i1], cconj(tw[j * ts])), t2 = cmul(ln[i2], cconj(tw[2 * j * ts])),
+                         t3 = cmul(ln[i3], cconj(tw[3 * j * ts]));
+            const float2 s02 = cadd(t0, t2), d02 = csub(t0, t2), s13 = cadd(t1, t3), d13 = mul_pi(csub(t1, t3));
+            ln[i0] = cadd(s02, s13);
+            ln[i1] = cadd(d02, d13);
+            ln[i2] = csub(s02, s13);
+            ln[i3] = csub(d02, d13);
+        }
+        __syncthreads();
+    }
+}
+
+// twiddles, then the frequency -> position permutation (n ints right behind the n twiddles)
+__device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restrict__ g_tw, int n, int log2n) {
+    int *perm = reinterpret_cast<int *>(tw + n);
+    for (int t = threadIdx.x; t < n; t += FBLK) {
+        tw[t] = g_tw[t];
+        perm[t] = pos_of_freq(t, log2n);
+    }
+}
+
+// 8 contiguous complex lines <-> LDS: 16-byte global accesses, two 8-byte LDS accesses (a pair
+// (e, e+1) with e even never straddles a 32-group, but its padded address may be odd)
+__device__ __forceinline__ void lds_load_lines(float2 *buf, const float2 *__restrict__ src, int n, int log2n) {
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+    for (int t = threadIdx.x; t < 8 * n / 2; t += FBLK) {
+        const float4 v = src4[t];
+        const int line = (2 * t) >> log2n, e = (2 * t) & (n - 1);
+        float2 *d = buf + line * NP(n) + PADI(e);
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
+    }
+}
+__device__ __forceinline__ void lds_store_lines(const float2 *buf, float2 *__restrict__ dst, int n, int log2n) {
+    float4 *dst4 = reinterpret_cast<float4 *>(dst);
+    for (int t = threadIdx.x; t < 8 * n / 2; t += FBLK) {
+        const int line = (2 * t) >> log2n, e = (2 * t) & (n - 1);
+        const float2 *s2 = buf + line * NP(n) + PADI(e);
+        dst4[t] = make_float4(s2[0].x, s2[0].y, s2[1].x, s2[1].y);
+    }
+}
+
+// ---- P1: z r2c, two real lines per complex FFT, transposed write ---------------------------------
+// workgroup = 16 real lines (x fixed, y0..y0+15) = 8 complex lines
+__global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho, float2 *__restrict__ B,
+                                                   const float2 *__restrict__ g_tw, int n, int log2n) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    float2 *buf = lds, *tw = lds + 8 * NP(n);
+    const int nh = (n >> 1) + 1;
+    const int64_t line0 = (int64_t)blockIdx.x * 16;  // flat (x*n + y) index of the first real line
+    load_twiddles(tw, g_tw, n, log2n);
+    const int *perm = reinterpret_cast<const int *>(tw + n);
+    {   // contiguous load of 16*n floats; real line 2m -> re, 2m+1 -> im of complex line m
+        const float4 *src = reinterpret_cast<const float4 *>(rho + line0 * n);
+        const int nq = n >> 2;
+        for (int t = threadIdx.x; t < 16 * nq; t += FBLK) {
+            const int rl = t / nq, z0 = (t - rl * nq) << 2;
+            const float4 v = src[t];
+            // z0 is a multiple of 4: z0..z0+3 share a 32-group, so the four slots stay contiguous
+            float *dst = reinterpret_cast<float *>(buf + (rl >> 1) * NP(n) + PADI(z0)) + (rl & 1);
+            dst[0] = v.x, dst[2] = v.y, dst[4] = v.z, dst[6] = v.w;
+        }
+    }
+    __syncthreads();
+    fft_forward_lds(buf, tw, n, log2n, 8);
+    // unpack and write B[kz][x][y]: thread = (complex line m, kz) -> the two real lines' spectra A, B are
+    // adjacent in y: one 16-byte store; 8 threads cover the 128 B of one kz
+    const int x = (int)(line0 >> log2n), y0 = (int)(line0 & (n - 1));
+    const int m = threadIdx.x & 7;
+    const float2 *ln = buf + m * NP(n);
+    for (int kz = threadIdx.x >> 3; kz < nh; kz += FBLK / 8) {
+        const float2 zk = ln[PADI(perm[kz])], zn = cconj(ln[PADI(perm[(n - kz) & (n - 1)])]);
+        const float2 d = csub(zk, zn);
+        // A[k] = (Z[k] + conj Z[n-k]) / 2 ;  B[k] = (Z[k] - conj Z[n-k]) / (2i)
+        const float4 v = make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y), 0.5f * d.y, -0.5f * d.x);
+        *reinterpret_cast<float4 *>(B + ((int64_t)kz * n + x) * n + y0 + 2 * m) = v;
+    }
+}
+
+// ---- P2 / P4: y transform with transposed global side ------------------------------------------------
+// workgroup = 8 lines (kz fixed, x0..x0+7).  FORWARD: B -> C, else C -> B.
+template <bool FORWARD>
+__global__ __launch_bounds__(FBLK) void fftp_y(float2 *__restrict__ B, float2 *__restrict__ C,
+                                               const float2 *__restrict__ g_tw, int n, int log2n) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    float2 *buf = lds, *tw = lds + 8 * NP(n);
+    const int nh = (n >> 1) + 1;
+    const int64_t line0 = (int64_t)blockIdx.x * 8;  // flat (kz*n + x)
+    const int kz = (int)(line0 >> log2n), x0 = (int)(line0 & (n - 1));
+    load_twiddles(tw, g_tw, n, log2n);
+    const int *perm = reinterpret_cast<const int *>(tw + n);
+    const int lx = threadIdx.x & 7;
+    if (!FORWARD) __syncthreads();  // the transposed load below reads the permutation table
+    if (FORWARD) {
+        lds_load_lines(buf, B + line0 * n, n, log2n);
+        __syncthreads();
+        fft_forward_lds(buf, tw, n, log2n, 8);
+        for (int ky = threadIdx.x >> 3; ky < n; ky += FBLK / 8)
+            C[((int64_t)ky * nh + kz) * n + x0 + lx] = buf[lx * NP(n) + PADI(perm[ky])];
+    } else {
+        for (int ky = threadIdx.x >> 3; ky < n; ky += FBLK / 8)
+            buf[lx * NP(n) + PADI(perm[ky])] = C[((int64_t)ky * nh + kz) * n + x0 + lx];
+        __syncthreads();
+        fft_inverse_lds(buf, tw, n, log2n, 8);
+        lds_store_lines(buf, B + line0 * n, n, log2n);
+    }
+}
+
+// ---- P3: x forward, Green's function, x inverse, in place ----------------------------------------------
+// workgroup = 8 consecutive lines of C viewed as [n*nh lines][n]
+template <int KIND>
+__global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, const float2 *__restrict__ g_tw, int n,
+                                                     int log2n, int p, const float *__restrict__ k2,
+                                                     const float *__restrict__ s, float c0, float norm) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    float2 *buf = lds, *tw = lds + 8 * NP(n);
+    const int nh = (n >> 1) + 1;
+    const int64_t line0 = (int64_t)blockIdx.x * 8;
+    load_twiddles(tw, g_tw, n, log2n);
+    const int *perm = reinterpret_cast<const int *>(tw + n);
+    lds_load_lines(buf, C + line0 * n, n, log2n);
+    __syncthreads();
+    // this pass needs position -> frequency: invert the table in place (each slot written once)
+    int *kxof = reinterpret_cast<int *>(tw + n);
+    {
+        int mine[(1024 + FBLK - 1) / FBLK];
+        for (int t = threadIdx.x, u = 0; t < n; t += FBLK, ++u) mine[u] = perm[t];
+        __syncthreads();
+        for (int t = threadIdx.x, u = 0; t < n; t += FBLK, ++u) kxof[mine[u]] = t;
+    }
+    fft_forward_lds(buf, tw, n, log2n, 8);
+    for (int t = threadIdx.x; t < 8 * n; t += FBLK) {
+        const int l = t >> log2n, pos = t & (n - 1);
+        const int64_t line = line0 + l;
+        const int ky = (int)(line / nh), kz = (int)(line - (int64_t)ky * nh);
+        const int kx = kxof[pos];
+        float g;  // fourier.py:460-595; for the compensated kernel `s` already holds sinc^(-2p) per axis
+        if (KIND == PM_GREEN_7PT) {
+            g = c0 / ((s[kx] + s[ky]) + s[kz]);
+        } else {
+            const float invk2 = c0 / ((k2[kx] + k2[ky]) + k2[kz]);
+            g = (KIND == PM_GREEN_COMPENSATED) ? ((s[kx] * s[ky]) * s[kz]) * invk2 : invk2;
+        }
+        g *= norm;  // 1/n^3 of the inverse transform
+        float2 *slot = buf + l * NP(n) + PADI(pos);
+        float2 v = *slot;
+        if ((kx | ky | kz) == 0)
+            v = make_float2(0.f, 0.f);
+        else
+            v.x *= g, v.y *= g;
+        *slot = v;
+    }
+    __syncthreads();
+    fft_inverse_lds(buf, tw, n, log2n, 8);
+    lds_store_lines(buf, C + line0 * n, n, log2n);
+}
+
+// ---- P5: z c2r, transposed read ---------------------------------------------------------------------------
+__global__ __launch_bounds__(FBLK) void fftp_z_c2r(const float2 *__restrict__ B, float *__restrict__ phi,
+                                                   const float2 *__restrict__ g_tw, int n, int log2n) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    float2 *buf = lds, *tw = lds + 8 * NP(n);
+    const int nh = (n >> 1) + 1;
+    const int64_t line0 = (int64_t)blockIdx.x * 16;
+    const int x = (int)(line0 >> log2n), y0 = (int)(line0 & (n - 1));
+    load_twiddles(tw, g_tw, n, log2n);
+    const int *perm = reinterpret_cast<const int *>(tw + n);
+    // Z = A + iB: thread = (complex line m, kz) loads the adjacent pair (A[kz], B[kz]) with one 16-byte
+    // load and writes Z[k] = A + iB and Z[n-k] = conj(A) + i conj(B)
+    __syncthreads();  // permutation table ready
+    {
+        const int m = threadIdx.x & 7;
+        float2 *ln = buf + m * NP(n);
+        for (int kz = threadIdx.x >> 3; kz < nh; kz += FBLK / 8) {
+            float4 v = *reinterpret_cast<const float4 *>(B + ((int64_t)kz * n + x) * n + y0 + 2 * m);
+            const bool edge = (kz == 0) || (kz == (n >> 1));
+            if (edge) v.y = 0.f, v.w = 0.f;  // c2r ignores the imaginary part of DC / Nyquist
+            // A = (v.x, v.y), Bh = (v.z, v.w):  A + i Bh = (v.x - v.w, v.y + v.z)
+            ln[PADI(perm[kz])] = make_float2(v.x - v.w, v.y + v.z);
+            // conj(A) + i conj(Bh) = (v.x + v.w, -v.y + v.z)
+            if (!edge) ln[PADI(perm[n - kz])] = make_float2(v.x + v.w, v.z - v.y);
+        }
+    }
+    __syncthreads();
+    fft_inverse_lds(buf, tw, n, log2n, 8);
+    {
+        float4 *dst = reinterpret_cast<float4 *>(phi + line0 * n);
+        const int nq = n >> 2;
+        for (int t = threadIdx.x; t < 16 * nq; t += FBLK) {
+            const int rl = t / nq, z0 = (t - rl * nq) << 2;
+            const float *src = reinterpret_cast<const float *>(buf + (rl >> 1) * NP(n) + PADI(z0)) + (rl & 1);
+            dst[t] = make_float4(src[0], src[2], src[4], src[6]);
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------
+
+static int ensure_fused_buffers(pm_ctx *c) {
+    const int n = c->n;
+    const size_t spec = (size_t)n * n * (n / 2 + 1) * sizeof(float2);
+    if (!c->fp_B) {
+        PM_HIP(hipMalloc(&c->fp_B, spec));
+        PM_HIP(hipMalloc(&c->fp_C, spec));
+        PM_HIP(hipMalloc(&c->fp_tw, (size_t)n * sizeof(float2)));
+        c->h_pow = new float[n];
+        float2 *h = new float2[n];
+        for (int t = 0; t < n; ++t) {
+            const double a = -2.0 * 3.14159265358979323846 * t / n;
+            h[t] = make_float2((float)cos(a), (float)sin(a));
+        }
+        hipError_t e = hipMemcpy(c->fp_tw, h, (size_t)n * sizeof(float2), hipMemcpyHostToDevice);
+        delete[] h;
+        PM_HIP(e);
+    }
+    return PM_OK;
+}
+
+extern "C" int pm_poisson_fft_fused(pm_ctx *c, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
+                                    const float *h_s, float c0) {
+    PM_REQUIRE(c && d_rhs && d_phi && h_k2 && h_s, "NULL argument");
+    const int n = c->n, log2n = c->log2n;
+    PM_REQUIRE(n >= 32 && n <= 1024, "fused FFT solve supports 32 <= n <= 1024 (use pm_poisson_fft otherwise)");
+    PM_REQUIRE(pm_aligned16(d_rhs) && pm_aligned16(d_phi), "grids must be 16-byte aligned");
+    PM_REQUIRE(kind == PM_GREEN_PLAIN || kind == PM_GREEN_COMPENSATED || kind == PM_GREEN_7PT,
+               "unknown Green's function kind");
+    int rc = ensure_fused_buffers(c);
+    if (rc) return rc;
+    PM_HIP(hipMemcpyAsync(c->d_tab, h_k2, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (kind == PM_GREEN_COMPENSATED) {
+        // (sx*sy*sz)^(-2p) = sx^(-2p) * sy^(-2p) * sz^(-2p): one pow per axis entry on the host instead
+        // of one per mode on the device (a few ulp from the reference's single pow, fourier.py:543)
+        float *hp = c->h_pow;
+        for (int i = 0; i < n; ++i) hp[i] = (float)pow((double)h_s[i], (double)(-2 * p));
+        PM_HIP(hipMemcpyAsync(c->d_tab + n, hp, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    } else {
+        PM_HIP(hipMemcpyAsync(c->d_tab + n, h_s, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    float2 *B = (float2 *)c->fp_B, *C = (float2 *)c->fp_C;
+    const float2 *tw = (const float2 *)c->fp_tw;
+    const int nh = n / 2 + 1;
+    const size_t lds = (size_t)(8 * (n + n / 32) + n) * sizeof(float2) + (size_t)n * sizeof(int);
+    const float norm = (float)(1.0 / ((double)n * n * n));
+    static bool attr_set = false;
+    if (!attr_set) {  // 72 KB of dynamic LDS at n = 1024
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_z_r2c, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_y<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_y<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_x_green<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_x_green<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_x_green<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_z_c2r, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_set = true;
+    }
+    const unsigned g1 = (unsigned)((int64_t)n * n / 16), g2 = (unsigned)((int64_t)nh * n / 8),
+                   g3 = (unsigned)((int64_t)n * nh / 8);
+    hipLaunchKernelGGL(fftp_z_r2c, dim3(g1), dim3(FBLK), lds, c->stream, d_rhs, B, tw, n, log2n);
+    hipLaunchKernelGGL((fftp_y<true>), dim3(g2), dim3(FBLK), lds, c->stream, B, C, tw, n, log2n);
+    switch (kind) {
+        case PM_GREEN_PLAIN:
+            hipLaunchKernelGGL((fftp_x_green<PM_GREEN_PLAIN>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n, log2n, p,
+                               c->d_tab, c->d_tab + n, c0, norm);
+            break;
+        case PM_GREEN_COMPENSATED:
+            hipLaunchKernelGGL((fftp_x_green<PM_GREEN_COMPENSATED>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n,
+                               log2n, p, c->d_tab, c->d_tab + n, c0, norm);
+            break;
+        default:
+            hipLaunchKernelGGL((fftp_x_green<PM_GREEN_7PT>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n, log2n, p,
+                               c->d_tab, c->d_tab + n, c0, norm);
+            break;
+    }
+    hipLaunchKernelGGL((fftp_y<false>), dim3(g2), dim3(FBLK), lds, c->stream, B, C, tw, n, log2n);
+    hipLaunchKernelGGL(fftp_z_c2r, dim3(g1), dim3(FBLK), lds, c->stream, B, d_phi, tw, n, log2n);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}

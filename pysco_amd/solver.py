@@ -16,6 +16,7 @@ from . import _lib as L
 from . import fourier, iostream, mesh, utils
 
 _C_LIGHT = 299792458.0  # astropy.constants.c (solver.py:14)
+_USE_FUSED_FFT = True  # False: rocFFT r2c -> Green's function -> c2r (always used when P(k) is written)
 
 
 def _empty(template):
@@ -277,6 +278,10 @@ def fft(rhs, param, _source_scale=None):
         c0 = float(np.float32(c0) * np.float32(_source_scale))
     want_pk = ("save_pk" in param) and param["save_pk"] and not compute_MOND_potential
     phi = torch.empty_like(rhs_d)
+    if not want_pk and 32 <= n <= 1024 and _USE_FUSED_FFT:
+        # five LDS-resident FFT passes with the Green's function inside the x pass (csrc/pm_fftpoisson.hip)
+        ctx.call("pm_poisson_fft_fused", kind, p, L.ptr(rhs_d), L.ptr(phi), L.hptr(k2), L.hptr(s), c0)
+        return phi
     # three C-ABI calls (== pm_poisson_fft) so that per-stage event timing sees each of them
     rhs_fourier = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64, device=rhs_d.device)
     ctx.call("pm_fft_r2c", L.ptr(rhs_d), L.ptr(rhs_fourier))

@@ -24,3 +24,11 @@ print(f"1-D c2c strided (x)     {t2:8.3f} ms   -> 2-D + 1-D forward {t1 + t2:8.3
 t3 = timeit(lambda: ctx.call("pm_fft1d_x", L.ptr(xk), n * (n // 2 + 1), 1))
 t4 = timeit(lambda: ctx.call("pm_fft2d_c2r", L.ptr(xk), L.ptr(x), n))
 print(f"1-D inverse {t3:8.3f} ms, 2-D c2r {t4:8.3f} ms -> inverse {t3 + t4:8.3f} ms")
+from pysco_amd import fourier
+
+k2, s, c0 = fourier.green_tables(n, 1)
+phi = torch.empty_like(x)
+t = timeit(lambda: ctx.call("pm_poisson_fft_fused", 1, 3, L.ptr(x), L.ptr(phi), L.hptr(k2), L.hptr(s), c0))
+print(f"fused Poisson solve (5 passes)  {t:8.3f} ms")
+t = timeit(lambda: ctx.call("pm_poisson_fft", 1, 3, L.ptr(x), L.ptr(phi), L.hptr(k2), L.hptr(s), c0))
+print(f"rocFFT r2c + greens + c2r       {t:8.3f} ms")
