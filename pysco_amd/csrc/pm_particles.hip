@@ -6,10 +6,10 @@
 // instruction touches contiguous bytes, so scattering 27 atomics per particle is ~20x off the HBM
 // roofline.  Instead a workgroup takes a contiguous chunk of the (Morton-sorted) particle stream,
 // accumulates it into an LDS tile of 16x16x16 cells + a one-cell halo, and flushes the tile with
-// one global atomic per touched cell (rows of 18 contiguous floats).  The LDS tile is fp64:
+// one global atomic per touched cell (rows of 18 contiguous floats).  The LDS tile is NOT fp32:
 // measured on gfx950 (tools/micro/lds_atomics.hip) ds_add_f32 retires 0.33 lane-ops/clk/CU while
 // ds_add_f64 retires 6.4 and ds_add_u64 7.8 -- a 20x difference -- so each fp32 weight (computed
-// exactly as the reference does) is widened and summed in fp64, then rounded once at the flush.  A chunk that
+// exactly as the reference does) is summed in 64-bit fixed point and rounded once at the flush.  A chunk that
 // spans several tiles is handled by re-anchoring the LDS tile (a few passes); particles that fall
 // outside the first PM_MAX_PASSES tiles -- unsorted input -- go straight to global atomics, so
 // the result never depends on the order, only the speed does.
@@ -147,14 +147,23 @@ __device__ __forceinline__ int64_t tile_cell_global(int c, const TileId &t, cons
 // ------------------------------------------------------------------------------------------------
 // deposit, LDS-tiled (see the header comment)
 
+// LDS accumulators are 64-bit fixed point (weight * 2^30, truncated): measured on gfx950
+// (tools/micro/lds_atomics.hip) ds_add_u64 retires 7.8 lane-ops/clk/CU against 6.4 for ds_add_f64 and
+// 0.33 for ds_add_f32.  Weights are in [0, 1]; a contribution loses at most 2^-30 = 9e-10 (fp32 ulp of
+// an O(1) density is 6e-8), a cell holds up to 2^34 particles, and -- integer adds being associative --
+// a tile's sums no longer depend on the order in which its particles arrive.
+typedef unsigned long long pm_acc_t;
+__device__ __forceinline__ pm_acc_t acc_of_weight(float w) { return (pm_acc_t)(unsigned)(w * 1073741824.0f); }
+__device__ __forceinline__ float weight_of_acc(pm_acc_t a) { return (float)((double)a * (1.0 / 1073741824.0)); }
+
 template <int SCHEME>
 __device__ __forceinline__ void deposit_lds(float xp, float yp, float zp, int i, int j, int k, const TileId &t,
-                                            double *tile) {
+                                            pm_acc_t *tile) {
     // local coordinates inside the haloed tile: cell (ti*TI-1) is local 0
     const int li = i - t.ti * PM_TI + 1, lj = j - t.tj * PM_TJ + 1, lk = k - t.tk * PM_TK + 1;
-    auto at = [&](int a, int b, int c) -> double * { return tile + ((li + a) * PM_HJ + (lj + b)) * PM_HK + (lk + c); };
+    auto at = [&](int a, int b, int c) -> pm_acc_t * { return tile + ((li + a) * PM_HJ + (lj + b)) * PM_HK + (lk + c); };
     if (SCHEME == PM_NGP) {
-        atomicAdd(at(0, 0, 0), 1.0);
+        atomicAdd(at(0, 0, 0), acc_of_weight(1.0f));
     } else if (SCHEME == PM_CIC) {
         float wx[2], wy[2], wz[2];
         int sx, sy, sz;
@@ -167,7 +176,7 @@ __device__ __forceinline__ void deposit_lds(float xp, float yp, float zp, int i,
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                    atomicAdd(at(a * sx, b * sy, c * sz), (double)(wx[a] * wy[b] * wz[c]));
+                    atomicAdd(at(a * sx, b * sy, c * sz), acc_of_weight(wx[a] * wy[b] * wz[c]));
     } else {
         float wx[3], wy[3], wz[3];
         tsc_weights(xp, i, wx);
@@ -179,7 +188,7 @@ __device__ __forceinline__ void deposit_lds(float xp, float yp, float zp, int i,
             for (int b = 0; b < 3; ++b) {
                 const float wxy = wx[a] * wy[b];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) atomicAdd(at(a - 1, b - 1, c - 1), (double)(wxy * wz[c]));
+                for (int c = 0; c < 3; ++c) atomicAdd(at(a - 1, b - 1, c - 1), acc_of_weight(wxy * wz[c]));
             }
     }
 }
@@ -187,13 +196,13 @@ __device__ __forceinline__ void deposit_lds(float xp, float yp, float zp, int i,
 template <int SCHEME>
 __global__ __launch_bounds__(BLK) void deposit_tiled_kernel(const float *__restrict__ pos, int64_t np, pm_geom geo,
                                                             float *__restrict__ rho) {
-    __shared__ double tile[PM_TILE];  // 25.9 KB
+    __shared__ pm_acc_t tile[PM_TILE];  // 25.9 KB
     __shared__ int s_first;
     __shared__ int s_anchor[3];
     const int tid = threadIdx.x;
     const int n = geo.n;
     const float nf = (float)n;
-    for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0.0;
+    for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0;
 
     const int64_t base = (int64_t)blockIdx.x * PM_CHUNK;
     // Particles are re-read from L2 on every pass rather than held in registers or staged in LDS
@@ -222,10 +231,10 @@ __global__ __launch_bounds__(BLK) void deposit_tiled_kernel(const float *__restr
         __syncthreads();
         // flush: one global atomic per touched cell; rows of 18 contiguous floats along k
         for (int c = tid; c < PM_TILE; c += BLK) {
-            const double v = tile[c];
-            if (v != 0.0) {
-                unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), (float)v);
-                tile[c] = 0.0;
+            const pm_acc_t v = tile[c];
+            if (v != 0) {
+                unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), weight_of_acc(v));
+                tile[c] = 0;
             }
         }
     }
@@ -735,14 +744,14 @@ __global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__rest
     unsigned key;
     int64_t s, e;
     if (!tile_work_item(work, key, s, e)) return;
-    __shared__ double tile[PM_TILE];  // 25.9 KB
+    __shared__ pm_acc_t tile[PM_TILE];  // 25.9 KB
     const int tid = threadIdx.x;
     const int n = geo.n;
     const float nf = (float)n;
     const TileId t = tile_of_key(key);
     PosQueue q;
     q.prime(pos, s + tid, e);
-    for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0.0;
+    for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0;
     __syncthreads();
 #pragma unroll 1
     for (int64_t p = s + tid; p < e; p += BLK) {
@@ -757,8 +766,8 @@ __global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__rest
     }
     __syncthreads();
     for (int c = tid; c < PM_TILE; c += BLK) {
-        const double v = tile[c];
-        if (v != 0.0) unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), (float)v);
+        const pm_acc_t v = tile[c];
+        if (v != 0) unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), weight_of_acc(v));
     }
 }
 
