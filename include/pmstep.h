@@ -106,6 +106,15 @@ int pm_poisson_fft(pm_ctx *ctx, int kind, int p, const float *d_rhs, float *d_ph
  * function applied between the forward and inverse x transforms (32 <= n <= 1024). */
 int pm_poisson_fft_fused(pm_ctx *ctx, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
                          const float *h_s, float c0);
+/* The three stages of pm_poisson_fft_fused, exposed for the slab-decomposed solve (nx = local x-planes):
+ *   pm_fftp_forward : d_rhs [nx,n,n] real            -> d_C [n (ky), n/2+1 (kz), nx]   (z r2c + y forward)
+ *   pm_fftp_xgreen  : in place on d_C laid out [n/nx segments][nky][n/2+1][nx] -- what an all-to-all over
+ *                     x-slabs delivers -- x forward, G(kx, ky0+ky, kz)/n^3, x inverse
+ *   pm_fftp_inverse : d_C [n, n/2+1, nx]            -> d_phi [nx,n,n] real              (y inverse + z c2r) */
+int pm_fftp_forward(pm_ctx *ctx, const float *d_rhs, int nx, void *d_C);
+int pm_fftp_xgreen(pm_ctx *ctx, int kind, int p, void *d_C, int nx, int nky, int ky0, const float *h_k2,
+                   const float *h_s, float c0);
+int pm_fftp_inverse(pm_ctx *ctx, const void *d_C, int nx, float *d_phi);
 /* leapfrog first half, integration.py:250-258: v += -half_dt*a ; x += dt*v ; periodic_wrap(x) */
 int pm_kick_drift_wrap(pm_ctx *ctx, float *d_pos, float *d_vel, const float *d_acc, float half_dt, float dt,
                        int64_t np);

@@ -50,6 +50,9 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_pk": (_vp, _i, _vp, _vp, _vp, _vp, _vp),
     "pm_poisson_fft": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),
     "pm_poisson_fft_fused": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),
+    "pm_fftp_forward": (_vp, _vp, _i, _vp),
+    "pm_fftp_xgreen": (_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _f),
+    "pm_fftp_inverse": (_vp, _vp, _i, _vp),
     "pm_kick_drift_wrap": (_vp, _vp, _vp, _vp, _f, _f, _i64),
     "pm_interp_kick": (_vp, _i, _vp, _vp, _i64, _vp, _vp, _f),
     "pm_last_maxabs": (_vp, C.POINTER(_f), C.POINTER(_f)),

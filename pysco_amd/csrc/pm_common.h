@@ -77,6 +77,7 @@ struct pm_ctx {
     size_t fft_work_bytes;
     void *d_spec;  // lazily allocated half-spectrum scratch for pm_poisson_fft
     void *fp_B, *fp_C, *fp_tw;  // fused FFT Poisson solve: two transposed half-spectra + twiddle table
+    size_t fp_B_bytes, fp_C_bytes;
     float *h_pow;               // host staging of the per-axis sinc^(-2p) table
     // slab-decomposed FFT pieces (multi-GPU): batched 2-D r2c/c2r over (y,z), strided 1-D c2c over x
     rocfft_plan plan_s[4];            // 0: 2-D r2c, 1: 2-D c2r, 2: 1-D forward, 3: 1-D backward

@@ -163,7 +163,7 @@ __device__ __forceinline__ void lds_store_lines(const float2 *buf, float2 *__res
 // ---- P1: z r2c, two real lines per complex FFT, transposed write ---------------------------------
 // workgroup = 16 real lines (x fixed, y0..y0+15) = 8 complex lines
 __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho, float2 *__restrict__ B,
-                                                   const float2 *__restrict__ g_tw, int n, int log2n) {
+                                                   const float2 *__restrict__ g_tw, int n, int log2n, int nx) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *buf = lds, *tw = lds + 8 * NP(n);
     const int nh = (n >> 1) + 1;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
         const float2 d = csub(zk, zn);
         // A[k] = (Z[k] + conj Z[n-k]) / 2 ;  B[k] = (Z[k] - conj Z[n-k]) / (2i)
         const float4 v = make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y), 0.5f * d.y, -0.5f * d.x);
-        *reinterpret_cast<float4 *>(B + ((int64_t)kz * n + x) * n + y0 + 2 * m) = v;
+        *reinterpret_cast<float4 *>(B + ((int64_t)kz * nx + x) * n + y0 + 2 * m) = v;
     }
 }
 
@@ -201,12 +201,12 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
 // workgroup = 8 lines (kz fixed, x0..x0+7).  FORWARD: B -> C, else C -> B.
 template <bool FORWARD>
 __global__ __launch_bounds__(FBLK) void fftp_y(float2 *__restrict__ B, float2 *__restrict__ C,
-                                               const float2 *__restrict__ g_tw, int n, int log2n) {
+                                               const float2 *__restrict__ g_tw, int n, int log2n, int nx) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *buf = lds, *tw = lds + 8 * NP(n);
     const int nh = (n >> 1) + 1;
-    const int64_t line0 = (int64_t)blockIdx.x * 8;  // flat (kz*n + x)
-    const int kz = (int)(line0 >> log2n), x0 = (int)(line0 & (n - 1));
+    const int64_t line0 = (int64_t)blockIdx.x * 8;  // flat (kz*nx + x), nx = local x planes (multiple of 8)
+    const int kz = (int)(line0 / nx), x0 = (int)(line0 - (int64_t)kz * nx);
     load_twiddles(tw, g_tw, n, log2n);
     const int *perm = reinterpret_cast<const int *>(tw + n);
     const int lx = threadIdx.x & 7;
@@ -216,29 +216,57 @@ __global__ __launch_bounds__(FBLK) void fftp_y(float2 *__restrict__ B, float2 *_
         __syncthreads();
         fft_forward_lds(buf, tw, n, log2n, 8);
         for (int ky = threadIdx.x >> 3; ky < n; ky += FBLK / 8)
-            C[((int64_t)ky * nh + kz) * n + x0 + lx] = buf[lx * NP(n) + PADI(perm[ky])];
+            C[((int64_t)ky * nh + kz) * nx + x0 + lx] = buf[lx * NP(n) + PADI(perm[ky])];
     } else {
         for (int ky = threadIdx.x >> 3; ky < n; ky += FBLK / 8)
-            buf[lx * NP(n) + PADI(perm[ky])] = C[((int64_t)ky * nh + kz) * n + x0 + lx];
+            buf[lx * NP(n) + PADI(perm[ky])] = C[((int64_t)ky * nh + kz) * nx + x0 + lx];
         __syncthreads();
         fft_inverse_lds(buf, tw, n, log2n, 8);
         lds_store_lines(buf, B + line0 * n, n, log2n);
     }
 }
 
+// 8 x-lines <-> LDS when a line is stored as nseg segments of nx elements: element x of line l lives
+// at ((x / nx) * nlines_total + l) * nx + x % nx (nseg = 1: plain contiguous lines).  This is the
+// layout an all-to-all over x-slabs delivers: [source rank][ky_local][kz][x_local].
+__device__ __forceinline__ void lds_load_seg_lines(float2 *buf, const float2 *__restrict__ base, int64_t line0,
+                                                   int64_t nlines_total, int n, int log2n, int nx) {
+    for (int t = threadIdx.x; t < 8 * n / 2; t += FBLK) {
+        const int line = (2 * t) >> log2n, e = (2 * t) & (n - 1);
+        const int seg = e / nx, xl = e - seg * nx;
+        const float4 v = *reinterpret_cast<const float4 *>(base + ((int64_t)seg * nlines_total + line0 + line) * nx + xl);
+        float2 *d = buf + line * NP(n) + PADI(e);
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
+    }
+}
+__device__ __forceinline__ void lds_store_seg_lines(const float2 *buf, float2 *__restrict__ base, int64_t line0,
+                                                    int64_t nlines_total, int n, int log2n, int nx) {
+    for (int t = threadIdx.x; t < 8 * n / 2; t += FBLK) {
+        const int line = (2 * t) >> log2n, e = (2 * t) & (n - 1);
+        const int seg = e / nx, xl = e - seg * nx;
+        const float2 *s2 = buf + line * NP(n) + PADI(e);
+        *reinterpret_cast<float4 *>(base + ((int64_t)seg * nlines_total + line0 + line) * nx + xl) =
+            make_float4(s2[0].x, s2[0].y, s2[1].x, s2[1].y);
+    }
+}
+
 // ---- P3: x forward, Green's function, x inverse, in place ----------------------------------------------
-// workgroup = 8 consecutive lines of C viewed as [n*nh lines][n]
+// workgroup = 8 consecutive lines (ky_local, kz) of C viewed as [nseg][nky*nh lines][nx]; ky0 = global
+// index of the first local ky (0 on a single GPU)
 template <int KIND>
 __global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, const float2 *__restrict__ g_tw, int n,
                                                      int log2n, int p, const float *__restrict__ k2,
-                                                     const float *__restrict__ s, float c0, float norm) {
+                                                     const float *__restrict__ s, float c0, float norm, int nx,
+                                                     int nky, int ky0) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *buf = lds, *tw = lds + 8 * NP(n);
     const int nh = (n >> 1) + 1;
     const int64_t line0 = (int64_t)blockIdx.x * 8;
     load_twiddles(tw, g_tw, n, log2n);
     const int *perm = reinterpret_cast<const int *>(tw + n);
-    lds_load_lines(buf, C + line0 * n, n, log2n);
+    const int64_t nlines_total = (int64_t)nky * nh;
+    lds_load_seg_lines(buf, C, line0, nlines_total, n, log2n, nx);
     __syncthreads();
     // this pass needs position -> frequency: invert the table in place (each slot written once)
     int *kxof = reinterpret_cast<int *>(tw + n);
@@ -252,7 +280,7 @@ __global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, con
     for (int t = threadIdx.x; t < 8 * n; t += FBLK) {
         const int l = t >> log2n, pos = t & (n - 1);
         const int64_t line = line0 + l;
-        const int ky = (int)(line / nh), kz = (int)(line - (int64_t)ky * nh);
+        const int kyl = (int)(line / nh), kz = (int)(line - (int64_t)kyl * nh), ky = ky0 + kyl;
         const int kx = kxof[pos];
         float g;  // fourier.py:460-595; for the compensated kernel `s` already holds sinc^(-2p) per axis
         if (KIND == PM_GREEN_7PT) {
@@ -272,12 +300,12 @@ __global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, con
     }
     __syncthreads();
     fft_inverse_lds(buf, tw, n, log2n, 8);
-    lds_store_lines(buf, C + line0 * n, n, log2n);
+    lds_store_seg_lines(buf, C, line0, nlines_total, n, log2n, nx);
 }
 
 // ---- P5: z c2r, transposed read ---------------------------------------------------------------------------
 __global__ __launch_bounds__(FBLK) void fftp_z_c2r(const float2 *__restrict__ B, float *__restrict__ phi,
-                                                   const float2 *__restrict__ g_tw, int n, int log2n) {
+                                                   const float2 *__restrict__ g_tw, int n, int log2n, int nx) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *buf = lds, *tw = lds + 8 * NP(n);
     const int nh = (n >> 1) + 1;
@@ -292,7 +320,7 @@ __global__ __launch_bounds__(FBLK) void fftp_z_c2r(const float2 *__restrict__ B,
         const int m = threadIdx.x & 7;
         float2 *ln = buf + m * NP(n);
         for (int kz = threadIdx.x >> 3; kz < nh; kz += FBLK / 8) {
-            float4 v = *reinterpret_cast<const float4 *>(B + ((int64_t)kz * n + x) * n + y0 + 2 * m);
+            float4 v = *reinterpret_cast<const float4 *>(B + ((int64_t)kz * nx + x) * n + y0 + 2 * m);
             const bool edge = (kz == 0) || (kz == (n >> 1));
             if (edge) v.y = 0.f, v.w = 0.f;  // c2r ignores the imaginary part of DC / Nyquist
             // A = (v.x, v.y), Bh = (v.z, v.w):  A + i Bh = (v.x - v.w, v.y + v.z)
@@ -316,12 +344,9 @@ __global__ __launch_bounds__(FBLK) void fftp_z_c2r(const float2 *__restrict__ B,
 
 // ---- host side -----------------------------------------------------------------------------------------------
 
-static int ensure_fused_buffers(pm_ctx *c) {
+static int ensure_fused_buffers(pm_ctx *c, size_t b_bytes, size_t c_bytes) {
     const int n = c->n;
-    const size_t spec = (size_t)n * n * (n / 2 + 1) * sizeof(float2);
-    if (!c->fp_B) {
-        PM_HIP(hipMalloc(&c->fp_B, spec));
-        PM_HIP(hipMalloc(&c->fp_C, spec));
+    if (!c->fp_tw) {
         PM_HIP(hipMalloc(&c->fp_tw, (size_t)n * sizeof(float2)));
         c->h_pow = new float[n];
         float2 *h = new float2[n];
@@ -332,19 +357,87 @@ static int ensure_fused_buffers(pm_ctx *c) {
         hipError_t e = hipMemcpy(c->fp_tw, h, (size_t)n * sizeof(float2), hipMemcpyHostToDevice);
         delete[] h;
         PM_HIP(e);
+        // up to 80 KB of dynamic LDS (78 KB at n = 1024)
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_z_r2c, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_y<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_y<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_x_green<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_x_green<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_x_green<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PM_HIP(hipFuncSetAttribute((const void *)fftp_z_c2r, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    }
+    if (c->fp_B_bytes < b_bytes) {
+        if (c->fp_B) PM_HIP(hipFree(c->fp_B));
+        c->fp_B = nullptr, c->fp_B_bytes = 0;
+        PM_HIP(hipMalloc(&c->fp_B, b_bytes));
+        c->fp_B_bytes = b_bytes;
+    }
+    if (c->fp_C_bytes < c_bytes) {
+        if (c->fp_C) PM_HIP(hipFree(c->fp_C));
+        c->fp_C = nullptr, c->fp_C_bytes = 0;
+        PM_HIP(hipMalloc(&c->fp_C, c_bytes));
+        c->fp_C_bytes = c_bytes;
     }
     return PM_OK;
 }
 
-extern "C" int pm_poisson_fft_fused(pm_ctx *c, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
-                                    const float *h_s, float c0) {
-    PM_REQUIRE(c && d_rhs && d_phi && h_k2 && h_s, "NULL argument");
-    const int n = c->n, log2n = c->log2n;
-    PM_REQUIRE(n >= 32 && n <= 1024, "fused FFT solve supports 32 <= n <= 1024 (use pm_poisson_fft otherwise)");
-    PM_REQUIRE(pm_aligned16(d_rhs) && pm_aligned16(d_phi), "grids must be 16-byte aligned");
+static inline size_t fftp_lds_bytes(int n) {
+    return (size_t)(8 * (n + n / 32) + n) * sizeof(float2) + (size_t)n * sizeof(int);
+}
+
+#define FFTP_CHECK_N(c)                                                                                        \
+    PM_REQUIRE((c)->n >= 32 && (c)->n <= 1024, "LDS-FFT passes support 32 <= n <= 1024 (use the rocFFT entry points otherwise)")
+
+// P1 + P2 on nx local x-planes: d_rhs [nx, n, n] real -> d_C [n (ky), n/2+1 (kz), nx] complex
+extern "C" int pm_fftp_forward(pm_ctx *c, const float *d_rhs, int nx, void *d_C) {
+    PM_REQUIRE(c && d_rhs && d_C, "NULL argument");
+    FFTP_CHECK_N(c);
+    const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
+    PM_REQUIRE(nx >= 8 && nx <= n && (nx % 8) == 0, "nx must be a multiple of 8 in [8, n]");
+    PM_REQUIRE(pm_aligned16(d_rhs) && pm_aligned16(d_C), "buffers must be 16-byte aligned");
+    int rc = ensure_fused_buffers(c, (size_t)nh * nx * n * sizeof(float2), 0);
+    if (rc) return rc;
+    const float2 *tw = (const float2 *)c->fp_tw;
+    const size_t lds = fftp_lds_bytes(n);
+    hipLaunchKernelGGL(fftp_z_r2c, dim3((unsigned)((int64_t)nx * n / 16)), dim3(FBLK), lds, c->stream, d_rhs,
+                       (float2 *)c->fp_B, tw, n, log2n, nx);
+    hipLaunchKernelGGL((fftp_y<true>), dim3((unsigned)((int64_t)nh * nx / 8)), dim3(FBLK), lds, c->stream,
+                       (float2 *)c->fp_B, (float2 *)d_C, tw, n, log2n, nx);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// P4 + P5: d_C [n, n/2+1, nx] -> d_phi [nx, n, n] real (d_C is read only)
+extern "C" int pm_fftp_inverse(pm_ctx *c, const void *d_C, int nx, float *d_phi) {
+    PM_REQUIRE(c && d_phi && d_C, "NULL argument");
+    FFTP_CHECK_N(c);
+    const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
+    PM_REQUIRE(nx >= 8 && nx <= n && (nx % 8) == 0, "nx must be a multiple of 8 in [8, n]");
+    PM_REQUIRE(pm_aligned16(d_phi) && pm_aligned16(d_C), "buffers must be 16-byte aligned");
+    int rc = ensure_fused_buffers(c, (size_t)nh * nx * n * sizeof(float2), 0);
+    if (rc) return rc;
+    const float2 *tw = (const float2 *)c->fp_tw;
+    const size_t lds = fftp_lds_bytes(n);
+    hipLaunchKernelGGL((fftp_y<false>), dim3((unsigned)((int64_t)nh * nx / 8)), dim3(FBLK), lds, c->stream,
+                       (float2 *)c->fp_B, (float2 *)const_cast<void *>(d_C), tw, n, log2n, nx);
+    hipLaunchKernelGGL(fftp_z_c2r, dim3((unsigned)((int64_t)nx * n / 16)), dim3(FBLK), lds, c->stream,
+                       (const float2 *)c->fp_B, d_phi, tw, n, log2n, nx);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// P3 in place on d_C laid out [nseg = n/nx][nky][n/2+1][nx]: the lines (ky0 + ky_local, kz) along x
+extern "C" int pm_fftp_xgreen(pm_ctx *c, int kind, int p, void *d_C, int nx, int nky, int ky0, const float *h_k2,
+                              const float *h_s, float c0) {
+    PM_REQUIRE(c && d_C && h_k2 && h_s, "NULL argument");
+    FFTP_CHECK_N(c);
+    const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
+    PM_REQUIRE(nx >= 8 && nx <= n && (n % nx) == 0 && (nx % 2) == 0, "nx must divide n");
+    PM_REQUIRE(nky >= 8 && (nky % 8) == 0 && ky0 >= 0 && ky0 + nky <= n, "bad ky range (multiple of 8 lines)");
     PM_REQUIRE(kind == PM_GREEN_PLAIN || kind == PM_GREEN_COMPENSATED || kind == PM_GREEN_7PT,
                "unknown Green's function kind");
-    int rc = ensure_fused_buffers(c);
+    PM_REQUIRE(pm_aligned16(d_C), "buffers must be 16-byte aligned");
+    int rc = ensure_fused_buffers(c, 0, 0);
     if (rc) return rc;
     PM_HIP(hipMemcpyAsync(c->d_tab, h_k2, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (kind == PM_GREEN_COMPENSATED) {
@@ -356,42 +449,39 @@ extern "C" int pm_poisson_fft_fused(pm_ctx *c, int kind, int p, const float *d_r
     } else {
         PM_HIP(hipMemcpyAsync(c->d_tab + n, h_s, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     }
-    float2 *B = (float2 *)c->fp_B, *C = (float2 *)c->fp_C;
     const float2 *tw = (const float2 *)c->fp_tw;
-    const int nh = n / 2 + 1;
-    const size_t lds = (size_t)(8 * (n + n / 32) + n) * sizeof(float2) + (size_t)n * sizeof(int);
+    const size_t lds = fftp_lds_bytes(n);
     const float norm = (float)(1.0 / ((double)n * n * n));
-    static bool attr_set = false;
-    if (!attr_set) {  // 72 KB of dynamic LDS at n = 1024
-        PM_HIP(hipFuncSetAttribute((const void *)fftp_z_r2c, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        PM_HIP(hipFuncSetAttribute((const void *)fftp_y<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        PM_HIP(hipFuncSetAttribute((const void *)fftp_y<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        PM_HIP(hipFuncSetAttribute((const void *)fftp_x_green<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        PM_HIP(hipFuncSetAttribute((const void *)fftp_x_green<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        PM_HIP(hipFuncSetAttribute((const void *)fftp_x_green<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        PM_HIP(hipFuncSetAttribute((const void *)fftp_z_c2r, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr_set = true;
-    }
-    const unsigned g1 = (unsigned)((int64_t)n * n / 16), g2 = (unsigned)((int64_t)nh * n / 8),
-                   g3 = (unsigned)((int64_t)n * nh / 8);
-    hipLaunchKernelGGL(fftp_z_r2c, dim3(g1), dim3(FBLK), lds, c->stream, d_rhs, B, tw, n, log2n);
-    hipLaunchKernelGGL((fftp_y<true>), dim3(g2), dim3(FBLK), lds, c->stream, B, C, tw, n, log2n);
+    const unsigned g3 = (unsigned)((int64_t)nky * nh / 8);
+    float2 *C = (float2 *)d_C;
     switch (kind) {
         case PM_GREEN_PLAIN:
             hipLaunchKernelGGL((fftp_x_green<PM_GREEN_PLAIN>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n, log2n, p,
-                               c->d_tab, c->d_tab + n, c0, norm);
+                               c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0);
             break;
         case PM_GREEN_COMPENSATED:
             hipLaunchKernelGGL((fftp_x_green<PM_GREEN_COMPENSATED>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n,
-                               log2n, p, c->d_tab, c->d_tab + n, c0, norm);
+                               log2n, p, c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0);
             break;
         default:
             hipLaunchKernelGGL((fftp_x_green<PM_GREEN_7PT>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n, log2n, p,
-                               c->d_tab, c->d_tab + n, c0, norm);
+                               c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0);
             break;
     }
-    hipLaunchKernelGGL((fftp_y<false>), dim3(g2), dim3(FBLK), lds, c->stream, B, C, tw, n, log2n);
-    hipLaunchKernelGGL(fftp_z_c2r, dim3(g1), dim3(FBLK), lds, c->stream, B, d_phi, tw, n, log2n);
     PM_LAUNCH_CHECK();
     return PM_OK;
+}
+
+extern "C" int pm_poisson_fft_fused(pm_ctx *c, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
+                                    const float *h_s, float c0) {
+    PM_REQUIRE(c && d_rhs && d_phi && h_k2 && h_s, "NULL argument");
+    FFTP_CHECK_N(c);
+    const int n = c->n;
+    int rc = ensure_fused_buffers(c, 0, (size_t)n * n * (n / 2 + 1) * sizeof(float2));
+    if (rc) return rc;
+    rc = pm_fftp_forward(c, d_rhs, n, c->fp_C);
+    if (rc) return rc;
+    rc = pm_fftp_xgreen(c, kind, p, c->fp_C, n, n, 0, h_k2, h_s, c0);
+    if (rc) return rc;
+    return pm_fftp_inverse(c, c->fp_C, n, d_phi);
 }

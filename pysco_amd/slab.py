@@ -119,6 +119,28 @@ class HipOps:
             c0 = float(np.float32(c0) * np.float32(scale))
         self.ctx.call("pm_greens_slab", kind, int(p), L.ptr(data), L.hptr(k2), L.hptr(s), c0, j0, nj)
 
+    # LDS-FFT passes of csrc/pm_fftpoisson.hip on a slab (no rocFFT, no stand-alone transposes)
+    def has_fftp(self, nx, nky) -> bool:
+        return 32 <= self.n <= 1024 and nx % 8 == 0 and nky % 8 == 0
+
+    def fftp_forward(self, rhs):
+        n, nx = self.n, rhs.shape[0]
+        out = self.torch.empty((n, n // 2 + 1, nx), dtype=self.torch.complex64, device=rhs.device)
+        self.ctx.call("pm_fftp_forward", L.ptr(rhs), nx, L.ptr(out))
+        return out
+
+    def fftp_xgreen(self, seg, kind, p, nx, nky, ky0, scale=None):
+        k2, s, c0 = fourier.green_tables(self.n, kind)
+        if scale is not None:
+            c0 = float(np.float32(c0) * np.float32(scale))
+        self.ctx.call("pm_fftp_xgreen", kind, int(p), L.ptr(seg), nx, nky, ky0, L.hptr(k2), L.hptr(s), c0)
+
+    def fftp_inverse(self, c, nx):
+        n = self.n
+        out = self.torch.empty((nx, n, n), dtype=self.torch.float32, device=c.device)
+        self.ctx.call("pm_fftp_inverse", L.ptr(c), nx, L.ptr(out))
+        return out
+
     def gradient(self, order, phi_ext, x0_phi, nx_force, x0_force):
         n = self.n
         out = self.torch.empty((nx_force, n, n, 3), dtype=self.torch.float32, device=phi_ext.device)
@@ -308,6 +330,16 @@ class Slab:
             kind, p = (L.GREEN_PLAIN, 0) if MAS_index == 0 else (L.GREEN_COMPENSATED, int(MAS_index))
         else:
             kind, p = L.GREEN_7PT, 0
+        if getattr(ops, "has_fftp", None) and ops.has_fftp(nx, ny):
+            # LDS-FFT passes: the forward stage already writes [ky][kz][x_local], so both all-to-alls
+            # exchange contiguous blocks and the x pass reads its lines as G segments of nx elements
+            c = ops.fftp_forward(rhs)                                          # [n (ky), nh, nx]
+            seg = all_to_all(c)                                                # [G (src), ny, nh, nx]
+            del c
+            ops.fftp_xgreen(seg, kind, p, nx, ny, self.rank * ny, scale)
+            back = all_to_all(seg)                                             # [n (ky), nh, nx] again
+            del seg
+            return ops.fftp_inverse(back, nx)
         spec = ops.fft2d_r2c(rhs)                                              # [nx, n, nh]
         send = spec.view(nx, G, ny, nh).permute(1, 0, 2, 3).contiguous()       # [G(dst), nx, ny, nh]
         del spec

@@ -84,6 +84,42 @@ class OracleOps:
             full *= np.float32(scale)
         data.copy_(torch.from_numpy(np.ascontiguousarray(full[:, j0:j0 + nj])))
 
+    # numpy equivalents of the LDS-FFT passes (unnormalised transforms, 1/n^3 inside the x pass)
+    def has_fftp(self, nx, nky):
+        return True
+
+    def fftp_forward(self, rhs):
+        a = np.fft.rfft(self._np(rhs).astype(np.float64), axis=2)      # [x, y, kz]
+        a = np.fft.fft(a, axis=1)                                        # [x, ky, kz]
+        return torch.from_numpy(np.ascontiguousarray(a.transpose(1, 2, 0)).astype(np.complex64))  # [ky, kz, x]
+
+    def fftp_xgreen(self, seg, kind, p, nx, nky, ky0, scale=None):
+        n, nh = self.n, self.n // 2 + 1
+        G = n // nx
+        a = self._np(seg).reshape(G, nky, nh, nx).transpose(1, 2, 0, 3).reshape(nky, nh, n)   # [ky_l, kz, x]
+        ak = np.fft.fft(a.astype(np.complex128), axis=2)                                       # [ky_l, kz, kx]
+        full = np.zeros((n, n, nh), np.complex64)
+        full[:, ky0:ky0 + nky, :] = ak.transpose(2, 0, 1)
+        if kind == L.GREEN_PLAIN:
+            orc.inverse_laplacian(full)
+        elif kind == L.GREEN_COMPENSATED:
+            orc.inverse_laplacian_compensated(full, p)
+        else:
+            orc.inverse_laplacian_7pt(full)
+        if scale is not None:
+            full *= np.float32(scale)
+        ak = full[:, ky0:ky0 + nky, :].transpose(1, 2, 0).astype(np.complex128) / float(n) ** 3
+        a = np.fft.ifft(ak, axis=2) * n                                                         # unnormalised
+        out = a.reshape(nky, nh, G, nx).transpose(2, 0, 1, 3)
+        seg.copy_(torch.from_numpy(np.ascontiguousarray(out).astype(np.complex64)).reshape(seg.shape))
+
+    def fftp_inverse(self, c, nx):
+        n = self.n
+        a = self._np(c).reshape(n, n // 2 + 1, nx).transpose(2, 0, 1).astype(np.complex128)     # [x, ky, kz]
+        a = np.fft.ifft(a, axis=1) * n
+        r = np.fft.irfft(a, n=n, axis=2) * n
+        return torch.from_numpy(np.ascontiguousarray(r.astype(np.float32)))
+
     def gradient(self, order, phi_ext, x0_phi, nx_force, x0_force):
         n = self.n
         full = np.zeros((n, n, n), np.float32)

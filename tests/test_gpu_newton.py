@@ -329,3 +329,41 @@ def test_fused_fft_poisson_vs_numpy_and_rocfft(amd, n):
         np.testing.assert_allclose(phi.cpu().numpy(), ref, rtol=0, atol=3e-6 * sc, err_msg=f"fused vs numpy kind={kind}")
         np.testing.assert_allclose(phi.cpu().numpy(), phi2.cpu().numpy(), rtol=0, atol=3e-6 * sc)
         assert torch.equal(rhs_d.cpu(), torch.from_numpy(rhs))  # the source grid is preserved
+
+
+@pytest.mark.parametrize("nseg", [2, 4])
+def test_fftp_stages_on_slabs_match_fused(amd, nseg):
+    """The slab form of the LDS-FFT passes (forward on x-slabs -> segmented x pass -> inverse on x-slabs),
+    with the all-to-all emulated by index shuffles on one GPU, reproduces pm_poisson_fft_fused bit for bit."""
+    import pysco_amd._lib as L
+    from pysco_amd import fourier
+
+    torch = amd.torch
+    n = 64
+    nx = ny = n // nseg
+    nh = n // 2 + 1
+    rhs = torch.randn((n, n, n), dtype=torch.float32, device="cuda")
+    ctx = L.context(n)
+    k2, s, c0 = fourier.green_tables(n, L.GREEN_COMPENSATED)
+    ref = torch.empty_like(rhs)
+    ctx.call("pm_poisson_fft_fused", L.GREEN_COMPENSATED, 3, L.ptr(rhs), L.ptr(ref), L.hptr(k2), L.hptr(s), c0)
+    # forward on every slab
+    cs = []
+    for r in range(nseg):
+        c = torch.empty((n, nh, nx), dtype=torch.complex64, device="cuda")
+        ctx.call("pm_fftp_forward", L.ptr(rhs[r * nx:(r + 1) * nx].contiguous()), nx, L.ptr(c))
+        cs.append(c)
+    # "all-to-all": rank q receives, from every rank r, the ky block q of r's array
+    outs = []
+    for q in range(nseg):
+        seg = torch.stack([cs[r][q * ny:(q + 1) * ny] for r in range(nseg)], dim=0).contiguous()  # [src, ny, nh, nx]
+        ctx.call("pm_fftp_xgreen", L.GREEN_COMPENSATED, 3, L.ptr(seg), nx, ny, q * ny, L.hptr(k2), L.hptr(s), c0)
+        outs.append(seg)
+    # back: rank r receives its x segment of every ky block
+    phi = torch.empty_like(rhs)
+    for r in range(nseg):
+        back = torch.cat([outs[q][r] for q in range(nseg)], dim=0).contiguous()  # [n (ky), nh, nx]
+        out = torch.empty((nx, n, n), dtype=torch.float32, device="cuda")
+        ctx.call("pm_fftp_inverse", L.ptr(back), nx, L.ptr(out))
+        phi[r * nx:(r + 1) * nx] = out
+    assert torch.equal(phi, ref)
