@@ -205,7 +205,9 @@ def main():
         cells, spec = float(n) ** 3 / world, float(n) * n * (n // 2 + 1) * 8.0 / world
         ab.update({"pm_deposit": 12.0 * npart / world + 4.0 * cells, "pm_interp_kick": 48.0 * npart / world + 12.0 * cells,
                    "pm_fft2d_r2c": 16.0 * cells, "pm_fft2d_c2r": 16.0 * cells, "pm_fft1d_x": 2.0 * spec,
-                   "pm_greens_slab": 2.0 * spec, "pm_gradient_slab": 16.0 * cells})
+                   "pm_greens_slab": 2.0 * spec, "pm_gradient_slab": 16.0 * cells,
+                   "pm_fftp_forward": 16.0 * cells, "pm_fftp_inverse": 16.0 * cells, "pm_fftp_xgreen": 2.0 * spec,
+                   "pm_kick_drift_wrap_slab": 60.0 * npart / world})
     table = []
     for name, (calls, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):
         avg = ms / calls

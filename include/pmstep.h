@@ -180,6 +180,11 @@ int pm_set_slab(pm_ctx *ctx, int nx, int x0);
  * planes from x0_force; needs phi on [x0_force - R, x0_force + nx_force + R), R = 1, 1, 2, 3 for order 2, 3, 5, 7 */
 int pm_gradient_slab(pm_ctx *ctx, int order, const float *d_phi, int nx_phi, int x0_phi, float *d_force,
                      int nx_force, int x0_force);
+/* pm_kick_drift_wrap that also lists the particles whose new x left the slab [x_lo, x_hi): their
+ * indices (unordered) go to d_leave_idx[0 .. min(*h_count, cap)), *h_count receives how many there
+ * were (synchronises; if it exceeds cap the caller rescans). */
+int pm_kick_drift_wrap_slab(pm_ctx *ctx, float *d_pos, float *d_vel, const float *d_acc, float half_dt, float dt,
+                            int64_t np, float x_lo, float x_hi, int64_t *d_leave_idx, int cap, int *h_count);
 /* slab FFT pieces: batched 2-D r2c / c2r over (y,z) on nplanes x-planes ([np,n,n] <-> [np,n,n/2+1]; the
  * c2r carries 1/n^3), and the in-place strided 1-D c2c along x of an [n, ncolumns] complex array
  * (the layout after the all-to-all transpose, ncolumns = (n/G)*(n/2+1)). */

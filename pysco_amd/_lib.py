@@ -74,6 +74,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_quartic_gauss_seidel": (_vp, _vp, _vp, _f, _vp, _i, _f),
     "pm_mond_rhs": (_vp, _vp, _vp, _i, _f, _i, _f),
     "pm_set_slab": (_vp, _i, _i),
+    "pm_kick_drift_wrap_slab": (_vp, _vp, _vp, _vp, _f, _f, _i64, _f, _f, _vp, _i, C.POINTER(_i)),
     "pm_gradient_slab": (_vp, _i, _vp, _i, _i, _vp, _i, _i),
     "pm_fft2d_r2c": (_vp, _vp, _vp, _i),
     "pm_fft2d_c2r": (_vp, _vp, _vp, _i),

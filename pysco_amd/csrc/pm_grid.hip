@@ -95,15 +95,24 @@ extern "C" int pm_periodic_wrap(pm_ctx *c, float *d_pos, int64_t count) {
 
 // leapfrog first half (integration.py:250-258): v += -half_dt*a; x += dt*v; wrap(x).  One pass over
 // the three particle arrays instead of the reference's three (axpy, axpy, wrap).
+// DETECT (slab decomposition): particles whose new x leaves [x_lo, x_hi) are appended to a list
+// (unordered; the host sorts the few entries) so that migration never scans the arrays again.
+template <bool DETECT>
 __global__ __launch_bounds__(BLK) void kick_drift_wrap_kernel(float *__restrict__ pos, float *__restrict__ vel,
                                                               const float *__restrict__ acc, float mhalf_dt, float dt,
-                                                              int64_t count, int vec_ok) {
+                                                              int64_t count, int vec_ok, float x_lo, float x_hi,
+                                                              int64_t *__restrict__ leave_idx, int cap,
+                                                              int *__restrict__ leave_count) {
     const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * BLK;
-    auto one = [&](float &x, float &v, float a) {
+    auto one = [&](float &x, float &v, float a, int64_t flat) {
         v = ew_apply<OP_AXPY>(v, a, mhalf_dt, 0.f);
         x = (dt == 1.0f) ? x + v : ((dt == -1.0f) ? x - v : x + dt * v);
         x = ew_apply<OP_WRAP>(x, 0.f, 0.f, 0.f);
+        if (DETECT && (flat % 3) == 0 && (x < x_lo || x >= x_hi)) {
+            const int slot = atomicAdd(leave_count, 1);
+            if (slot < cap) leave_idx[slot] = flat / 3;
+        }
     };
     int64_t start = 0;
     if (vec_ok) {
@@ -113,10 +122,10 @@ __global__ __launch_bounds__(BLK) void kick_drift_wrap_kernel(float *__restrict_
         const float4 *a4 = reinterpret_cast<const float4 *>(acc);
         for (int64_t i = tid; i < n4; i += nthreads) {
             float4 x = p4[i], v = v4[i], a = a4[i];
-            one(x.x, v.x, a.x);
-            one(x.y, v.y, a.y);
-            one(x.z, v.z, a.z);
-            one(x.w, v.w, a.w);
+            one(x.x, v.x, a.x, 4 * i);
+            one(x.y, v.y, a.y, 4 * i + 1);
+            one(x.z, v.z, a.z, 4 * i + 2);
+            one(x.w, v.w, a.w, 4 * i + 3);
             v4[i] = v;
             p4[i] = x;
         }
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(BLK) void kick_drift_wrap_kernel(float *__restrict_
     }
     for (int64_t i = start + tid; i < count; i += nthreads) {
         float x = pos[i], v = vel[i];
-        one(x, v, acc[i]);
+        one(x, v, acc[i], i);
         vel[i] = v;
         pos[i] = x;
     }
@@ -138,9 +147,29 @@ extern "C" int pm_kick_drift_wrap(pm_ctx *c, float *d_pos, float *d_vel, const f
     const int64_t count = 3 * np;
     int vec_ok = pm_aligned16(d_pos) && pm_aligned16(d_vel) && pm_aligned16(d_acc);
     int blocks = pm_stream_blocks(count, BLK * 4 * 2);
-    hipLaunchKernelGGL(kick_drift_wrap_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_pos, d_vel, d_acc, -half_dt,
-                       dt, count, vec_ok);
+    hipLaunchKernelGGL((kick_drift_wrap_kernel<false>), dim3(blocks), dim3(BLK), 0, c->stream, d_pos, d_vel, d_acc,
+                       -half_dt, dt, count, vec_ok, 0.f, 1.f, (int64_t *)nullptr, 0, (int *)nullptr);
     PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+extern "C" int pm_kick_drift_wrap_slab(pm_ctx *c, float *d_pos, float *d_vel, const float *d_acc, float half_dt,
+                                       float dt, int64_t np, float x_lo, float x_hi, int64_t *d_leave_idx, int cap,
+                                       int *h_count) {
+    PM_REQUIRE(c && d_leave_idx && h_count && cap > 0 && np >= 0 && (np == 0 || (d_pos && d_vel && d_acc)),
+               "bad argument");
+    int *d_count = reinterpret_cast<int *>(c->d_scratch + 16);
+    PM_HIP(hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
+    if (np > 0) {
+        const int64_t count = 3 * np;
+        int vec_ok = pm_aligned16(d_pos) && pm_aligned16(d_vel) && pm_aligned16(d_acc);
+        int blocks = pm_stream_blocks(count, BLK * 4 * 2);
+        hipLaunchKernelGGL((kick_drift_wrap_kernel<true>), dim3(blocks), dim3(BLK), 0, c->stream, d_pos, d_vel, d_acc,
+                           -half_dt, dt, count, vec_ok, x_lo, x_hi, d_leave_idx, cap, d_count);
+        PM_LAUNCH_CHECK();
+    }
+    PM_HIP(hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
     return PM_OK;
 }
 

@@ -55,8 +55,19 @@ class HipOps:
         self.ctx = L.context(n)
 
     # particles
-    def kick_drift_wrap(self, pos, vel, acc, half_dt, dt):
-        self.ctx.call("pm_kick_drift_wrap", L.ptr(pos), L.ptr(vel), L.ptr(acc), float(half_dt), float(dt), pos.shape[0])
+    def kick_drift_wrap(self, pos, vel, acc, half_dt, dt, x_lo, x_hi):
+        """Fused kick + drift + wrap; returns the (sorted) indices of the particles that left [x_lo, x_hi)."""
+        torch, n = self.torch, pos.shape[0]
+        cap = max(4096, n // 16)
+        if getattr(self, "_leave_buf", None) is None or self._leave_buf.numel() < cap:
+            self._leave_buf = torch.empty(cap, dtype=torch.int64, device=pos.device)
+        count = C.c_int(0)
+        self.ctx.call("pm_kick_drift_wrap_slab", L.ptr(pos), L.ptr(vel), L.ptr(acc), float(half_dt), float(dt), n,
+                      float(x_lo), float(x_hi), L.ptr(self._leave_buf), cap, C.byref(count))
+        if count.value > cap:  # more leavers than the list holds (unsorted / first placement): rescan
+            x = pos[:, 0]
+            return torch.nonzero((x < x_lo) | (x >= x_hi), as_tuple=False).squeeze(1)
+        return torch.sort(self._leave_buf[:count.value]).values
 
     def deposit(self, scheme, pos, nx, x0):
         n = self.n
@@ -259,6 +270,91 @@ class Slab:
                 result.append(torch.cat([stay, recv], dim=0) if recv.shape[0] else stay.contiguous())
         return tuple(result)
 
+    # ---- capacity-backed particle storage + O(leavers) migration ----------------------------------
+    def _adopt(self, position, velocity):
+        """Make (position, velocity, *carry) views of buffers with head-room so that arrivals can be
+        appended without reallocating; no-op when the caller hands back last step's views."""
+        import torch
+
+        st = getattr(self, "_store", None)
+        n = position.shape[0]
+        if (st is not None and st["n"] == n and st["bufs"][0].data_ptr() == position.data_ptr()
+                and st["bufs"][1].data_ptr() == velocity.data_ptr()):
+            return
+        cap = int(n * 1.03) + 4096
+        bufs = []
+        for a in (position, velocity) + tuple(self.carry):
+            b = torch.empty((cap,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+            b[:n] = a
+            bufs.append(b)
+        self._store = {"bufs": bufs, "n": n, "cap": cap}
+
+    def _views(self):
+        st = self._store
+        v = [b[:st["n"]] for b in st["bufs"]]
+        self.carry = tuple(v[2:])
+        return v[0], v[1]
+
+    def _grow(self, need):
+        import torch
+
+        st = self._store
+        cap = int(need * 1.05) + 4096
+        new = []
+        for b in st["bufs"]:
+            nb = torch.empty((cap,) + tuple(b.shape[1:]), dtype=b.dtype, device=b.device)
+            nb[:st["n"]] = b[:st["n"]]
+            new.append(nb)
+        st["bufs"], st["cap"] = new, cap
+
+    def _migrate_leavers(self, leave):
+        """Send the particles at (sorted) indices `leave` to their owners and file the arrivals into the
+        holes they leave; surplus holes are filled from the tail, surplus arrivals are appended.  Touches
+        O(leavers + arrivals) elements -- never the whole arrays."""
+        import torch
+
+        st = self._store
+        bufs, n = st["bufs"], st["n"]
+        nl = int(leave.numel())
+        dev = bufs[0].device
+        counts_out = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        by_dest = leave
+        if nl:
+            dest = self.owner_of(bufs[0][leave])
+            order = torch.argsort(dest, stable=True)
+            by_dest = leave[order]
+            counts_out = torch.bincount(dest, minlength=self.world)
+        counts_in = all_to_all(counts_out)
+        out_splits = [int(c) for c in counts_out.tolist()]
+        in_splits = [int(c) for c in counts_in.tolist()]
+        na = sum(in_splits)
+        arrivals = [all_to_all(b[by_dest], in_splits, out_splits) for b in bufs]
+        if nl == 0 and na == 0:
+            return
+        if na >= nl:
+            extra = na - nl
+            if n + extra > st["cap"]:
+                self._grow(n + extra)
+                bufs = st["bufs"]
+            for b, a in zip(bufs, arrivals):
+                if nl:
+                    b[leave] = a[:nl]
+                if extra:
+                    b[n:n + extra] = a[nl:]
+            st["n"] = n + extra
+        else:
+            n_new = n - (nl - na)
+            rem = leave[na:]                                   # holes no arrival fills (ascending)
+            tail = torch.arange(n_new, n, device=dev)
+            movers = tail[~torch.isin(tail, rem)]              # live particles beyond the new end
+            targets = rem[rem < n_new]                         # holes below it: same count
+            for b, a in zip(bufs, arrivals):
+                if na:
+                    b[leave[:na]] = a
+                if movers.numel():
+                    b[targets] = b[movers]
+            st["n"] = n_new
+
     # ---- the PM solve (solver.py:30-215, Newtonian FFT branch) -------------------------------------
     def pm(self, position, param, potential=None, additional_field=None, tables=(), kick=None):
         import torch
@@ -360,7 +456,10 @@ class Slab:
         from . import utils
 
         ops = self.ops
-        if getattr(self, "_max_for", None) == (id(acceleration), id(velocity)):
+        self._adopt(position, velocity)
+        position, velocity = self._views()
+        key = (acceleration.data_ptr(), acceleration.shape[0], velocity.data_ptr(), velocity.shape[0])
+        if getattr(self, "_max_for", None) == key:
             ma, mv = self.local_max
         else:
             ma, mv = ops.max_abs(acceleration), ops.max_abs(velocity)
@@ -387,23 +486,25 @@ class Slab:
             param["aexp"] = np.exp(tables[0](param["t"]))
             utils.set_units(param)
 
+        x_lo, x_hi = self.rank / self.world, (self.rank + 1) / self.world  # exact in fp32 (G is a power of two)
         if INTEGRATOR == "leapfrog":
             half_dt = np.float32(0.5 * dt)
-            ops.kick_drift_wrap(position, velocity, acceleration, half_dt, np.float32(dt))
+            leave = ops.kick_drift_wrap(position, velocity, acceleration, half_dt, np.float32(dt), x_lo, x_hi)
             advance_clock()
-            position, velocity, *carry = self.migrate(position, velocity, *self.carry)
-            self.carry = tuple(carry)
+            self._migrate_leavers(leave)
+            position, velocity = self._views()
             acceleration, potential, additional_field = self.pm(position, param, potential, additional_field, tables,
                                                                 kick=(velocity, half_dt))
         else:
-            ops.kick_drift_wrap(position, velocity, acceleration, np.float32(0), np.float32(dt))  # drift + wrap only
-            advance_clock()
+            # drift with the old velocity, then kick with the old acceleration (integration.py:178-183)
+            leave = ops.kick_drift_wrap(position, velocity, acceleration, np.float32(0), np.float32(dt), x_lo, x_hi)
             ops.axpy(velocity, acceleration, -np.float32(dt))
-            position, velocity, *carry = self.migrate(position, velocity, *self.carry)
-            self.carry = tuple(carry)
+            advance_clock()
+            self._migrate_leavers(leave)
+            position, velocity = self._views()
             acceleration, potential, additional_field = self.pm(position, param, potential, additional_field, tables)
             self.local_max = (self.local_max[0], ops.max_abs(velocity))
-        self._max_for = (id(acceleration), id(velocity))
+        self._max_for = (acceleration.data_ptr(), acceleration.shape[0], velocity.data_ptr(), velocity.shape[0])
         return position, velocity, acceleration, potential, additional_field
 
 

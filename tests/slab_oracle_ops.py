@@ -19,11 +19,13 @@ class OracleOps:
     def _planes(self, nx, x0):
         return [(x0 + l) % self.n for l in range(nx)]
 
-    def kick_drift_wrap(self, pos, vel, acc, half_dt, dt):
+    def kick_drift_wrap(self, pos, vel, acc, half_dt, dt, x_lo, x_hi):
         p, v, a = self._np(pos), self._np(vel), self._np(acc)
         orc.add_vector_scalar_inplace(v, a, -np.float32(half_dt))
         orc.add_vector_scalar_inplace(p, v, np.float32(dt))
         orc.periodic_wrap(p)
+        x = p[:, 0]
+        return torch.from_numpy(np.nonzero((x < np.float32(x_lo)) | (x >= np.float32(x_hi)))[0].astype(np.int64))
 
     def deposit(self, scheme, pos, nx, x0):
         fn = {L.TSC: orc.TSC, L.CIC: orc.CIC, L.NGP: orc.NGP}[scheme]

@@ -1,5 +1,5 @@
 """Worker for tests/test_slab_gloo.py (and the 2-rank GPU rehearsal): one rank of a slab-decomposed
-run.  usage: python -m tests.slab_worker <rank> <world> <port> <outdir> <backend: oracle|hip> <n> <steps>"""
+run.  usage: python -m tests.slab_worker <rank> <world> <port> <outdir> <backend: oracle|hip> <n> <steps> [integrator]"""
 import os
 import sys
 
@@ -31,6 +31,11 @@ def main():
              "linear_newton_solver": "fft", "gradient_stencil_order": 5, "save_power_spectrum": "no", "nthreads": 1,
              "Courant_factor": 1.0, "max_aexp_stepping": 10, "integrator": "leapfrog", "write_snapshot": False,
              "nsteps": 0}
+    if len(sys.argv) > 8:
+        param["integrator"] = sys.argv[8]
+    if len(sys.argv) > 9 and sys.argv[9] == "asym":  # one-way flow across x = 0.5: rank 0 only loses, rank 1 only gains
+        vel[:] = 0
+        vel[(pos[:, 0] > 0.25) & (pos[:, 0] < 0.5), 0] = 1.0
     param["t"] = float(tables[1](np.log(param["aexp"])))
     s = slab.get(n, ops)
     mine = (np.floor(pos[:, 0] * world).astype(int).clip(0, world - 1) == rank)

@@ -21,24 +21,29 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def run_ranks(world, outdir, backend, n, steps, timeout=600):
+def run_ranks(world, outdir, backend, n, steps, timeout=600, integrator="leapfrog", flow="sym"):
     port = _free_port()
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, "-m", "tests.slab_worker", str(r), str(world), port, str(outdir),
-                               backend, str(n), str(steps)], cwd=ROOT, env=env) for r in range(world)]
+                               backend, str(n), str(steps), integrator, flow], cwd=ROOT, env=env)
+             for r in range(world)]
     codes = [p.wait(timeout=timeout) for p in procs]
     assert codes == [0] * world, codes
     return [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
 
 
-def reference_run(n, steps):
+def reference_run(n, steps, integrator="leapfrog", flow="sym"):
     pos, vel = zeldovich_particles(n, seed=11, rms_cells=1.2, vel_factor=0.5)
+    if flow == "asym":
+        vel[:] = 0
+        vel[(pos[:, 0] > 0.25) & (pos[:, 0] < 0.5), 0] = 1.0
     tables = synth_tables()
     param = {"theory": "newton", "mass_scheme": "TSC", "npart": n**3, "ncoarse": int(np.log2(n)), "Om_m": 0.25733,
              "Om_lambda": 0.742589237, "H0": 72.0, "boxlen": 100.0, "aexp": 0.5, "aexp_old": 0.49,
              "linear_newton_solver": "fft", "gradient_stencil_order": 5, "save_power_spectrum": "no", "nthreads": 1,
              "Courant_factor": 1.0, "max_aexp_stepping": 10, "integrator": "leapfrog", "write_snapshot": False,
              "nsteps": 0}
+    param["integrator"] = integrator
     param["t"] = float(tables[1](np.log(param["aexp"])))
     p, v = pos.copy(), vel.copy()
     acc, phi, extra = orc.pm(p, param, tables=tables)
@@ -81,6 +86,22 @@ def test_two_rank_slab_step_matches_single_process(tmp_path):
     ranks = run_ranks(world, tmp_path, "oracle", n, steps)
     moved = check_against_reference(ranks, reference_run(n, steps), n, world)
     print(f"{moved} particles changed rank")
+
+
+def test_two_rank_one_way_flow_fills_holes_and_appends(tmp_path):
+    """Rank 0 only loses particles (holes refilled from its tail), rank 1 only gains (appended)."""
+    n, steps, world = 32, 2, 2
+    ranks = run_ranks(world, tmp_path, "oracle", n, steps, flow="asym")
+    ref = reference_run(n, steps, flow="asym")
+    moved = check_against_reference(ranks, ref, n, world)
+    n0 = int((np.floor(ref["pos0"][:, 0] * world).astype(int) == 0).sum())
+    assert len(ranks[0]["id"]) < n0 < n**3 - len(ranks[1]["id"]) + n0 and moved > 100
+
+
+def test_two_rank_slab_euler(tmp_path):
+    n, steps, world = 32, 2, 2
+    ranks = run_ranks(world, tmp_path, "oracle", n, steps, integrator="euler")
+    check_against_reference(ranks, reference_run(n, steps, "euler"), n, world)
 
 
 def test_four_rank_slab_step(tmp_path):
