@@ -143,12 +143,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())  # (== local_rank on a full node)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("PMSTEP_DIST_BACKEND", "nccl")  # "gloo": rehearsal of this path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from pysco_amd import _lib as L
     from pysco_amd import integration, solver, utils
@@ -189,7 +194,7 @@ def main():
     wall = time.perf_counter() - t0
     stages = L.profile_stop()
     if dist is not None:  # the step is over when the slowest rank is
-        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
 
