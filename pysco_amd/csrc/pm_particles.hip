@@ -787,21 +787,28 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     const TileId t = tile_of_key(key);
     PosQueue q;
     q.prime(pos, s + tid, e);
-    {   // tile fill: all loads in flight before the first LDS write
-        constexpr int NQ = (PM_TILE + BLK - 1) / BLK;
-        float gx[NQ], gy[NQ], gz[NQ];
+    {   // tile fill, float-granular: consecutive lanes read consecutive floats of a tile row (18 cells x 3
+        // components = 216 contiguous bytes), so a wave load is a few full lines instead of 64 scattered
+        // 12-byte pieces (PMC: the per-cell dwordx3 fill fetched 2.4x the tile bytes).  All loads are in
+        // flight before the first LDS write.
+        constexpr int NF = PM_TILE * 3, NQ = (NF + BLK - 1) / BLK;  // 9720 floats, 38 per thread
+        float g[NQ];
+        float *tile_f = reinterpret_cast<float *>(tile);
 #pragma unroll
-        for (int c4 = 0; c4 < NQ; ++c4) {
-            const int c = c4 * BLK + tid;
-            if (c < PM_TILE) {
-                const float *g = grid + 3 * tile_cell_global(c, t, geo);
-                gx[c4] = g[0], gy[c4] = g[1], gz[c4] = g[2];
+        for (int u = 0; u < NQ; ++u) {
+            const int f = u * BLK + tid;
+            if (f < NF) {
+                const int c = f / 3, m = f - 3 * c;
+                g[u] = grid[3 * tile_cell_global(c, t, geo) + m];
             }
         }
 #pragma unroll
-        for (int c4 = 0; c4 < NQ; ++c4) {
-            const int c = c4 * BLK + tid;
-            if (c < PM_TILE) tile[c] = make_float4(gx[c4], gy[c4], gz[c4], 0.f);
+        for (int u = 0; u < NQ; ++u) {
+            const int f = u * BLK + tid;
+            if (f < NF) {
+                const int c = f / 3, m = f - 3 * c;
+                tile_f[4 * c + m] = g[u];
+            }
         }
     }
     __syncthreads();
