@@ -11,7 +11,8 @@ x-planes [r*n/G, (r+1)*n/G) of every grid and the particles inside them.  Exchan
   particles all-to-all of the particles that left the slab after the drift
   scalars   max|a|, max|v| all-reduce(MAX) for dt
 
-Only the Newtonian FFT path is decomposed so far; multigrid / f(R) / MOND raise in multi-GPU mode.
+The Newtonian FFT path is fully decomposed.  Multigrid / f(R) / MOND / P(k) run with decomposed
+particles but a replicated grid solve (all-gather of the density slabs; halo-exchange multigrid is next).
 All compute goes through an `ops` provider: `HipOps` (libpmstep, the product path).  The CPU tests
 inject their own provider built on the oracle -- nothing in this package falls back to the CPU.
 """
@@ -370,21 +371,20 @@ class Slab:
             param["MAS_index"] = 3
         else:
             raise NotImplementedError(f"{param['mass_scheme']=}, should be 'CIC' or 'TSC'")
-        if THEORY not in ("newton",):
-            raise NotImplementedError(f"multi-GPU slabs: theory {THEORY!r} is single-GPU only for now")
+        if THEORY not in ("newton", "parametrized", "fr", "mond"):
+            raise NotImplementedError(f"{param['theory']=}, should be 'newton', 'fr', 'parametrized' or 'mond'")
         LINEAR_NEWTON_SOLVER = param["linear_newton_solver"].casefold()
-        if LINEAR_NEWTON_SOLVER not in ("fft", "fft_7pt"):
-            raise NotImplementedError(
-                f"multi-GPU slabs: linear_newton_solver {LINEAR_NEWTON_SOLVER!r} is single-GPU only for now")
         SAVE = param["save_power_spectrum"].casefold()
         if SAVE not in ("yes", "z_out", "no"):
             raise NotImplementedError(f"SAVE_POWER_SPECTRUM={SAVE!r}, should be 'yes', 'z_out' or 'no'")
-        param["save_pk"] = SAVE == "yes" or (SAVE == "z_out" and bool(param["write_snapshot"]))
-        if param["save_pk"]:
-            raise NotImplementedError("multi-GPU slabs: P(k) output is single-GPU only for now")
-        param["parametrized_mu_z"] = np.float32(1)
+        save_pk = SAVE == "yes" or (SAVE == "z_out" and bool(param["write_snapshot"]))
         scheme = _SCHEME[MASS_SCHEME]
         nx = self.nx
+        decomposed = THEORY == "newton" and LINEAR_NEWTON_SOLVER in ("fft", "fft_7pt") and not save_pk
+        if not decomposed:
+            return self._pm_replicated_grid(position, param, potential, additional_field, tables, kick, scheme)
+        param["save_pk"] = False
+        param["parametrized_mu_z"] = np.float32(1)
 
         # deposit into the slab + one ghost plane each side, then fold the ghosts into the neighbours
         rho_ext = ops.deposit(scheme, position, nx + 2, self.x_lo - 1)
@@ -414,6 +414,45 @@ class Slab:
         self.local_max = (ma, mv)
         empty = torch.empty(0, dtype=torch.float32, device=position.device)
         return acc, phi, empty
+
+    def _pm_replicated_grid(self, position, param, potential, additional_field, tables, kick, scheme):
+        """Multigrid / f(R) / MOND / P(k) under slabs, first cut: the particles (deposit, gather, kick) stay
+        decomposed, but the density slabs are all-gathered and every rank runs the single-GPU grid solve
+        on the full mesh (no halo-exchange multigrid yet).  Returns the FULL potential / extra field so
+        that the next step can warm-start from them (solver.py:273-280)."""
+        import torch
+
+        from . import solver
+
+        n, nx, ops = self.n, self.nx, self.ops
+        dist = _dist()
+        rho_ext = ops.deposit(scheme, position, nx + 2, self.x_lo - 1)
+        from_left, from_right = exchange_planes(rho_ext[0], rho_ext[nx + 1])
+        rho_ext[1] += from_left
+        rho_ext[nx] += from_right
+        mine = _stage(rho_ext[1:nx + 1].contiguous())
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        density = _unstage(torch.cat(parts, dim=0), position)
+        del rho_ext, mine, parts
+        if potential is None:
+            potential = torch.empty(0, dtype=torch.float32, device=position.device)
+        if additional_field is None:
+            additional_field = torch.empty(0, dtype=torch.float32, device=position.device)
+        solver._WRITE_PK = self.rank == 0
+        try:
+            potential, additional_field, force = solver._solve_grid(density, param, potential, additional_field,
+                                                                    tables)
+        finally:
+            solver._WRITE_PK = True
+        del density
+        planes = [(self.x_lo - 1 + l) % n for l in range(nx + 2)]
+        force_loc = force[planes].contiguous()  # own planes + one ghost each side
+        del force
+        vel, half_dt = (kick if kick is not None else (None, 0.0))
+        acc, ma, mv = ops.interp_kick(scheme, force_loc, nx + 2, self.x_lo - 1, position, vel, half_dt)
+        self.local_max = (ma, mv)
+        return acc, potential, additional_field
 
     def poisson_fft(self, rhs, param, scale=None):
         """solver.fft (solver.py:453-522) on slabs: 2-D r2c, transpose, 1-D c2c, Green's function in

@@ -16,6 +16,7 @@ from . import _lib as L
 from . import fourier, iostream, mesh, utils
 
 _C_LIGHT = 299792458.0  # astropy.constants.c (solver.py:14)
+_WRITE_PK = True       # the slab layer lets only rank 0 write the P(k) file
 _USE_FUSED_FFT = True  # False: rocFFT r2c -> Green's function -> c2r (always used when P(k) is written)
 
 
@@ -59,6 +60,29 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     else:
         raise NotImplementedError(f"{param['mass_scheme']=}, should be 'CIC' or 'TSC'")
 
+    potential_d, additional_field_d, force = _solve_grid(density, param, _dev(potential), _dev(additional_field),
+                                                         tables)
+    del density
+
+    if _kick is not None and ncells_1d >= 16:
+        acceleration = mesh.interp_vec_kick(MASS_SCHEME, force, pos_d, _kick[0], _kick[1])
+    else:
+        acceleration = mesh.invCIC_vec(force, pos_d) if MASS_SCHEME == "cic" else mesh.invTSC_vec(force, pos_d)
+        if _kick is not None:
+            utils.add_vector_scalar_inplace(_kick[0], acceleration, -_kick[1])
+    del force
+    if L.is_device_array(position):
+        return acceleration, potential_d, additional_field_d
+    return acceleration.cpu().numpy(), potential_d.cpu().numpy(), additional_field_d.cpu().numpy()
+
+
+def _solve_grid(density, param, potential_d, additional_field_d, tables):
+    """Everything of pm() between the deposit and the interpolation, on a full [n,n,n] density grid:
+    normalisation, [P(k)], extra field, rhs, Poisson solve, force.  Returns (potential, additional_field,
+    force[n,n,n,3]).  Shared by the single-GPU pm() and the replicated grid solve of the slab layer
+    (which clears _WRITE_PK on all ranks but one)."""
+    ncells_1d = density.shape[0]
+    THEORY = param["theory"].casefold()
     if THEORY == "parametrized":  # solver.py:95-110
         evolution_term = param["aexp"] ** (-3 * (1 + param["w0"] + param["wa"])) * np.exp(
             -3 * param["wa"] * (1 - param["aexp"])
@@ -92,10 +116,11 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
         del density_fourier
         Pk *= np.float32((param["boxlen"] / ncells_1d**2) ** 3)
         k *= np.float32(2 * np.pi / param["boxlen"])
-        iostream.write_power_spectrum_to_ascii_file(k, Pk, Nmodes, param)
+        if _WRITE_PK:
+            iostream.write_power_spectrum_to_ascii_file(k, Pk, Nmodes, param)
 
     param["compute_additional_field"] = True
-    additional_field_d = get_additional_field(_dev(additional_field), density, param, tables)
+    additional_field_d = get_additional_field(additional_field_d, density, param, tables)
     param["compute_additional_field"] = False
     # Newtonian FFT solve without P(k): rhs = f1*(rho - 1) is linear and its k = 0 mode is discarded by
     # the Green's function (fourier.py:491, 544, 595), so the scaling pass (solver.py:445-449) folds
@@ -105,9 +130,7 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     if not fold_scale:
         rhs_poisson(density, additional_field_d, param)
     rhs = density
-    del density
 
-    potential_d = _dev(potential)
     if LINEAR_NEWTON_SOLVER == "multigrid":
         potential_d = initialise_potential(potential_d, rhs, param, tables)
         from . import multigrid
@@ -136,16 +159,7 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     else:
         force = mesh.derivative(potential_d, param["gradient_stencil_order"])
 
-    if _kick is not None and ncells_1d >= 16:
-        acceleration = mesh.interp_vec_kick(MASS_SCHEME, force, pos_d, _kick[0], _kick[1])
-    else:
-        acceleration = mesh.invCIC_vec(force, pos_d) if MASS_SCHEME == "cic" else mesh.invTSC_vec(force, pos_d)
-        if _kick is not None:
-            utils.add_vector_scalar_inplace(_kick[0], acceleration, -_kick[1])
-    del force
-    if L.is_device_array(position):
-        return acceleration, potential_d, additional_field_d
-    return acceleration.cpu().numpy(), potential_d.cpu().numpy(), additional_field_d.cpu().numpy()
+    return potential_d, additional_field_d, force
 
 
 def _dev(x):
@@ -292,7 +306,8 @@ def fft(rhs, param, _source_scale=None):
             / param["parametrized_mu_z"] ** 2
         )
         k *= np.float32(2 * np.pi / param["boxlen"])
-        iostream.write_power_spectrum_to_ascii_file(k, Pk, Nmodes, param)
+        if _WRITE_PK:
+            iostream.write_power_spectrum_to_ascii_file(k, Pk, Nmodes, param)
     ctx.call("pm_greens", kind, p, L.ptr(rhs_fourier), L.hptr(k2), L.hptr(s), c0)
     ctx.call("pm_fft_c2r", L.ptr(rhs_fourier), L.ptr(phi))
     return phi

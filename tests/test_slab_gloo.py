@@ -21,18 +21,19 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def run_ranks(world, outdir, backend, n, steps, timeout=600, integrator="leapfrog", flow="sym"):
+def run_ranks(world, outdir, backend, n, steps, timeout=600, integrator="leapfrog", flow="sym", theory=None):
     port = _free_port()
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
+    extra = [theory] if theory else []
     procs = [subprocess.Popen([sys.executable, "-m", "tests.slab_worker", str(r), str(world), port, str(outdir),
-                               backend, str(n), str(steps), integrator, flow], cwd=ROOT, env=env)
+                               backend, str(n), str(steps), integrator, flow] + extra, cwd=ROOT, env=env)
              for r in range(world)]
     codes = [p.wait(timeout=timeout) for p in procs]
     assert codes == [0] * world, codes
     return [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
 
 
-def reference_run(n, steps, integrator="leapfrog", flow="sym"):
+def reference_run(n, steps, integrator="leapfrog", flow="sym", theory=None):
     pos, vel = zeldovich_particles(n, seed=11, rms_cells=1.2, vel_factor=0.5)
     if flow == "asym":
         vel[:] = 0
@@ -44,7 +45,15 @@ def reference_run(n, steps, integrator="leapfrog", flow="sym"):
              "Courant_factor": 1.0, "max_aexp_stepping": 10, "integrator": "leapfrog", "write_snapshot": False,
              "nsteps": 0}
     param["integrator"] = integrator
+    if theory:
+        param.update({"Npre": 2, "Npost": 1, "epsrel": 1e-2, "linear_newton_solver": "multigrid"})
+        if theory == "mond":
+            param.update({"theory": "mond", "mond_function": "simple", "mond_g0": 1.2, "mond_alpha": 1,
+                          "mond_scale_factor_exponent": 0})
+        elif theory == "fr":
+            param.update({"theory": "fr", "fR_n": 1, "fR_logfR0": 5, "boxlen": 1000.0})
     param["t"] = float(tables[1](np.log(param["aexp"])))
+    orc.set_units(param)
     p, v = pos.copy(), vel.copy()
     acc, phi, extra = orc.pm(p, param, tables=tables)
     acc0, phi0 = acc.copy(), phi.copy()
@@ -117,3 +126,25 @@ def test_two_ranks_on_one_gpu_hip(tmp_path):
     n, steps, world = 64, 2, 2
     ranks = run_ranks(world, tmp_path, "hip", n, steps)
     check_against_reference(ranks, reference_run(n, steps), n, world)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("theory", ["newton_mg", "mond", "fr"])
+def test_two_ranks_replicated_grid_solve_hip(tmp_path, theory):
+    """Multigrid / MOND / f(R) under slabs: decomposed particles + replicated grid solve (HIP kernels,
+    2 ranks sharing cuda:0 over gloo) against the single-process oracle, at the solvers' own accuracy."""
+    n, steps, world = 32, 1, 2
+    ranks = run_ranks(world, tmp_path, "hip", n, steps, theory=theory)
+    ref = reference_run(n, steps, theory=theory)
+    ids0 = np.concatenate([r["id0"] for r in ranks])
+    acc0 = np.concatenate([r["acc0"] for r in ranks])
+    sa = np.abs(ref["acc0"]).max()
+    np.testing.assert_allclose(acc0, ref["acc0"][ids0], rtol=0, atol=2e-3 * sa)
+    for r in ranks:  # every rank holds the full potential (warm start of the next solve)
+        assert r["phi0"].shape == (n, n, n)
+        np.testing.assert_allclose(r["phi0"], ref["phi0"], rtol=0, atol=5e-4 * np.abs(ref["phi0"]).max())
+    ids = np.concatenate([r["id"] for r in ranks])
+    assert sorted(ids.tolist()) == list(range(n**3))
+    pos = np.concatenate([r["pos"] for r in ranks])
+    d = np.abs(pos - ref["pos"][ids])
+    assert np.minimum(d, 1 - d).max() < 1e-4
