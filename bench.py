@@ -101,6 +101,7 @@ def alg_bytes(n, npart):
         "pm_gradient": 16.0 * cells,                 # read phi, write F(3)
         "pm_interp": 24.0 * npart + 12.0 * cells,    # read x, F; write a
         "pm_interp_kick": 48.0 * npart + 12.0 * cells,  # gather + second kick + CFL maxima: read x,v,F; write v,a
+        "pm_gradient_interp_kick": 48.0 * npart + 4.0 * cells,  # the same reading phi instead of F (gradient fused)
         "pm_axpy": 36.0 * npart,                     # second kick: read v,a; write v
         "pm_max_abs": 12.0 * npart,                  # CFL reductions (two per step)
     }
@@ -204,7 +205,8 @@ def main():
 
     ab = alg_bytes(n, npart / world)
     for k in ab:  # per-rank share of the grid stages in slab mode
-        if k not in ("pm_kick_drift_wrap", "pm_deposit", "pm_interp", "pm_interp_kick", "pm_axpy", "pm_max_abs"):
+        if k not in ("pm_kick_drift_wrap", "pm_deposit", "pm_interp", "pm_interp_kick", "pm_gradient_interp_kick",
+                     "pm_axpy", "pm_max_abs"):
             ab[k] /= world
     if world > 1:
         cells, spec = float(n) ** 3 / world, float(n) * n * (n // 2 + 1) * 8.0 / world

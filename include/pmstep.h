@@ -125,6 +125,23 @@ int pm_kick_drift_wrap(pm_ctx *ctx, float *d_pos, float *d_vel, const float *d_a
  * for Morton-sorted streams; any particle order gives the same result.  Needs n >= 16. */
 int pm_interp_kick(pm_ctx *ctx, int scheme, const float *d_force, const float *d_pos, int64_t np, float *d_acc,
                    float *d_vel, float half_dt);
+/* Optional preparation for the tile-range kernels (pm_deposit with sorted_hint 1, pm_interp_kick,
+ * pm_gradient_interp_kick), no reference counterpart.  A stream that was Morton-sorted some steps ago
+ * (main.py:146-150 re-orders every n_reorder steps) has stragglers: particles filed under a tile they
+ * have left.  Served one by one from global memory they dominate the kernels already at 1 % (scattered
+ * atomics / loads).  pm_tile_lists computes the tile ranges once and, in one pass over the positions,
+ * the list of stragglers grouped by the tile they are in now, so that every later call on the SAME d_pos /
+ * np serves all particles from LDS.  The lists are dropped by pm_tile_lists(ctx, NULL, 0), by any ctx call
+ * that writes positions, and must be dropped by the caller before d_pos is modified otherwise.  Results
+ * are identical with and without (gather: same bits; deposit: same sums up to atomic ordering). */
+int pm_tile_lists(pm_ctx *ctx, const float *d_pos, int64_t np);
+/* mesh.derivative (mesh.py:2072, orders 2/3/5/7) + pm_interp_kick in one kernel: every workgroup stages the
+ * potential of its tile in LDS, differentiates it there with the reference's stencil and gathers from the
+ * result, so the [n,n,n,3] force grid is never written or read.  Same bits as pm_gradient followed by
+ * pm_interp_kick.  d_phi holds nx_phi planes starting at global plane x0_phi (single GPU: n, 0; slabs: the
+ * owned planes + reach+1 ghosts each side).  d_vel may be NULL (no kick).  Needs n >= 16. */
+int pm_gradient_interp_kick(pm_ctx *ctx, int order, int scheme, const float *d_phi, int nx_phi, int x0_phi,
+                            const float *d_pos, int64_t np, float *d_acc, float *d_vel, float half_dt);
 /* utils.max_abs of the acc / vel arrays written by the last pm_interp_kick (syncs).  *h_max_vel is 0
  * if that call had d_vel == NULL. */
 int pm_last_maxabs(pm_ctx *ctx, float *h_max_acc, float *h_max_vel);

@@ -63,6 +63,37 @@ __device__ __forceinline__ int64_t pm_cell(const pm_geom &g, int gi, int gj, int
     li = li < g.nx ? li : g.nx - 1;
     return ((((int64_t)li << g.log2n) + (gj & g.mask)) << g.log2n) + (gk & g.mask);
 }
+
+// 1-D gradient stencils of mesh.py:639-850 (and the f(R) fused variants :860-2069), shared by the grid
+// gradient kernels (pm_grid.hip) and the gather that differentiates its own phi tile (pm_particles.hip)
+template <int FRN>
+__device__ __forceinline__ float fr_pow(float b) {
+    return FRN == 1 ? b * b : b * b * b;
+}
+
+template <int ORDER, int FRN>
+struct Stencil {
+    // value of the 1-D stencil given a[-3..3] (and b when FRN>0); operation order as the reference
+    static __device__ __forceinline__ float eval(const float *a, const float *b, float f, float scale) {
+        // a[3] is the centre
+        if (ORDER == 2) {
+            if (FRN == 0) return scale * (-a[3] + a[4]);
+            return scale * (-a[3] + a[4] + f * (-fr_pow<FRN>(b[3]) + fr_pow<FRN>(b[4])));
+        } else if (ORDER == 3) {
+            if (FRN == 0) return scale * (-a[2] + a[4]);
+            return scale * (-a[2] + a[4] + f * (-fr_pow<FRN>(b[2]) + fr_pow<FRN>(b[4])));
+        } else if (ORDER == 5) {
+            if (FRN == 0) return scale * (8.0f * (-a[2] + a[4]) + a[1] - a[5]);
+            return scale * (8.0f * (-a[2] + a[4] + f * (-fr_pow<FRN>(b[2]) + fr_pow<FRN>(b[4]))) + a[1] - a[5] +
+                            f * (fr_pow<FRN>(b[1]) - fr_pow<FRN>(b[5])));
+        } else {
+            if (FRN == 0) return scale * (45.0f * (-a[2] + a[4]) + 9.0f * (a[1] - a[5]) - a[0] + a[6]);
+            return scale * (45.0f * (-a[2] + a[4] + f * (-fr_pow<FRN>(b[2]) + fr_pow<FRN>(b[4]))) +
+                            9.0f * (+a[1] - a[5] + f * (fr_pow<FRN>(b[1]) - fr_pow<FRN>(b[5]))) - a[0] + a[6] +
+                            f * (-fr_pow<FRN>(b[0]) + fr_pow<FRN>(b[6])));
+        }
+    }
+};
 #endif
 
 struct pm_ctx {
@@ -93,6 +124,14 @@ struct pm_ctx {
     void *tile_tmp;
     size_t tile_tmp_bytes;
     int gather_mode;  // 1: tile-range gather (default), 2: chunk/anchor gather
+    // prepared tile ranges + straggler lists (pm_tile_lists): valid for exactly these positions
+    const float *lists_pos;
+    int64_t lists_np;
+    unsigned lists_blocks;
+    int lists_use;       // 1: every straggler is in the per-tile incoming lists
+    const void *lists_ptr[4];  // start, xstart (tile_tmp); idx, lstart (list_buf)
+    void *list_buf;      // keys/indices (in, out), per-tile list offsets, sort scratch
+    size_t list_buf_bytes;
     // sort workspace (grown on demand)
     void *sort_tmp;
     size_t sort_tmp_bytes;

@@ -89,6 +89,7 @@ extern "C" int pm_linear_operator_vectors(pm_ctx *c, float *d_x, float f1, const
 }
 
 extern "C" int pm_periodic_wrap(pm_ctx *c, float *d_pos, int64_t count) {
+    if (c) c->lists_pos = nullptr;  // positions change: prepared tile lists (pm_tile_lists) are void
     PM_REQUIRE(c && d_pos && count >= 0, "bad argument");
     return ew_launch<OP_WRAP, true, false>(c, d_pos, nullptr, 0.f, 0.f, count);
 }
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(BLK) void kick_drift_wrap_kernel(float *__restrict_
 
 extern "C" int pm_kick_drift_wrap(pm_ctx *c, float *d_pos, float *d_vel, const float *d_acc, float half_dt, float dt,
                                   int64_t np) {
+    if (c) c->lists_pos = nullptr;  // positions change: prepared tile lists (pm_tile_lists) are void
     PM_REQUIRE(c && d_pos && d_vel && d_acc && np >= 0, "bad argument");
     if (np == 0) return PM_OK;
     // (the reference's a == +-1 special cases, utils.py:289-295, are arithmetically identical to y + a*x)
@@ -156,6 +158,7 @@ extern "C" int pm_kick_drift_wrap(pm_ctx *c, float *d_pos, float *d_vel, const f
 extern "C" int pm_kick_drift_wrap_slab(pm_ctx *c, float *d_pos, float *d_vel, const float *d_acc, float half_dt,
                                        float dt, int64_t np, float x_lo, float x_hi, int64_t *d_leave_idx, int cap,
                                        int *h_count) {
+    if (c) c->lists_pos = nullptr;  // positions change: prepared tile lists (pm_tile_lists) are void
     PM_REQUIRE(c && d_leave_idx && h_count && cap > 0 && np >= 0 && (np == 0 || (d_pos && d_vel && d_acc)),
                "bad argument");
     int *d_count = reinterpret_cast<int *>(c->d_scratch + 16);
@@ -224,35 +227,6 @@ extern "C" int pm_max_abs(pm_ctx *c, const float *d_x, int64_t count, float *h_o
 // loads, the z neighbours come from the three float4 at k-4, k, k+4 (periodic), and the AoS
 // [n,n,n,3] output is three contiguous float4 stores (48 B) per thread.  Consecutive threads walk k
 // then j, so every wave reads and writes whole 1-3 KiB segments.
-
-template <int FRN>
-__device__ __forceinline__ float fr_pow(float b) {
-    return FRN == 1 ? b * b : b * b * b;
-}
-
-template <int ORDER, int FRN>
-struct Stencil {
-    // value of the 1-D stencil given a[-3..3] (and b when FRN>0); operation order as the reference
-    static __device__ __forceinline__ float eval(const float *a, const float *b, float f, float scale) {
-        // a[3] is the centre
-        if (ORDER == 2) {
-            if (FRN == 0) return scale * (-a[3] + a[4]);
-            return scale * (-a[3] + a[4] + f * (-fr_pow<FRN>(b[3]) + fr_pow<FRN>(b[4])));
-        } else if (ORDER == 3) {
-            if (FRN == 0) return scale * (-a[2] + a[4]);
-            return scale * (-a[2] + a[4] + f * (-fr_pow<FRN>(b[2]) + fr_pow<FRN>(b[4])));
-        } else if (ORDER == 5) {
-            if (FRN == 0) return scale * (8.0f * (-a[2] + a[4]) + a[1] - a[5]);
-            return scale * (8.0f * (-a[2] + a[4] + f * (-fr_pow<FRN>(b[2]) + fr_pow<FRN>(b[4]))) + a[1] - a[5] +
-                            f * (fr_pow<FRN>(b[1]) - fr_pow<FRN>(b[5])));
-        } else {
-            if (FRN == 0) return scale * (45.0f * (-a[2] + a[4]) + 9.0f * (a[1] - a[5]) - a[0] + a[6]);
-            return scale * (45.0f * (-a[2] + a[4] + f * (-fr_pow<FRN>(b[2]) + fr_pow<FRN>(b[4]))) +
-                            9.0f * (+a[1] - a[5] + f * (fr_pow<FRN>(b[1]) - fr_pow<FRN>(b[5]))) - a[0] + a[6] +
-                            f * (-fr_pow<FRN>(b[0]) + fr_pow<FRN>(b[6])));
-        }
-    }
-};
 
 // Slab form: phi (and u) hold nxp planes starting at global plane x0p, the output holds nxf planes
 // starting at x0f; plane lookups go through the periodic origin (single GPU: nxp = nxf = n, 0, 0).

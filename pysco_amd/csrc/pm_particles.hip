@@ -647,13 +647,30 @@ struct TileWork {
     unsigned ntiles;
 };
 
+// Incoming stragglers per tile (pm_tile_lists): particles that the sorted order files under another
+// tile but that are inside this one now.  With `use` set, a workgroup skips the strangers it meets in
+// its own range (the tile they are in serves them from its list) and adds its own list to the range:
+// every particle goes through LDS and the global straggler paths below are never taken.
+struct TileLists {
+    const unsigned *idx;     // particle indices grouped by current tile
+    const unsigned *lstart;  // [ntiles + 1] offsets into idx
+    int use;
+};
+
 // work item of this workgroup: tile key and particle range [s, e); false if it has none
 __device__ __forceinline__ bool tile_work_item(const TileWork &w, unsigned &key, int64_t &s, int64_t &e) {
     const unsigned b = blockIdx.x;
     if (b < w.ntiles) {
+        // Workgroups go round-robin to the 8 XCDs (each with its own L2): deal every XCD runs of 64
+        // consecutive tiles (a 32x64x64-cell Morton block) so the tile halos it re-reads are its own L2 hits.
+        constexpr unsigned G = 512;
         key = b;
-        s = w.start[b];
-        e = min(w.start[b + 1], s + PM_RANGE_CHUNK);
+        if (b < (w.ntiles / G) * G) {
+            const unsigned r = b % G;
+            key = b - r + (r % 8) * (G / 8) + r / 8;
+        }
+        s = w.start[key];
+        e = min(w.start[key + 1], s + PM_RANGE_CHUNK);
     } else {
         const int64_t x = (int64_t)(b - w.ntiles);
         if (x >= w.xstart[w.ntiles]) return false;
@@ -715,6 +732,125 @@ static int tile_ranges(pm_ctx *c, const float *pos, int64_t np, TileWork *out, u
     return PM_OK;
 }
 
+// ---- pm_tile_lists: ranges + incoming-straggler lists, prepared once per set of positions ---------
+
+__global__ __launch_bounds__(BLK) void straggler_scan_kernel(const float *__restrict__ pos, TileWork work, int n,
+                                                             unsigned *__restrict__ keys, unsigned *__restrict__ idx,
+                                                             unsigned cap, unsigned *__restrict__ total) {
+    unsigned key;
+    int64_t s, e;
+    if (!tile_work_item(work, key, s, e)) return;
+    __shared__ unsigned s_k[PM_RANGE_CHUNK], s_p[PM_RANGE_CHUNK];  // 32 KB
+    __shared__ unsigned s_cnt, s_base;
+    const int tid = threadIdx.x;
+    const float nf = (float)n;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int64_t p = s + tid; p < e; p += BLK) {
+        const unsigned k = tile_key_of_pos(pos + 3 * p, nf, n);
+        if (k != key) {
+            const unsigned slot = atomicAdd(&s_cnt, 1u);
+            s_k[slot] = k, s_p[slot] = (unsigned)p;
+        }
+    }
+    __syncthreads();
+    const unsigned cnt = s_cnt;
+    if (cnt == 0) return;
+    if (tid == 0) s_base = atomicAdd(total, cnt);
+    __syncthreads();
+    const unsigned base = s_base;
+    for (unsigned i = tid; i < cnt; i += BLK)
+        if (base + i < cap) keys[base + i] = s_k[i], idx[base + i] = s_p[i];
+}
+
+__global__ __launch_bounds__(BLK) void list_bounds_kernel(const unsigned *__restrict__ keys, unsigned count,
+                                                          unsigned ntiles, unsigned *__restrict__ lstart) {
+    const unsigned t = blockIdx.x * BLK + threadIdx.x;
+    if (t > ntiles) return;
+    unsigned lo = 0, hi = count;  // first entry with key >= t
+    while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (keys[mid] < t)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    lstart[t] = lo;
+}
+
+static void tile_lists_drop(pm_ctx *c) { c->lists_pos = nullptr, c->lists_np = 0, c->lists_use = 0; }
+
+extern "C" int pm_tile_lists(pm_ctx *c, const float *d_pos, int64_t np) {
+    PM_REQUIRE(c && np >= 0, "bad argument");
+    tile_lists_drop(c);
+    if (!d_pos || np == 0 || c->n < 16) return PM_OK;
+    TileWork work;
+    unsigned blocks = 0;
+    int rc = tile_ranges(c, d_pos, np, &work, &blocks);
+    if (rc) return rc;
+    const unsigned ntiles = work.ntiles;
+    c->lists_ptr[0] = work.start, c->lists_ptr[1] = work.xstart, c->lists_ptr[2] = c->lists_ptr[3] = nullptr;
+    c->lists_blocks = blocks;
+    int use = 0;
+    if (np < 4294967296LL) {
+        // room for one straggler in eight particles; beyond that the stream is not worth calling sorted
+        const size_t cap = (size_t)(np / 8 + 1024);
+        const size_t off_l = ((cap * 4 * sizeof(unsigned)) + 255) & ~(size_t)255;
+        const size_t off_t = off_l + ((((size_t)ntiles + 1) * sizeof(unsigned) + 255) & ~(size_t)255);
+        size_t tmp_bytes = 0;
+        unsigned *nu = nullptr;
+        const int bits = 32 - __builtin_clz(ntiles > 1 ? ntiles - 1 : 1);
+        PM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, nu, nu, nu, nu, cap, 0, bits, c->stream));
+        const size_t need = off_t + tmp_bytes;
+        if (c->list_buf_bytes < need) {
+            if (c->list_buf) PM_HIP(hipFree(c->list_buf));
+            c->list_buf = nullptr, c->list_buf_bytes = 0;
+            PM_HIP(hipMalloc(&c->list_buf, need));
+            c->list_buf_bytes = need;
+        }
+        unsigned *k_in = (unsigned *)c->list_buf, *i_in = k_in + cap, *k_out = i_in + cap, *i_out = k_out + cap;
+        unsigned *lstart = (unsigned *)((char *)c->list_buf + off_l);
+        unsigned *total = c->d_scratch + 12;
+        PM_HIP(hipMemsetAsync(total, 0, sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(straggler_scan_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_pos, work, c->n, k_in, i_in,
+                           (unsigned)cap, total);
+        PM_LAUNCH_CHECK();
+        unsigned h_total = 0;
+        PM_HIP(hipMemcpyAsync(&h_total, total, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        PM_HIP(hipStreamSynchronize(c->stream));
+        if (h_total <= cap) {
+            const unsigned *keys = k_in, *idx = i_in;
+            if (h_total > 1) {
+                PM_HIP(rocprim::radix_sort_pairs((char *)c->list_buf + off_t, tmp_bytes, k_in, k_out, i_in, i_out,
+                                                 (size_t)h_total, 0, bits, c->stream));
+                keys = k_out, idx = i_out;
+            }
+            hipLaunchKernelGGL(list_bounds_kernel, dim3((ntiles + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys,
+                               h_total, ntiles, lstart);
+            PM_LAUNCH_CHECK();
+            c->lists_ptr[2] = idx, c->lists_ptr[3] = lstart;
+            use = 1;
+        }
+    }
+    c->lists_pos = d_pos, c->lists_np = np, c->lists_use = use;
+    return PM_OK;
+}
+
+// ranges (+ lists) for a tile-range launch: the prepared ones if they are for these positions
+static int tile_work_for(pm_ctx *c, const float *pos, int64_t np, TileWork *work, TileLists *lists, unsigned *blocks) {
+    if (c->lists_pos == pos && c->lists_np == np && pos) {
+        work->start = (const int64_t *)c->lists_ptr[0], work->xstart = (const int64_t *)c->lists_ptr[1];
+        work->ntiles = (unsigned)(((int64_t)c->n * c->n * c->n) >> (PM_LI + PM_LJ + PM_LK));
+        lists->idx = (const unsigned *)c->lists_ptr[2], lists->lstart = (const unsigned *)c->lists_ptr[3];
+        lists->use = c->lists_use;
+        *blocks = c->lists_blocks;
+        return PM_OK;
+    }
+    tile_lists_drop(c);  // tile_ranges reuses the table the prepared ranges live in
+    lists->idx = lists->lstart = nullptr, lists->use = 0;
+    return tile_ranges(c, pos, np, work, blocks);
+}
+
 // Rolling depth-4 prefetch of the positions a thread will process (p, p+BLK, p+2BLK, ...): the
 // particle loop stays rolled (register budget) while four loads per lane are always in flight.
 struct PosQueue {
@@ -740,29 +876,46 @@ struct PosQueue {
 
 template <int SCHEME>
 __global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__restrict__ pos, TileWork work,
-                                                             pm_geom geo, float *__restrict__ rho) {
+                                                             TileLists lists, pm_geom geo, float *__restrict__ rho) {
     unsigned key;
     int64_t s, e;
-    if (!tile_work_item(work, key, s, e)) return;
+    const bool has_range = tile_work_item(work, key, s, e);
+    unsigned ls = 0, le = 0;  // incoming stragglers (first workgroup of the tile only)
+    if (lists.use && blockIdx.x < work.ntiles) ls = lists.lstart[key], le = lists.lstart[key + 1];
+    if (!has_range && ls == le) return;
     __shared__ pm_acc_t tile[PM_TILE];  // 25.9 KB
     const int tid = threadIdx.x;
     const int n = geo.n;
     const float nf = (float)n;
     const TileId t = tile_of_key(key);
     PosQueue q;
-    q.prime(pos, s + tid, e);
+    if (has_range) q.prime(pos, s + tid, e);
     for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0;
     __syncthreads();
+    if (has_range) {
 #pragma unroll 1
-    for (int64_t p = s + tid; p < e; p += BLK) {
-        float x, y, z;
-        q.pop(p, x, y, z);
+        for (int64_t p = s + tid; p < e; p += BLK) {
+            float x, y, z;
+            q.pop(p, x, y, z);
+            const float xp = x * nf, yp = y * nf, zp = z * nf;
+            const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+            if (in_tile(i, j, k, t)) {
+                deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
+            } else if (!lists.use) {  // filed under another tile (drifted / unsorted) and nobody else serves it
+                deposit_global<SCHEME>(x, y, z, geo, rho);
+            }
+        }
+    }
+#pragma unroll 1
+    for (unsigned l = ls + tid; l < le; l += BLK) {
+        const int64_t p = lists.idx[l];
+        const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
         const float xp = x * nf, yp = y * nf, zp = z * nf;
         const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
         if (in_tile(i, j, k, t))
             deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
         else
-            deposit_global<SCHEME>(x, y, z, geo, rho);  // filed under another tile: drifted / unsorted
+            deposit_global<SCHEME>(x, y, z, geo, rho);
     }
     __syncthreads();
     for (int c = tid; c < PM_TILE; c += BLK) {
@@ -771,23 +924,114 @@ __global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__rest
     }
 }
 
-template <int SCHEME, bool KICK>
-__global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restrict__ grid,
-                                                            const float *__restrict__ pos, TileWork work, pm_geom geo,
-                                                            float *__restrict__ out, float *__restrict__ vel,
-                                                            float mhalf_dt, unsigned *__restrict__ maxbits) {
+// ------------------------------------------------------------------------------------------------
+// Gradient + gather + kick in one kernel (mesh.derivative + mesh.inv*_vec + the second kick): the
+// workgroup stages the POTENTIAL of its tile (force tile + stencil reach R on every side) in LDS,
+// differentiates it there with the reference's stencil (Stencil<ORDER,0>::eval, same bits as
+// pm_gradient), parks the three components in registers, and rewrites the same LDS as the float4
+// force tile the gather reads.  The [n,n,n,3] force grid (12.9 GB at 1024^3: one write, 1.6 reads
+// with halos) and the gradient pass never exist.
+
+template <int ORDER>
+struct GradReach {
+    static constexpr int R = (ORDER == 2 || ORDER == 3) ? 1 : (ORDER == 5 ? 2 : 3);
+};
+
+template <int ORDER>
+__device__ __forceinline__ float grad_scale(int n) {
+    return ORDER == 2 ? (float)n : (ORDER == 3 ? (float)(0.5 * n) : (ORDER == 5 ? (float)(n / 12.0) : (float)(n / 60.0)));
+}
+
+// force of one cell straight from the global potential (stragglers only)
+template <int ORDER>
+struct PhiFetch {
+    const float *phi;
+    pm_geom geo;
+    float scale;
+    __device__ __forceinline__ void operator()(int ii, int jj, int kk, float g[3]) const {
+        constexpr int R = GradReach<ORDER>::R;
+        float sa[7], sb[7];
+#pragma unroll
+        for (int o = 0; o < 7; ++o) sa[o] = sb[o] = 0.f;
+#pragma unroll
+        for (int o = -R; o <= R; ++o) sa[o + 3] = phi[pm_cell(geo, ii + o, jj, kk)];
+        g[0] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+#pragma unroll
+        for (int o = -R; o <= R; ++o) sa[o + 3] = phi[pm_cell(geo, ii, jj + o, kk)];
+        g[1] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+#pragma unroll
+        for (int o = -R; o <= R; ++o) sa[o + 3] = phi[pm_cell(geo, ii, jj, kk + o)];
+        g[2] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+    }
+};
+
+template <int SCHEME, int ORDER>
+__device__ __noinline__ void gather_phi_global(const float *__restrict__ phi, float scale, float xp, float yp, float zp,
+                                               int i, int j, int k, const pm_geom &geo, float acc[3]) {
+    PhiFetch<ORDER> fetch{phi, geo, scale};
+    acc[0] = acc[1] = acc[2] = 0.f;
+    float g[3];
+    if (SCHEME == PM_NGP) {
+        fetch(i, j, k, g);
+        acc[0] = g[0], acc[1] = g[1], acc[2] = g[2];
+    } else if (SCHEME == PM_CIC) {
+        float wx[2], wy[2], wz[2];
+        int sx, sy, sz;
+        cic_weights(xp, i, wx[0], wx[1], sx);
+        cic_weights(yp, j, wy[0], wy[1], sy);
+        cic_weights(zp, k, wz[0], wz[1], sz);
+#pragma unroll 1
+        for (int q = 0; q < 8; ++q) {
+            const int a = q >> 2, b = (q >> 1) & 1, c = q & 1;
+            const float w = (a ? wx[1] : wx[0]) * (b ? wy[1] : wy[0]) * (c ? wz[1] : wz[0]);
+            fetch(i + a * sx, j + b * sy, k + c * sz, g);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[m] = acc[m] + w * g[m];
+        }
+    } else {
+        float wx[3], wy[3], wz[3];
+        tsc_weights(xp, i, wx);
+        tsc_weights(yp, j, wy);
+        tsc_weights(zp, k, wz);
+#pragma unroll 1
+        for (int q = 0; q < 27; ++q) {
+            const int a = q / 9, b = (q / 3) % 3, c = q % 3;
+            const float wxa = a == 0 ? wx[0] : (a == 1 ? wx[1] : wx[2]);
+            const float wyb = b == 0 ? wy[0] : (b == 1 ? wy[1] : wy[2]);
+            const float wzc = c == 0 ? wz[0] : (c == 1 ? wz[1] : wz[2]);
+            const float w = (wxa * wyb) * wzc;
+            fetch(i + a - 1, j + b - 1, k + c - 1, g);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[m] = acc[m] + w * g[m];
+        }
+    }
+}
+
+// One workgroup per tile: gather + second kick + CFL maxima.  ORDER == 0: `src` is the [.,n,n,3] force
+// grid; ORDER in {2,3,5,7}: `src` is the potential and the force tile is differentiated in LDS.
+template <int SCHEME, int ORDER, bool KICK>
+__global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restrict__ src,
+                                                            const float *__restrict__ pos, TileWork work,
+                                                            TileLists lists, pm_geom geo, float *__restrict__ out,
+                                                            float *__restrict__ vel, float mhalf_dt,
+                                                            unsigned *__restrict__ maxbits) {
     unsigned key;
     int64_t s, e;
-    if (!tile_work_item(work, key, s, e)) return;
-    __shared__ float4 tile[PM_TILE];  // 51.8 KB
+    const bool has_range = tile_work_item(work, key, s, e);
+    unsigned ls = 0, le = 0;  // incoming stragglers (first workgroup of the tile only)
+    if (lists.use && blockIdx.x < work.ntiles) ls = lists.lstart[key], le = lists.lstart[key + 1];
+    if (!has_range && ls == le) return;
+    __shared__ float4 tile[PM_TILE];  // 51.8 KB (ORDER > 0: first the potential tile, as floats)
     __shared__ unsigned s_max[2][BLK / 64];
     const int tid = threadIdx.x;
     const int n = geo.n;
     const float nf = (float)n;
+    const float scale = grad_scale<ORDER>(n);
     const TileId t = tile_of_key(key);
     PosQueue q;
-    q.prime(pos, s + tid, e);
-    {   // tile fill, float-granular: consecutive lanes read consecutive floats of a tile row (18 cells x 3
+    if (has_range) q.prime(pos, s + tid, e);
+    if constexpr (ORDER == 0) {
+        // tile fill, float-granular: consecutive lanes read consecutive floats of a tile row (18 cells x 3
         // components = 216 contiguous bytes), so a wave load is a few full lines instead of 64 scattered
         // 12-byte pieces (PMC: the per-cell dwordx3 fill fetched 2.4x the tile bytes).  All loads are in
         // flight before the first LDS write.
@@ -799,7 +1043,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
             const int f = u * BLK + tid;
             if (f < NF) {
                 const int c = f / 3, m = f - 3 * c;
-                g[u] = grid[3 * tile_cell_global(c, t, geo) + m];
+                g[u] = src[3 * tile_cell_global(c, t, geo) + m];
             }
         }
 #pragma unroll
@@ -810,44 +1054,105 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                 tile_f[4 * c + m] = g[u];
             }
         }
+    } else {
+        constexpr int R = GradReach<ORDER>::R;
+        constexpr int DX = PM_HI + 2 * R, DY = PM_HJ + 2 * R, DZ = PM_HK + 2 * R;  // potential tile
+        constexpr int NPHI = DX * DY * DZ;                                        // 6776 (R=2), 9216 (R=3)
+        static_assert(NPHI * 4 <= PM_TILE * 16, "potential tile must fit in the force tile");
+        float *ptile = reinterpret_cast<float *>(tile);
+        {   // consecutive lanes read consecutive z (rows of DZ floats); all loads in flight first
+            constexpr int NQ = (NPHI + BLK - 1) / BLK;
+            const int gi0 = t.ti * PM_TI - 1 - R, gj0 = t.tj * PM_TJ - 1 - R, gk0 = t.tk * PM_TK - 1 - R;
+            float g[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int f = u * BLK + tid;
+                if (f < NPHI) {
+                    const int c = f % DZ, ab = f / DZ;
+                    g[u] = src[pm_cell(geo, gi0 + ab / DY, gj0 + ab % DY, gk0 + c)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int f = u * BLK + tid;
+                if (f < NPHI) ptile[f] = g[u];
+            }
+        }
+        __syncthreads();
+        // differentiate: thread owns force-tile cells tid, tid + BLK, ...
+        constexpr int NC = (PM_TILE + BLK - 1) / BLK;  // 13
+        float gx[NC], gy[NC], gz[NC];
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const int c = u * BLK + tid;
+            if (c < PM_TILE) {
+                const int lk = c % PM_HK, lij = c / PM_HK;
+                const int lj = lij % PM_HJ, li = lij / PM_HJ;
+                const float *ctr = ptile + ((li + R) * DY + (lj + R)) * DZ + (lk + R);
+                float sa[7], sb[7];
+#pragma unroll
+                for (int o = 0; o < 7; ++o) sa[o] = sb[o] = 0.f;
+#pragma unroll
+                for (int o = -R; o <= R; ++o) sa[o + 3] = ctr[o * DY * DZ];
+                gx[u] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+#pragma unroll
+                for (int o = -R; o <= R; ++o) sa[o + 3] = ctr[o * DZ];
+                gy[u] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+#pragma unroll
+                for (int o = -R; o <= R; ++o) sa[o + 3] = ctr[o];
+                gz[u] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+            }
+        }
+        __syncthreads();  // every stencil has read its potential: the buffer becomes the force tile
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const int c = u * BLK + tid;
+            if (c < PM_TILE) tile[c] = make_float4(gx[u], gy[u], gz[u], 0.f);
+        }
     }
     __syncthreads();
-#pragma unroll 1
-    for (int64_t p = s + tid; p < e; p += BLK) {
-        float x, y, z;
-        q.pop(p, x, y, z);
+    // gather, second kick (utils.py:297, y += a*x) and the CFL maxima in one pass: the acceleration never
+    // leaves its registers (PMC: re-reading it in a separate coalesced pass cost a further 12.9 GB of fetch)
+    unsigned ma = 0, mv = 0;  // bit patterns of max|a|, max|v| (integer order == float order, NaN on top)
+    auto serve = [&](int64_t p, float x, float y, float z, bool own_range) {
         const float xp = x * nf, yp = y * nf, zp = z * nf;
         const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+        const bool inside = in_tile(i, j, k, t);
+        if (!inside && own_range && lists.use) return;  // the tile it is in now serves it from its list
+        float v[3] = {0.f, 0.f, 0.f};
+        if (KICK) v[0] = vel[3 * p], v[1] = vel[3 * p + 1], v[2] = vel[3 * p + 2];
         float a[3];
-        if (in_tile(i, j, k, t))
+        if (inside) {
             gather_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile, a);
-        else
-            gather_global<SCHEME>(grid, xp, yp, zp, i, j, k, geo, a);
-        out[3 * p] = a[0], out[3 * p + 1] = a[1], out[3 * p + 2] = a[2];
-    }
-    __syncthreads();  // the range's accelerations are visible to the whole workgroup (same CU)
-
-    // kick + maxima over the contiguous float range [3s, 3e): coalesced dword streams, 4 in flight
-    unsigned ma = 0, mv = 0;  // bit patterns of max|a|, max|v| (integer order == float order, NaN on top)
-    const int64_t f0 = 3 * s, f1 = 3 * e;
-    for (int64_t i = f0 + tid; i < f1; i += 4 * BLK) {
-        float a[4], v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t ii = i + u * BLK;
-            a[u] = ii < f1 ? out[ii] : 0.f;
-            v[u] = (KICK && ii < f1) ? vel[ii] : 0.f;
+        } else {  // no lists prepared (or positions changed behind them): the slow path, still correct
+            if constexpr (ORDER == 0)
+                gather_global<SCHEME>(src, xp, yp, zp, i, j, k, geo, a);
+            else
+                gather_phi_global<SCHEME, ORDER>(src, scale, xp, yp, zp, i, j, k, geo, a);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t ii = i + u * BLK;
-            ma = max(ma, __float_as_uint(a[u]) & 0x7fffffffu);
-            if (KICK && ii < f1) {
-                const float w = v[u] + mhalf_dt * a[u];  // y += a*x (utils.py:297)
-                vel[ii] = w;
+        for (int m = 0; m < 3; ++m) {
+            out[3 * p + m] = a[m];
+            ma = max(ma, __float_as_uint(a[m]) & 0x7fffffffu);
+            if (KICK) {
+                const float w = v[m] + mhalf_dt * a[m];
+                vel[3 * p + m] = w;
                 mv = max(mv, __float_as_uint(w) & 0x7fffffffu);
             }
         }
+    };
+    if (has_range) {
+#pragma unroll 1
+        for (int64_t p = s + tid; p < e; p += BLK) {
+            float x, y, z;
+            q.pop(p, x, y, z);
+            serve(p, x, y, z, true);
+        }
+    }
+#pragma unroll 1
+    for (unsigned l = ls + tid; l < le; l += BLK) {
+        const int64_t p = lists.idx[l];
+        serve(p, pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], false);
     }
     for (int off = 32; off > 0; off >>= 1) {
         ma = max(ma, (unsigned)__shfl_down((int)ma, off, 64));
@@ -870,10 +1175,11 @@ static int deposit_launch(pm_ctx *c, const float *pos, int64_t np, float *rho, i
     const int n = c->n;
     if (sorted_hint == 1 && n >= 16) {  // one workgroup per tile (Morton-sorted streams)
         TileWork work;
+        TileLists lists;
         unsigned blocks = 0;
-        int rc = tile_ranges(c, pos, np, &work, &blocks);
+        int rc = tile_work_for(c, pos, np, &work, &lists, &blocks);
         if (rc) return rc;
-        hipLaunchKernelGGL((deposit_ranges_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, work,
+        hipLaunchKernelGGL((deposit_ranges_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, work, lists,
                            pm_ctx_geom(c), rho);
     } else if (sorted_hint && n >= 16) {
         const int64_t blocks = (np + PM_CHUNK - 1) / PM_CHUNK;
@@ -910,15 +1216,16 @@ static int interp_kick_launch(pm_ctx *c, const float *grid, const float *pos, in
     unsigned *mb = c->d_scratch + 8;
     if (c->gather_mode == 1) {  // one workgroup per tile
         TileWork work;
+        TileLists lists;
         unsigned nblk = 0;
-        int rc = tile_ranges(c, pos, np, &work, &nblk);
+        int rc = tile_work_for(c, pos, np, &work, &lists, &nblk);
         if (rc) return rc;
         if (vel)
-            hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, true>), dim3(nblk), dim3(BLK), 0, c->stream, grid, pos,
-                               work, pm_ctx_geom(c), out, vel, -half_dt, mb);
+            hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, 0, true>), dim3(nblk), dim3(BLK), 0, c->stream, grid, pos,
+                               work, lists, pm_ctx_geom(c), out, vel, -half_dt, mb);
         else
-            hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, false>), dim3(nblk), dim3(BLK), 0, c->stream, grid, pos,
-                               work, pm_ctx_geom(c), out, vel, 0.f, mb);
+            hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, 0, false>), dim3(nblk), dim3(BLK), 0, c->stream, grid, pos,
+                               work, lists, pm_ctx_geom(c), out, vel, 0.f, mb);
         PM_LAUNCH_CHECK();
         return PM_OK;
     }
@@ -943,6 +1250,57 @@ extern "C" int pm_interp_kick(pm_ctx *c, int scheme, const float *d_force, const
         case PM_NGP: return interp_kick_launch<PM_NGP>(c, d_force, d_pos, np, d_acc, d_vel, half_dt);
         case PM_CIC: return interp_kick_launch<PM_CIC>(c, d_force, d_pos, np, d_acc, d_vel, half_dt);
         case PM_TSC: return interp_kick_launch<PM_TSC>(c, d_force, d_pos, np, d_acc, d_vel, half_dt);
+    }
+    pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme);
+    return PM_EINVAL;
+}
+
+template <int SCHEME, int ORDER>
+static int grad_interp_kick_launch(pm_ctx *c, const float *phi, pm_geom geo, const float *pos, int64_t np, float *out,
+                                   float *vel, float half_dt) {
+    unsigned *mb = c->d_scratch + 8;
+    TileWork work;
+    TileLists lists;
+    unsigned nblk = 0;
+    int rc = tile_work_for(c, pos, np, &work, &lists, &nblk);
+    if (rc) return rc;
+    if (vel)
+        hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, ORDER, true>), dim3(nblk), dim3(BLK), 0, c->stream, phi, pos,
+                           work, lists, geo, out, vel, -half_dt, mb);
+    else
+        hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, ORDER, false>), dim3(nblk), dim3(BLK), 0, c->stream, phi, pos,
+                           work, lists, geo, out, vel, 0.f, mb);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+template <int SCHEME>
+static int grad_interp_kick_order(pm_ctx *c, int order, const float *phi, pm_geom geo, const float *pos, int64_t np,
+                                  float *out, float *vel, float half_dt) {
+    switch (order) {
+        case 2: return grad_interp_kick_launch<SCHEME, 2>(c, phi, geo, pos, np, out, vel, half_dt);
+        case 3: return grad_interp_kick_launch<SCHEME, 3>(c, phi, geo, pos, np, out, vel, half_dt);
+        case 5: return grad_interp_kick_launch<SCHEME, 5>(c, phi, geo, pos, np, out, vel, half_dt);
+        case 7: return grad_interp_kick_launch<SCHEME, 7>(c, phi, geo, pos, np, out, vel, half_dt);
+    }
+    pm_set_error("gradient order %d, should be 2, 3, 5 or 7", order);
+    return PM_EINVAL;
+}
+
+extern "C" int pm_gradient_interp_kick(pm_ctx *c, int order, int scheme, const float *d_phi, int nx_phi, int x0_phi,
+                                       const float *d_pos, int64_t np, float *d_acc, float *d_vel, float half_dt) {
+    PM_REQUIRE(c && d_phi && np >= 0 && ((d_pos && d_acc) || np == 0), "bad argument");
+    PM_REQUIRE(c->n >= 16, "pm_gradient_interp_kick needs n >= 16 (use pm_gradient + pm_interp below that)");
+    PM_REQUIRE(nx_phi >= 1 && nx_phi <= c->n, "bad potential slab");
+    PM_REQUIRE((np + PM_CHUNK - 1) / PM_CHUNK < 2147483647LL, "too many particles for one launch");
+    PM_HIP(hipMemsetAsync(c->d_scratch + 8, 0, 2 * sizeof(unsigned), c->stream));
+    if (np == 0) return PM_OK;
+    pm_geom geo = pm_ctx_geom(c);  // tiles are filed on the full mesh; phi is the (slab + ghosts) array given
+    geo.nx = nx_phi, geo.x0 = ((x0_phi % c->n) + c->n) % c->n;
+    switch (scheme) {
+        case PM_NGP: return grad_interp_kick_order<PM_NGP>(c, order, d_phi, geo, d_pos, np, d_acc, d_vel, half_dt);
+        case PM_CIC: return grad_interp_kick_order<PM_CIC>(c, order, d_phi, geo, d_pos, np, d_acc, d_vel, half_dt);
+        case PM_TSC: return grad_interp_kick_order<PM_TSC>(c, order, d_phi, geo, d_pos, np, d_acc, d_vel, half_dt);
     }
     pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme);
     return PM_EINVAL;

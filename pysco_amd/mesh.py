@@ -79,6 +79,27 @@ def interp_vec_kick(scheme_name: str, grid, position, velocity, half_dt):
     return out
 
 
+def derivative_interp_vec_kick(scheme_name: str, potential, order: int, position, velocity=None, half_dt=0.0,
+                               nx_phi=None, x0_phi=0):
+    """mesh.derivative (mesh.py:2072) + inv*_vec (+ the second kick when `velocity` is given) in one
+    kernel, without materialising the force grid; bit-identical to derivative() followed by
+    interp_vec_kick().  `potential` may be a slab [nx_phi, n, n] starting at global plane x0_phi."""
+    from . import utils
+
+    torch = L.require_gpu()
+    n = potential.shape[1]
+    scheme = {"cic": L.CIC, "tsc": L.TSC, "ngp": L.NGP}[scheme_name]
+    if order not in (2, 3, 5, 7):
+        raise ValueError(f"{order=}, should be 2, 3, 5 or 7")
+    ctx = L.context(n)
+    out = torch.empty_like(position)
+    ctx.call("pm_gradient_interp_kick", int(order), scheme, L.ptr(potential),
+             int(potential.shape[0] if nx_phi is None else nx_phi), int(x0_phi), L.ptr(position), position.shape[0],
+             L.ptr(out), None if velocity is None else L.ptr(velocity), float(np.float32(half_dt)))
+    utils.register_fused_maxabs(ctx, out, velocity)
+    return out
+
+
 def invNGP(grid, position):  # reference mesh.py:2600
     return _interp(L.NGP, 1, grid, position)
 

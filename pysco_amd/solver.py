@@ -17,6 +17,7 @@ from . import fourier, iostream, mesh, utils
 
 _C_LIGHT = 299792458.0  # astropy.constants.c (solver.py:14)
 _WRITE_PK = True       # the slab layer lets only rank 0 write the P(k) file
+_FUSE_GRADIENT = True  # tests flip this to compare with the unfused derivative + interpolation
 _USE_FUSED_FFT = True  # False: rocFFT r2c -> Green's function -> c2r (always used when P(k) is written)
 
 
@@ -51,32 +52,44 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     THEORY = param["theory"].casefold()
     pos_d = _dev(position)
 
-    if MASS_SCHEME == "cic":
-        param["MAS_index"] = 2
-        density = mesh.CIC(pos_d, ncells_1d)
-    elif MASS_SCHEME == "tsc":
-        param["MAS_index"] = 3
-        density = mesh.TSC(pos_d, ncells_1d)  # TSC == TSC_seq here (solver.py:86-89)
-    else:
+    if MASS_SCHEME not in ("cic", "tsc"):
         raise NotImplementedError(f"{param['mass_scheme']=}, should be 'CIC' or 'TSC'")
+    param["MAS_index"] = 2 if MASS_SCHEME == "cic" else 3
+    ctx = L.context(ncells_1d)
+    # tile ranges + straggler lists once for the deposit and the gather of these positions (pmstep.h)
+    ctx.call("pm_tile_lists", L.ptr(pos_d), pos_d.shape[0])
+    try:
+        # TSC == TSC_seq here (solver.py:86-89)
+        density = mesh.CIC(pos_d, ncells_1d) if MASS_SCHEME == "cic" else mesh.TSC(pos_d, ncells_1d)
 
-    potential_d, additional_field_d, force = _solve_grid(density, param, _dev(potential), _dev(additional_field),
-                                                         tables)
-    del density
+        # Without an f(R) term the force grid is only ever read by the gather: the gather kernel then takes
+        # the potential and differentiates its own LDS tile (mesh.derivative_interp_vec_kick), and the
+        # [n,n,n,3] array is never built.
+        fuse_gradient = _FUSE_GRADIENT and ncells_1d >= 16 and THEORY != "fr"
+        potential_d, additional_field_d, force = _solve_grid(density, param, _dev(potential),
+                                                             _dev(additional_field), tables,
+                                                             want_force=not fuse_gradient)
+        del density
 
-    if _kick is not None and ncells_1d >= 16:
-        acceleration = mesh.interp_vec_kick(MASS_SCHEME, force, pos_d, _kick[0], _kick[1])
-    else:
-        acceleration = mesh.invCIC_vec(force, pos_d) if MASS_SCHEME == "cic" else mesh.invTSC_vec(force, pos_d)
-        if _kick is not None:
-            utils.add_vector_scalar_inplace(_kick[0], acceleration, -_kick[1])
-    del force
+        if fuse_gradient:
+            vel, half_dt = (None, 0.0) if _kick is None else _kick
+            acceleration = mesh.derivative_interp_vec_kick(MASS_SCHEME, potential_d,
+                                                           param["gradient_stencil_order"], pos_d, vel, half_dt)
+        elif _kick is not None and ncells_1d >= 16:
+            acceleration = mesh.interp_vec_kick(MASS_SCHEME, force, pos_d, _kick[0], _kick[1])
+        else:
+            acceleration = mesh.invCIC_vec(force, pos_d) if MASS_SCHEME == "cic" else mesh.invTSC_vec(force, pos_d)
+            if _kick is not None:
+                utils.add_vector_scalar_inplace(_kick[0], acceleration, -_kick[1])
+        del force
+    finally:
+        ctx.call("pm_tile_lists", None, 0)
     if L.is_device_array(position):
         return acceleration, potential_d, additional_field_d
     return acceleration.cpu().numpy(), potential_d.cpu().numpy(), additional_field_d.cpu().numpy()
 
 
-def _solve_grid(density, param, potential_d, additional_field_d, tables):
+def _solve_grid(density, param, potential_d, additional_field_d, tables, want_force=True):
     """Everything of pm() between the deposit and the interpolation, on a full [n,n,n] density grid:
     normalisation, [P(k)], extra field, rhs, Poisson solve, force.  Returns (potential, additional_field,
     force[n,n,n,3]).  Shared by the single-GPU pm() and the replicated grid solve of the slab layer
@@ -156,8 +169,12 @@ def _solve_grid(density, param, potential_d, additional_field_d, tables):
         half_c2 = fr_half_c2(param)
         force = mesh.derivative_fR(potential_d, additional_field_d, half_c2, param["fR_n"],
                                    param["gradient_stencil_order"])
-    else:
+    elif want_force:
         force = mesh.derivative(potential_d, param["gradient_stencil_order"])
+    else:
+        if param["gradient_stencil_order"] not in (2, 3, 5, 7):  # same error as mesh.derivative
+            raise ValueError(f"gradient_order={param['gradient_stencil_order']}, should be 2, 3, 5 or 7")
+        force = None
 
     return potential_d, additional_field_d, force
 

@@ -125,6 +125,84 @@ def test_gradient_bit_exact(amd, golden):
         amd.mesh.derivative_fR(a, b, f, 3, 5)
 
 
+@pytest.mark.parametrize("n", [16, 32, 64])
+def test_fused_gradient_gather_kick_bit_exact(amd, n):
+    """pm_gradient_interp_kick (potential tile differentiated in LDS) == oracle derivative + inv*_vec, for every
+    stencil order and scheme; sorted stream (LDS path), shuffled stream (global straggler path), and a
+    potential handed over as an x-slab with ghost planes."""
+    rng = np.random.default_rng(100 + n)
+    phi = rng.normal(size=(n, n, n)).astype(np.float32)
+    pos, _ = zeldovich_particles(n, seed=3, rms_cells=1.2)
+    pos_sorted = amd.utils.reorder_particles(pos)
+    pos_shuf = pos[rng.permutation(len(pos))]
+    t = amd.torch
+    phi_d = t.from_numpy(phi).cuda()
+    inv = {"tsc": orc.invTSC_vec, "cic": orc.invCIC_vec, "ngp": orc.invNGP_vec}
+    for order in (2, 3, 5, 7):
+        F = orc.derivative(phi, order)
+        for scheme in ("tsc", "cic", "ngp"):
+            for p in (pos_sorted, pos_shuf):
+                ref = inv[scheme](F, p)
+                pd = t.from_numpy(p).cuda()
+                vel = t.ones_like(pd)
+                acc = amd.mesh.derivative_interp_vec_kick(scheme, phi_d, order, pd, vel, np.float32(0.25))
+                np.testing.assert_array_equal(acc.cpu().numpy(), ref)
+                np.testing.assert_array_equal(vel.cpu().numpy(), np.float32(1) + np.float32(-0.25) * ref)
+                assert amd.utils.max_abs(acc) == np.abs(ref).max()
+    # slab form: planes [x0 - g, x0 + nx + g) of phi, particles inside [x0, x0 + nx)
+    order, g, nx, x0 = 5, 3, n // 2, n // 4 * 3
+    planes = (np.arange(x0 - g, x0 + nx + g)) % n
+    slab = t.from_numpy(np.ascontiguousarray(phi[planes])).cuda()
+    cell_x = np.floor(pos_sorted[:, 0] * n).astype(np.int64) % n
+    own = ((cell_x - x0) % n) < nx
+    p_own = np.ascontiguousarray(pos_sorted[own])
+    acc = amd.mesh.derivative_interp_vec_kick("tsc", slab, order, t.from_numpy(p_own).cuda(), None, 0.0,
+                                              nx_phi=nx + 2 * g, x0_phi=x0 - g)
+    np.testing.assert_array_equal(acc.cpu().numpy(), orc.invTSC_vec(orc.derivative(phi, order), p_own))
+
+
+@pytest.mark.parametrize("drift_cells", [0.3, 3.0])
+def test_drifted_sorted_stream_stragglers(amd, drift_cells):
+    """A stream sorted once and then drifted (what integrate() produces between re-orderings): a few per
+    cent (0.3 cell) or most (3 cells) of the particles are filed under a tile they have left: served in
+    place from global memory, or -- with pm_tile_lists -- by the tile they are in now from LDS.  Gather is
+    bit-exact, deposit within the atomics tolerance."""
+    n = 64
+    rng = np.random.default_rng(5)
+    pos, _ = zeldovich_particles(n, seed=11, rms_cells=1.0)
+    pos = amd.utils.reorder_particles(pos)
+    pos = np.mod(pos + (drift_cells / n) * rng.normal(size=pos.shape), 1.0).astype(np.float32)
+    pos[pos >= 1.0] = 0.0
+    phi = rng.normal(size=(n, n, n)).astype(np.float32)
+    F = orc.derivative(phi, 5)
+    t = amd.torch
+    pd = t.from_numpy(pos).cuda()
+    from pysco_amd import _lib as L
+
+    ctx = L.context(n)
+    for scheme, dep, odep, oinv, lists in (("tsc", amd.mesh.TSC, orc.TSC, orc.invTSC_vec, False),
+                                           ("cic", amd.mesh.CIC, orc.CIC, orc.invCIC_vec, False),
+                                           ("tsc", amd.mesh.TSC, orc.TSC, orc.invTSC_vec, True),
+                                           ("cic", amd.mesh.CIC, orc.CIC, orc.invCIC_vec, True)):
+        # lists=True: stragglers pre-grouped by pm_tile_lists (what solver.pm does), every particle via LDS;
+        # at 3 cells of drift the list overflows its np/8 capacity and the kernels fall back by themselves
+        ctx.call("pm_tile_lists", L.ptr(pd) if lists else None, pd.shape[0] if lists else 0)
+        ref = odep(pos, n)
+        rho = dep(pd, n).cpu().numpy()
+        np.testing.assert_allclose(rho, ref, rtol=0, atol=4e-6 * _scale(ref))
+        a_ref = oinv(F, pos)
+        vel = t.zeros_like(pd)
+        acc = amd.mesh.derivative_interp_vec_kick(scheme, t.from_numpy(phi).cuda(), 5, pd, vel, np.float32(2))
+        np.testing.assert_array_equal(acc.cpu().numpy(), a_ref)
+        np.testing.assert_array_equal(vel.cpu().numpy(), np.float32(-2) * a_ref)
+        vel = t.zeros_like(pd)
+        acc = amd.mesh.interp_vec_kick(scheme, t.from_numpy(F).cuda(), pd, vel, np.float32(2))
+        np.testing.assert_array_equal(acc.cpu().numpy(), a_ref)
+        np.testing.assert_array_equal(vel.cpu().numpy(), np.float32(-2) * a_ref)
+        assert amd.utils.max_abs(acc) == np.abs(a_ref).max()
+    ctx.call("pm_tile_lists", None, 0)
+
+
 @pytest.mark.parametrize("n", [64, 128])
 def test_gradient_marching_kernel_bit_exact(amd, n):
     """n >= 128 takes the marching (2.5-D) gradient kernel: same bits as the oracle for every order."""

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--ncells", type=int, default=512)
     ap.add_argument("--rms-cells", type=float, default=0.5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--drift-cells", type=float, default=0.0, help="rms displacement applied AFTER the sort")
     args = ap.parse_args()
     import torch
 
@@ -42,6 +43,16 @@ def main():
     utils.periodic_wrap(pos)
     pos, vel = utils.reorder_particles(pos, vel)
     npart = n**3
+    if args.drift_cells > 0:
+        pos += (args.drift_cells / n) * torch.randn_like(pos)
+        utils.periodic_wrap(pos)
+        c = (pos * n).to(torch.int32).clamp_(0, n - 1)
+        tile = (c[:, 0] >> 3) * (n >> 4) ** 2 + (c[:, 1] >> 4) * (n >> 4) + (c[:, 2] >> 4)
+        del c
+        frac = float((tile[1:] != tile[:-1]).float().mean())
+        del tile
+        print(f"drift {args.drift_cells} cells: {frac:.4f} of consecutive particles change tile "
+              f"(sorted stream: {1.0 / 2048 * (n**3 / npart):.4f})")
     only = set(args.only.split(",")) if args.only else None
     ctx = L.context(n)
     rho = torch.empty((n, n, n), dtype=torch.float32, device="cuda")
@@ -77,6 +88,13 @@ def main():
         ctx.call("pm_set_gather_mode", 1)
         t = timeit(lambda: ctx.call("pm_interp_kick", 3, L.ptr(F), L.ptr(pos), npart, L.ptr(acc), None, 0.0))
         rows.append(("interp_kick TSC (tiled, no kick)", t, (24 * npart + 12 * n**3) / t / 1e6))
+    if want("fusedgather"):
+        phi = torch.randn((n, n, n), dtype=torch.float32, device="cuda")
+        for order in (3, 5, 7):
+            t = timeit(lambda: ctx.call("pm_gradient_interp_kick", order, 3, L.ptr(phi), n, 0, L.ptr(pos), npart,
+                                        L.ptr(acc), L.ptr(vel), 1e-9))
+            rows.append((f"gradient+interp_kick TSC order {order}", t, (48 * npart + 4 * n**3) / t / 1e6))
+        del phi
     if want("gradient"):
         phi = torch.randn((n, n, n), dtype=torch.float32, device="cuda")
         for order in (2, 3, 5, 7):
