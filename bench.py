@@ -93,6 +93,7 @@ def alg_bytes(n, npart):
     return {
         "pm_kick_drift_wrap": 60.0 * npart,          # read x,v,a; write x,v
         "pm_deposit": 12.0 * npart + 4.0 * cells,    # read x; write rho
+        "pm_kick_drift_wrap_deposit": 60.0 * npart + 4.0 * cells,  # the two above in one kernel (x read once)
         "pm_linear_operator": 8.0 * cells,           # rhs scaling (fused into the FFT in the ideal count)
         "pm_fft_r2c": 24.0 * cells,                  # 3 axis passes, read+write
         "pm_greens": 2.0 * spec,                     # read+write half spectrum (0 in the fused ideal)
@@ -206,6 +207,7 @@ def main():
     ab = alg_bytes(n, npart / world)
     for k in ab:  # per-rank share of the grid stages in slab mode
         if k not in ("pm_kick_drift_wrap", "pm_deposit", "pm_interp", "pm_interp_kick", "pm_gradient_interp_kick",
+                     "pm_kick_drift_wrap_deposit",
                      "pm_axpy", "pm_max_abs"):
             ab[k] /= world
     if world > 1:

@@ -135,6 +135,15 @@ int pm_interp_kick(pm_ctx *ctx, int scheme, const float *d_force, const float *d
  * that writes positions, and must be dropped by the caller before d_pos is modified otherwise.  Results
  * are identical with and without (gather: same bits; deposit: same sums up to atomic ordering). */
 int pm_tile_lists(pm_ctx *ctx, const float *d_pos, int64_t np);
+/* pm_kick_drift_wrap (integration.py:250-258) + pm_deposit (mesh.py:2240/2284/2468) in one kernel, for a
+ * stream that is (approximately) Morton-sorted: the update streams through HBM while the LDS does the
+ * deposit, and the positions are read once.  d_pos / d_vel are updated in place exactly as by
+ * pm_kick_drift_wrap; d_rho receives the density of the NEW positions (same sums as pm_deposit up to
+ * atomic ordering).  The tile ranges (of the positions before the drift) and the list of particles that
+ * ended up outside the tile they are filed under stay prepared: a following pm_tile_lists(ctx, d_pos, np)
+ * keeps them, so the gather of the same step reuses them.  Single-GPU layout, n >= 16, np < 2^32. */
+int pm_kick_drift_wrap_deposit(pm_ctx *ctx, int scheme, float *d_pos, float *d_vel, const float *d_acc,
+                               float half_dt, float dt, int64_t np, float *d_rho);
 /* mesh.derivative (mesh.py:2072, orders 2/3/5/7) + pm_interp_kick in one kernel: every workgroup stages the
  * potential of its tile in LDS, differentiates it there with the reference's stencil and gathers from the
  * result, so the [n,n,n,3] force grid is never written or read.  Same bits as pm_gradient followed by

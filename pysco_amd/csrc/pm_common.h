@@ -64,6 +64,22 @@ __device__ __forceinline__ int64_t pm_cell(const pm_geom &g, int gi, int gj, int
     return ((((int64_t)li << g.log2n) + (gj & g.mask)) << g.log2n) + (gk & g.mask);
 }
 
+// utils.periodic_wrap (utils.py:1120-1149); eps = -(2^-25)*(1+1e-6) as a double
+__device__ __forceinline__ float pm_wrap01(float y) {
+    const double eps = -(1.0 / 33554432.0) * (1.0 + 1e-6);
+    if (y < 0.0f) return ((double)y > eps) ? 0.0f : y + 1.0f;
+    if (y >= 1.0f) return y - 1.0f;
+    return y;
+}
+
+// leapfrog first half for one coordinate (integration.py:250-258): v += -half_dt*a; x += dt*v; wrap(x)
+// (the reference's a == +-1 special cases of y += a*x, utils.py:289-295, are kept for the drift)
+__device__ __forceinline__ void pm_kick_drift_wrap_one(float &x, float &v, float a, float mhalf_dt, float dt) {
+    v = v + mhalf_dt * a;
+    x = (dt == 1.0f) ? x + v : ((dt == -1.0f) ? x - v : x + dt * v);
+    x = pm_wrap01(x);
+}
+
 // 1-D gradient stencils of mesh.py:639-850 (and the f(R) fused variants :860-2069), shared by the grid
 // gradient kernels (pm_grid.hip) and the gather that differentiates its own phi tile (pm_particles.hip)
 template <int FRN>
@@ -129,6 +145,7 @@ struct pm_ctx {
     int64_t lists_np;
     unsigned lists_blocks;
     int lists_use;       // 1: every straggler is in the per-tile incoming lists
+    int lists_sticky;    // prepared by pm_kick_drift_wrap_deposit: the next pm_tile_lists on them keeps them
     const void *lists_ptr[4];  // start, xstart (tile_tmp); idx, lstart (list_buf)
     void *list_buf;      // keys/indices (in, out), per-tile list offsets, sort scratch
     size_t list_buf_bytes;

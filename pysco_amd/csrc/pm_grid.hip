@@ -18,12 +18,7 @@ __device__ __forceinline__ float ew_apply(float y, float x, float a, float b) {
     if (OP == OP_SCALE) return y * a;             // y *= a
     if (OP == OP_LINOP) return a * x + b;         // out = f1*x + f2
     if (OP == OP_LINOPV) return a * y + b * x;    // x = f1*x + f2*y   (y arg = mutable, x arg = other)
-    if (OP == OP_WRAP) {                          // periodic_wrap; eps = -(2^-25)*(1+1e-6) as a double
-        const double eps = -(1.0 / 33554432.0) * (1.0 + 1e-6);
-        if (y < 0.0f) return ((double)y > eps) ? 0.0f : y + 1.0f;
-        if (y >= 1.0f) return y - 1.0f;
-        return y;
-    }
+    if (OP == OP_WRAP) return pm_wrap01(y);       // periodic_wrap
     return y;
 }
 
@@ -107,9 +102,7 @@ __global__ __launch_bounds__(BLK) void kick_drift_wrap_kernel(float *__restrict_
     const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * BLK;
     auto one = [&](float &x, float &v, float a, int64_t flat) {
-        v = ew_apply<OP_AXPY>(v, a, mhalf_dt, 0.f);
-        x = (dt == 1.0f) ? x + v : ((dt == -1.0f) ? x - v : x + dt * v);
-        x = ew_apply<OP_WRAP>(x, 0.f, 0.f, 0.f);
+        pm_kick_drift_wrap_one(x, v, a, mhalf_dt, dt);
         if (DETECT && (flat % 3) == 0 && (x < x_lo || x >= x_hi)) {
             const int slot = atomicAdd(leave_count, 1);
             if (slot < cap) leave_idx[slot] = flat / 3;

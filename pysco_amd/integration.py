@@ -57,15 +57,31 @@ def euler(position, velocity, acceleration, potential, additional_field, dt, tab
     return position, velocity, acceleration, potential, additional_field
 
 
+_FUSE_DEPOSIT = True  # tests flip this to compare with the separate kick-drift-wrap and deposit
+
+
 def leapfrog(position, velocity, acceleration, potential, additional_field, dt, tables, param):
     """Kick-drift-kick (integration.py:192-264).  On device tensors the first kick, the drift and
     the periodic wrap are one fused pass over the particle arrays."""
     half_dt = np.float32(0.5 * dt)
     fused = L.is_device_array(position) and L.is_device_array(velocity) and L.is_device_array(acceleration)
+    density = None
     if fused:
-        ctx = L.context(4)
-        ctx.call("pm_kick_drift_wrap", L.ptr(position), L.ptr(velocity), L.ptr(acceleration),
-                                           float(half_dt), float(np.float32(dt)), position.shape[0])
+        from . import slab
+
+        ncells_1d = 2 ** int(param["ncoarse"])
+        scheme = {"cic": L.CIC, "tsc": L.TSC}.get(param["mass_scheme"].casefold())
+        if (_FUSE_DEPOSIT and scheme is not None and ncells_1d >= 16 and not slab.active()
+                and 0 < position.shape[0] < 2**32):
+            # the deposit of pm() rides on the streaming update (pmstep.h: pm_kick_drift_wrap_deposit)
+            torch = L.require_gpu()
+            density = torch.empty((ncells_1d,) * 3, dtype=torch.float32, device=position.device)
+            L.context(ncells_1d).call("pm_kick_drift_wrap_deposit", scheme, L.ptr(position), L.ptr(velocity),
+                                      L.ptr(acceleration), float(half_dt), float(np.float32(dt)), position.shape[0],
+                                      L.ptr(density))
+        else:
+            L.context(4).call("pm_kick_drift_wrap", L.ptr(position), L.ptr(velocity), L.ptr(acceleration),
+                              float(half_dt), float(np.float32(dt)), position.shape[0])
         _advance_clock(dt, tables, param)
     else:
         utils.add_vector_scalar_inplace(velocity, acceleration, -half_dt)
@@ -75,7 +91,7 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
     logging.info(f"{param['t']=} {param['aexp']=}")
     if fused:  # second kick fused into the interpolation kernel
         acceleration, potential, additional_field = solver.pm(position, param, potential, additional_field, tables,
-                                                              _kick=(velocity, half_dt))
+                                                              _kick=(velocity, half_dt), _density=density)
     else:
         acceleration, potential, additional_field = solver.pm(position, param, potential, additional_field, tables)
         utils.add_vector_scalar_inplace(velocity, acceleration, -half_dt)

@@ -28,14 +28,15 @@ def _empty(template):
     return np.empty(0, dtype=np.float32)
 
 
-def pm(position, param, potential=None, additional_field=None, tables: List = (), *, _kick=None):
+def pm(position, param, potential=None, additional_field=None, tables: List = (), *, _kick=None, _density=None):
     """Acceleration at the particles, potential and (for f(R)/MOND) the extra field.
 
     Mirrors solver.py:30-215: deposit -> density scaling -> [P(k)] -> extra field -> rhs ->
     Poisson solve (fft | fft_7pt | multigrid) -> gradient -> inverse interpolation.
 
     `_kick=(velocity, half_dt)` is the private hook integration.leapfrog uses to fuse its second
-    kick (integration.py:262) into the interpolation kernel; not part of the reference API.
+    kick (integration.py:262) into the interpolation kernel, and `_density` the density it already
+    deposited together with its first kick and drift; neither is part of the reference API.
     """
     from . import slab
 
@@ -60,7 +61,10 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     ctx.call("pm_tile_lists", L.ptr(pos_d), pos_d.shape[0])
     try:
         # TSC == TSC_seq here (solver.py:86-89)
-        density = mesh.CIC(pos_d, ncells_1d) if MASS_SCHEME == "cic" else mesh.TSC(pos_d, ncells_1d)
+        if _density is not None:
+            density = _density
+        else:
+            density = mesh.CIC(pos_d, ncells_1d) if MASS_SCHEME == "cic" else mesh.TSC(pos_d, ncells_1d)
 
         # Without an f(R) term the force grid is only ever read by the gather: the gather kernel then takes
         # the potential and differentiates its own LDS tile (mesh.derivative_interp_vec_kick), and the

@@ -203,6 +203,44 @@ def test_drifted_sorted_stream_stragglers(amd, drift_cells):
     ctx.call("pm_tile_lists", None, 0)
 
 
+@pytest.mark.parametrize("sorted_stream", [True, False])
+def test_fused_kick_drift_wrap_deposit(amd, sorted_stream):
+    """pm_kick_drift_wrap_deposit == pm_kick_drift_wrap followed by pm_deposit: positions and velocities
+    bit-exact, density within the atomics tolerance, and the lists it leaves behind serve the gather of
+    the same positions (bit-exact).  Sorted stream with a drift that makes stragglers; unsorted stream
+    (list overflow: the entry point re-deposits with the order-independent kernel)."""
+    from pysco_amd import _lib as L
+
+    n = 64
+    rng = np.random.default_rng(21)
+    pos, vel = zeldovich_particles(n, seed=4, rms_cells=1.0)
+    if sorted_stream:
+        pos, vel = amd.utils.reorder_particles(pos, vel)
+    acc = (rng.normal(size=pos.shape) * 0.3).astype(np.float32)
+    vel = (vel * np.float32(0.5 / max(np.abs(vel).max(), 1e-30) / n)).astype(np.float32)   # <= 0.5 cell per unit dt
+    half_dt, dt = np.float32(0.01), np.float32(1.3)
+    t = amd.torch
+    ctx = L.context(n)
+    phi = rng.normal(size=(n, n, n)).astype(np.float32)
+    for scheme_id, scheme, odep, oinv in ((L.TSC, "tsc", orc.TSC, orc.invTSC_vec), (L.CIC, "cic", orc.CIC, orc.invCIC_vec)):
+        p_ref, v_ref = t.from_numpy(pos).cuda(), t.from_numpy(vel).cuda()
+        a_d = t.from_numpy(acc).cuda()
+        ctx.call("pm_kick_drift_wrap", L.ptr(p_ref), L.ptr(v_ref), L.ptr(a_d), float(half_dt), float(dt), len(pos))
+        p_d, v_d = t.from_numpy(pos).cuda(), t.from_numpy(vel).cuda()
+        rho = t.empty((n, n, n), dtype=t.float32, device="cuda")
+        ctx.call("pm_kick_drift_wrap_deposit", scheme_id, L.ptr(p_d), L.ptr(v_d), L.ptr(a_d), float(half_dt), float(dt),
+                 len(pos), L.ptr(rho))
+        assert t.equal(p_d, p_ref) and t.equal(v_d, v_ref)
+        new_pos = p_d.cpu().numpy()
+        ref = odep(new_pos, n)
+        np.testing.assert_allclose(rho.cpu().numpy(), ref, rtol=0, atol=4e-6 * _scale(ref))
+        assert abs(float(rho.sum(dtype=t.float64)) - len(pos)) < 1e-5 * len(pos)
+        ctx.call("pm_tile_lists", L.ptr(p_d), len(pos))      # keeps what the fused call prepared
+        a_out = amd.mesh.derivative_interp_vec_kick(scheme, t.from_numpy(phi).cuda(), 5, p_d)
+        ctx.call("pm_tile_lists", None, 0)
+        np.testing.assert_array_equal(a_out.cpu().numpy(), oinv(orc.derivative(phi, 5), new_pos))
+
+
 @pytest.mark.parametrize("n", [64, 128])
 def test_gradient_marching_kernel_bit_exact(amd, n):
     """n >= 128 takes the marching (2.5-D) gradient kernel: same bits as the oracle for every order."""
