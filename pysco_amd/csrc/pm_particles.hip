@@ -550,8 +550,10 @@ __global__ __launch_bounds__(BLK) void interp_tiled_kernel(const float *__restri
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < BLK / 64; ++w) ma = max(ma, s_max[0][w]), mv = max(mv, s_max[1][w]);
-        atomicMax(maxbits, ma);
-        if (KICK) atomicMax(maxbits + 1, mv);
+        // one same-address atomic costs ~12 ns at the L2 and half a million workgroups would queue up on
+        // it; the maximum only grows, so a workgroup that cannot raise it (nearly all) just reads it
+        if (ma > __atomic_load_n(maxbits, __ATOMIC_RELAXED)) atomicMax(maxbits, ma);
+        if (KICK && mv > __atomic_load_n(maxbits + 1, __ATOMIC_RELAXED)) atomicMax(maxbits + 1, mv);
     }
 }
 
@@ -734,9 +736,18 @@ static int tile_ranges(pm_ctx *c, const float *pos, int64_t np, TileWork *out, u
 
 // ---- pm_tile_lists: ranges + incoming-straggler lists, prepared once per set of positions ---------
 
+// The list is appended to through PM_NSUB counters, each with its own segment of the buffers and its own
+// 128-byte line: appends of different workgroups mostly hit different L2 channels instead of queueing
+// on one address (~12 ns per same-address atomic: 6 ms for the 524288 workgroups of a 1024^3 step).
+constexpr int PM_NSUB = 64, PM_SUB_STRIDE = 32;
+
+__device__ __forceinline__ unsigned *sub_counter(unsigned *counts) {
+    return counts + (blockIdx.x % PM_NSUB) * PM_SUB_STRIDE;
+}
+
 __global__ __launch_bounds__(BLK) void straggler_scan_kernel(const float *__restrict__ pos, TileWork work, int n,
                                                              unsigned *__restrict__ keys, unsigned *__restrict__ idx,
-                                                             unsigned cap, unsigned *__restrict__ total) {
+                                                             unsigned subcap, unsigned *__restrict__ counts) {
     unsigned key;
     int64_t s, e;
     if (!tile_work_item(work, key, s, e)) return;
@@ -756,11 +767,25 @@ __global__ __launch_bounds__(BLK) void straggler_scan_kernel(const float *__rest
     __syncthreads();
     const unsigned cnt = s_cnt;
     if (cnt == 0) return;
-    if (tid == 0) s_base = atomicAdd(total, cnt);
+    if (tid == 0) s_base = atomicAdd(sub_counter(counts), cnt);
     __syncthreads();
-    const unsigned base = s_base;
+    const unsigned base = s_base, seg = (blockIdx.x % PM_NSUB) * subcap;
     for (unsigned i = tid; i < cnt; i += BLK)
-        if (base + i < cap) keys[base + i] = s_k[i], idx[base + i] = s_p[i];
+        if (base + i < subcap) keys[seg + base + i] = s_k[i], idx[seg + base + i] = s_p[i];
+}
+
+struct SubLists {
+    unsigned count[PM_NSUB], offset[PM_NSUB];
+};
+
+// segments -> one contiguous list
+__global__ __launch_bounds__(BLK) void list_compact_kernel(const unsigned *__restrict__ k_seg,
+                                                           const unsigned *__restrict__ i_seg, unsigned subcap,
+                                                           SubLists sub, unsigned *__restrict__ k_out,
+                                                           unsigned *__restrict__ i_out) {
+    const unsigned k = blockIdx.y, cnt = sub.count[k], off = sub.offset[k];
+    for (unsigned i = blockIdx.x * BLK + threadIdx.x; i < cnt; i += gridDim.x * BLK)
+        k_out[off + i] = k_seg[k * subcap + i], i_out[off + i] = i_seg[k * subcap + i];
 }
 
 __global__ __launch_bounds__(BLK) void list_bounds_kernel(const unsigned *__restrict__ keys, unsigned count,
@@ -782,17 +807,19 @@ static void tile_lists_drop(pm_ctx *c) { c->lists_pos = nullptr, c->lists_np = 0
 
 // device buffers of the straggler lists: unsorted and sorted (key, index) pairs, per-tile offsets
 struct ListBufs {
-    unsigned *k_in, *i_in, *k_out, *i_out, *lstart, *total;
+    unsigned *k_in, *i_in, *k_out, *i_out, *lstart, *counts;
     void *sort_tmp;
-    size_t sort_tmp_bytes, cap;
+    size_t sort_tmp_bytes, cap, subcap;
     int bits;
 };
 
 static int list_bufs(pm_ctx *c, int64_t np, unsigned ntiles, ListBufs *b) {
     // room for one straggler in eight particles; beyond that the stream is not worth calling sorted
-    b->cap = (size_t)(np / 8 + 1024);
+    b->subcap = (size_t)(np / (8 * PM_NSUB) + 64);
+    b->cap = b->subcap * PM_NSUB;
     const size_t off_l = ((b->cap * 4 * sizeof(unsigned)) + 255) & ~(size_t)255;
-    const size_t off_t = off_l + ((((size_t)ntiles + 1) * sizeof(unsigned) + 255) & ~(size_t)255);
+    const size_t off_c = off_l + ((((size_t)ntiles + 1) * sizeof(unsigned) + 255) & ~(size_t)255);
+    const size_t off_t = off_c + PM_NSUB * PM_SUB_STRIDE * sizeof(unsigned);
     unsigned *nu = nullptr;
     b->bits = 32 - __builtin_clz(ntiles > 1 ? ntiles - 1 : 1);
     b->sort_tmp_bytes = 0;
@@ -806,27 +833,41 @@ static int list_bufs(pm_ctx *c, int64_t np, unsigned ntiles, ListBufs *b) {
     }
     b->k_in = (unsigned *)c->list_buf, b->i_in = b->k_in + b->cap, b->k_out = b->i_in + b->cap, b->i_out = b->k_out + b->cap;
     b->lstart = (unsigned *)((char *)c->list_buf + off_l);
+    b->counts = (unsigned *)((char *)c->list_buf + off_c);
     b->sort_tmp = (char *)c->list_buf + off_t;
-    b->total = c->d_scratch + 12;
     return PM_OK;
 }
 
-// reads the straggler count back (stream sync), groups the first min(count, cap) entries by tile;
-// *listed = entries grouped, *complete = every straggler is among them
+// reads the straggler counts back (stream sync), compacts the segments and groups the entries by tile;
+// *listed = entries grouped, *complete = every straggler is among them (no segment overflowed)
 static int list_group(pm_ctx *c, const ListBufs &b, unsigned ntiles, const unsigned **idx, unsigned *listed,
                       int *complete) {
-    unsigned h_total = 0;
-    PM_HIP(hipMemcpyAsync(&h_total, b.total, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    unsigned h_counts[PM_NSUB * PM_SUB_STRIDE];
+    PM_HIP(hipMemcpyAsync(h_counts, b.counts, sizeof(h_counts), hipMemcpyDeviceToHost, c->stream));
     PM_HIP(hipStreamSynchronize(c->stream));
-    *complete = h_total <= b.cap;
-    const unsigned cnt = *complete ? h_total : (unsigned)b.cap;
-    const unsigned *keys = b.k_in;
-    *idx = b.i_in;
-    if (cnt > 1) {
+    SubLists sub;
+    unsigned cnt = 0, biggest = 0;
+    *complete = 1;
+    for (int k = 0; k < PM_NSUB; ++k) {
+        unsigned ck = h_counts[k * PM_SUB_STRIDE];
+        if (ck > b.subcap) ck = (unsigned)b.subcap, *complete = 0;
+        sub.count[k] = ck, sub.offset[k] = cnt;
+        cnt += ck;
+        if (ck > biggest) biggest = ck;
+    }
+    const unsigned *keys = b.k_out;
+    *idx = b.i_out;
+    if (cnt > 0) {
+        const unsigned gx = (biggest + BLK * 8 - 1) / (BLK * 8);
+        hipLaunchKernelGGL(list_compact_kernel, dim3(gx ? gx : 1, PM_NSUB), dim3(BLK), 0, c->stream, b.k_in, b.i_in,
+                           (unsigned)b.subcap, sub, b.k_out, b.i_out);
+        PM_LAUNCH_CHECK();
+    }
+    if (cnt > 1) {  // sort back into the (now free) segment buffers
         size_t tmp = b.sort_tmp_bytes;
-        PM_HIP(rocprim::radix_sort_pairs(b.sort_tmp, tmp, b.k_in, b.k_out, b.i_in, b.i_out, (size_t)cnt, 0, b.bits,
+        PM_HIP(rocprim::radix_sort_pairs(b.sort_tmp, tmp, b.k_out, b.k_in, b.i_out, b.i_in, (size_t)cnt, 0, b.bits,
                                          c->stream));
-        keys = b.k_out, *idx = b.i_out;
+        keys = b.k_in, *idx = b.i_in;
     }
     hipLaunchKernelGGL(list_bounds_kernel, dim3((ntiles + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, cnt, ntiles,
                        b.lstart);
@@ -855,9 +896,9 @@ extern "C" int pm_tile_lists(pm_ctx *c, const float *d_pos, int64_t np) {
         ListBufs b;
         rc = list_bufs(c, np, ntiles, &b);
         if (rc) return rc;
-        PM_HIP(hipMemsetAsync(b.total, 0, sizeof(unsigned), c->stream));
+        PM_HIP(hipMemsetAsync(b.counts, 0, PM_NSUB * PM_SUB_STRIDE * sizeof(unsigned), c->stream));
         hipLaunchKernelGGL(straggler_scan_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_pos, work, c->n, b.k_in, b.i_in,
-                           (unsigned)b.cap, b.total);
+                           (unsigned)b.subcap, b.counts);
         PM_LAUNCH_CHECK();
         const unsigned *idx = nullptr;
         unsigned listed = 0;
@@ -973,7 +1014,7 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
                                                           const float *__restrict__ acc, float mhalf_dt, float dt,
                                                           TileWork work, pm_geom geo, float *__restrict__ rho,
                                                           unsigned *__restrict__ lkeys, unsigned *__restrict__ lidx,
-                                                          unsigned cap, unsigned *__restrict__ total) {
+                                                          unsigned subcap, unsigned *__restrict__ counts) {
     unsigned key;
     int64_t s, e;
     if (!tile_work_item(work, key, s, e)) return;
@@ -987,9 +1028,10 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
     for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
+    const unsigned seg = (blockIdx.x % PM_NSUB) * subcap;
     auto append = [&](unsigned k, unsigned p) {  // past the staging area: straight to the global list
-        const unsigned g = atomicAdd(total, 1u);
-        if (g < cap) lkeys[g] = k, lidx[g] = p;
+        const unsigned g = atomicAdd(sub_counter(counts), 1u);
+        if (g < subcap) lkeys[seg + g] = k, lidx[seg + g] = p;
     };
     // two particles per iteration: 18 dword loads in flight per lane
 #pragma unroll 1
@@ -1035,11 +1077,11 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
     }
     const unsigned cnt = min(s_cnt, (unsigned)PM_SCAP);
     if (cnt == 0) return;
-    if (tid == 0) s_base = atomicAdd(total, cnt);
+    if (tid == 0) s_base = atomicAdd(sub_counter(counts), cnt);
     __syncthreads();
     const unsigned base = s_base;
     for (unsigned i = tid; i < cnt; i += BLK)
-        if (base + i < cap) lkeys[base + i] = s_k[i], lidx[base + i] = s_p[i];
+        if (base + i < subcap) lkeys[seg + base + i] = s_k[i], lidx[seg + base + i] = s_p[i];
 }
 
 // deposit of the listed stragglers, one workgroup per tile with a non-empty incoming list
@@ -1087,9 +1129,9 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     if (rc) return rc;
     const size_t cells = (size_t)c->slab_nx * c->n * c->n;
     PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));
-    PM_HIP(hipMemsetAsync(b.total, 0, sizeof(unsigned), c->stream));
+    PM_HIP(hipMemsetAsync(b.counts, 0, PM_NSUB * PM_SUB_STRIDE * sizeof(unsigned), c->stream));
     hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, vel, acc, -half_dt, dt, work,
-                       pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.cap, b.total);
+                       pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts);
     PM_LAUNCH_CHECK();
     const unsigned *idx = nullptr;
     unsigned listed = 0;
@@ -1377,8 +1419,10 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < BLK / 64; ++w) ma = max(ma, s_max[0][w]), mv = max(mv, s_max[1][w]);
-        atomicMax(maxbits, ma);
-        if (KICK) atomicMax(maxbits + 1, mv);
+        // one same-address atomic costs ~12 ns at the L2 and half a million workgroups would queue up on
+        // it; the maximum only grows, so a workgroup that cannot raise it (nearly all) just reads it
+        if (ma > __atomic_load_n(maxbits, __ATOMIC_RELAXED)) atomicMax(maxbits, ma);
+        if (KICK && mv > __atomic_load_n(maxbits + 1, __ATOMIC_RELAXED)) atomicMax(maxbits + 1, mv);
     }
 }
 

@@ -57,7 +57,7 @@ def main():
     ctx = L.context(n)
     rho = torch.empty((n, n, n), dtype=torch.float32, device="cuda")
     F = torch.randn((n, n, n, 3), dtype=torch.float32, device="cuda")
-    acc = torch.empty_like(pos)
+    acc = torch.zeros_like(pos)
 
     def want(k):
         return only is None or k in only
@@ -110,6 +110,12 @@ def main():
         k2, s, c0 = fourier.green_tables(n, 1)
         t = timeit(lambda: ctx.call("pm_greens", 1, 3, L.ptr(xk), L.hptr(k2), L.hptr(s), c0))
         rows.append(("greens compensated", t, 16 * n * n * (n // 2 + 1) / t / 1e6))
+    if want("kdwdep"):
+        for name, sch in (("CIC", 2), ("TSC", 3)):
+            t = timeit(lambda: ctx.call("pm_kick_drift_wrap_deposit", sch, L.ptr(pos), L.ptr(vel), L.ptr(acc), 1e-9, 1e-9,
+                                        npart, L.ptr(rho)))
+            rows.append((f"kick_drift_wrap + deposit {name}", t, (60 * npart + 4 * n**3) / t / 1e6))
+        ctx.call("pm_tile_lists", None, 0)
     if want("stream"):
         t = timeit(lambda: ctx.call("pm_kick_drift_wrap", L.ptr(pos), L.ptr(vel), L.ptr(acc), 1e-9, 1e-9, npart))
         rows.append(("kick_drift_wrap", t, 60 * npart / t / 1e6))
