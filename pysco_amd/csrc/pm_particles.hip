@@ -103,6 +103,7 @@ constexpr int PM_TI = 8, PM_TJ = 16, PM_TK = 16;      // tile extent in cells
 constexpr int PM_LI = 3, PM_LJ = 4, PM_LK = 4;        // log2 of the above
 constexpr int PM_HI = PM_TI + 2, PM_HJ = PM_TJ + 2, PM_HK = PM_TK + 2;
 constexpr int PM_TILE = PM_HI * PM_HJ * PM_HK;        // 3240 cells
+constexpr int PM_FSTRIDE = 3264;                      // floats per component plane of the LDS force tile (51 * 64)
 constexpr int PM_PPT = 8;                             // particles per thread
 constexpr int PM_CHUNK = BLK * PM_PPT;                // particles per workgroup
 constexpr int PM_MAX_PASSES = 6;
@@ -350,20 +351,28 @@ extern "C" int pm_interp(pm_ctx *c, int scheme, int ncomp, const float *d_grid, 
 // reductions of the next step (integration.py:294, 325).
 //
 // The direct kernel above is bound by the L1 tag rate (27 scattered 12-byte loads per particle).
-// Here the workgroup stages the force tile of its chunk (8x16x16 cells + halo, float4 per cell,
-// 51.8 KB) in LDS with coalesced loads and every particle does 27 ds_read_b128.  Sum order is the
+// Here the workgroup stages the force tile of its chunk (8x16x16 cells + halo, three component planes,
+// 39.2 KB) in LDS with coalesced loads and every particle does 27 x 3 ds_read_b32.  Sum order is the
 // reference's, so the accelerations are bit-identical to the direct kernel and to the oracle.
 
 template <int SCHEME>
 __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, int j, int k, const TileId &t,
-                                           const float4 *tile, float acc[3]) {
+                                           const float *tile, float acc[3]) {
     const int li = i - t.ti * PM_TI + 1, lj = j - t.tj * PM_TJ + 1, lk = k - t.tk * PM_TK + 1;
-    auto at = [&](int a, int b, int c) -> float4 { return tile[((li + a) * PM_HJ + (lj + b)) * PM_HK + (lk + c)]; };
+    // component planes (SoA): a wave's 64 cells of one ds_read_b32 spread over the 64 banks, where the
+    // float4-per-cell layout put 16 lanes on 16 four-bank slots (2-way conflicts for a Morton block)
+    struct F3 {
+        float x, y, z;
+    };
+    auto at = [&](int a, int b, int c) -> F3 {
+        const float *g = tile + ((li + a) * PM_HJ + (lj + b)) * PM_HK + (lk + c);
+        return F3{g[0], g[PM_FSTRIDE], g[2 * PM_FSTRIDE]};
+    };
     // The running sums start from +0 (0 + w*g == w*g exactly) and add the terms in the reference's
     // left-to-right order (mesh.py:3058-3086).
     acc[0] = acc[1] = acc[2] = 0.f;
     if (SCHEME == PM_NGP) {
-        const float4 g = at(0, 0, 0);
+        const F3 g = at(0, 0, 0);
         acc[0] = g.x, acc[1] = g.y, acc[2] = g.z;
     } else if (SCHEME == PM_CIC) {
         float wx[2], wy[2], wz[2];
@@ -378,7 +387,7 @@ __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, 
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const float w = wx[a] * wy[b] * wz[c];
-                    const float4 g = at(a * sx, b * sy, c * sz);
+                    const F3 g = at(a * sx, b * sy, c * sz);
                     acc[0] = acc[0] + w * g.x;
                     acc[1] = acc[1] + w * g.y;
                     acc[2] = acc[2] + w * g.z;
@@ -399,7 +408,7 @@ __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, 
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float w = wxy * wz[c];
-                    const float4 g = at(a - 1, b - 1, c - 1);
+                    const F3 g = at(a - 1, b - 1, c - 1);
                     acc[0] = acc[0] + w * g.x;
                     acc[1] = acc[1] + w * g.y;
                     acc[2] = acc[2] + w * g.z;
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(BLK) void interp_tiled_kernel(const float *__restri
                                                            const float *__restrict__ pos, int64_t np, pm_geom geo,
                                                            float *__restrict__ out, float *__restrict__ vel,
                                                            float mhalf_dt, unsigned *__restrict__ maxbits) {
-    __shared__ float4 tile[PM_TILE];  // 51.8 KB
+    __shared__ float tile[3 * PM_FSTRIDE];  // 39.2 KB
     __shared__ int s_first;
     __shared__ int s_anchor[3];
     __shared__ unsigned s_max[2][BLK / 64];
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(BLK) void interp_tiled_kernel(const float *__restri
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int c = q * BLK + tid;
-                if (c < PM_TILE) tile[c] = make_float4(gx[q], gy[q], gz[q], 0.f);
+                if (c < PM_TILE) tile[c] = gx[q], tile[PM_FSTRIDE + c] = gy[q], tile[2 * PM_FSTRIDE + c] = gz[q];
             }
         }
         __syncthreads();
@@ -660,17 +669,20 @@ struct TileLists {
 };
 
 // work item of this workgroup: tile key and particle range [s, e); false if it has none
+// tile of workgroup b < ntiles (no memory access).  Workgroups go round-robin to the 8 XCDs (each with
+// its own L2): deal every XCD runs of 64 consecutive tiles (a 32x64x64-cell Morton block) so the tile
+// halos it re-reads are its own L2 hits.
+__device__ __forceinline__ unsigned tile_key_of_block(unsigned b, unsigned ntiles) {
+    constexpr unsigned G = 512;
+    if (b >= (ntiles / G) * G) return b;
+    const unsigned r = b % G;
+    return b - r + (r % 8) * (G / 8) + r / 8;
+}
+
 __device__ __forceinline__ bool tile_work_item(const TileWork &w, unsigned &key, int64_t &s, int64_t &e) {
     const unsigned b = blockIdx.x;
     if (b < w.ntiles) {
-        // Workgroups go round-robin to the 8 XCDs (each with its own L2): deal every XCD runs of 64
-        // consecutive tiles (a 32x64x64-cell Morton block) so the tile halos it re-reads are its own L2 hits.
-        constexpr unsigned G = 512;
-        key = b;
-        if (b < (w.ntiles / G) * G) {
-            const unsigned r = b % G;
-            key = b - r + (r % 8) * (G / 8) + r / 8;
-        }
+        key = tile_key_of_block(b, w.ntiles);
         s = w.start[key];
         e = min(w.start[key + 1], s + PM_RANGE_CHUNK);
     } else {
@@ -948,6 +960,29 @@ struct PosQueue {
     }
 };
 
+// the same for the velocities the fused kick updates (loaded at the top of an iteration they would be
+// waited for at its end, one memory latency per particle; four iterations ahead they are simply there)
+struct VelQueue {
+    float x[4], y[4], z[4];
+    const float *vel;
+    int64_t last;
+    __device__ __forceinline__ void load(int slot, int64_t p) {
+        p = p < last ? p : last;
+        x[slot] = vel[3 * p], y[slot] = vel[3 * p + 1], z[slot] = vel[3 * p + 2];
+    }
+    __device__ __forceinline__ void prime(const float *vel_, int64_t p0, int64_t end) {
+        vel = vel_, last = end - 1;
+        load(0, p0), load(1, p0 + BLK), load(2, p0 + 2 * BLK), load(3, p0 + 3 * BLK);
+    }
+    __device__ __forceinline__ void pop(int64_t p, float v[3]) {
+        v[0] = x[0], v[1] = y[0], v[2] = z[0];
+        x[0] = x[1], y[0] = y[1], z[0] = z[1];
+        x[1] = x[2], y[1] = y[2], z[1] = z[2];
+        x[2] = x[3], y[2] = y[3], z[2] = z[3];
+        load(3, p + 4 * BLK);
+    }
+};
+
 template <int SCHEME>
 __global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__restrict__ pos, TileWork work,
                                                              TileLists lists, pm_geom geo, float *__restrict__ rho) {
@@ -1179,7 +1214,7 @@ extern "C" int pm_kick_drift_wrap_deposit(pm_ctx *c, int scheme, float *d_pos, f
 // Gradient + gather + kick in one kernel (mesh.derivative + mesh.inv*_vec + the second kick): the
 // workgroup stages the POTENTIAL of its tile (force tile + stencil reach R on every side) in LDS,
 // differentiates it there with the reference's stencil (Stencil<ORDER,0>::eval, same bits as
-// pm_gradient), parks the three components in registers, and rewrites the same LDS as the float4
+// pm_gradient), parks the three components in registers, and rewrites the same LDS as the
 // force tile the gather reads.  The [n,n,n,3] force grid (12.9 GB at 1024^3: one write, 1.6 reads
 // with halos) and the gradient pass never exist.
 
@@ -1266,21 +1301,55 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                                                             TileLists lists, pm_geom geo, float *__restrict__ out,
                                                             float *__restrict__ vel, float mhalf_dt,
                                                             unsigned *__restrict__ maxbits) {
-    unsigned key;
-    int64_t s, e;
-    const bool has_range = tile_work_item(work, key, s, e);
-    unsigned ls = 0, le = 0;  // incoming stragglers (first workgroup of the tile only)
-    if (lists.use && blockIdx.x < work.ntiles) ls = lists.lstart[key], le = lists.lstart[key + 1];
-    if (!has_range && ls == le) return;
-    __shared__ float4 tile[PM_TILE];  // 51.8 KB (ORDER > 0: first the potential tile, as floats)
+    // The tile of a first-chunk workgroup follows from blockIdx alone, so its fill loads are issued
+    // together with the range lookup instead of one memory latency after it.
+    unsigned key = 0;
+    int64_t s = 0, e = 0;
+    bool has_range = false;
+    const bool first_chunk = blockIdx.x < work.ntiles;
+    if (first_chunk)
+        key = tile_key_of_block(blockIdx.x, work.ntiles);
+    else if (!tile_work_item(work, key, s, e))
+        return;
+    else
+        has_range = true;
+    __shared__ float tile[3 * PM_FSTRIDE];  // 39.2 KB: three component planes (ORDER > 0: first the potential tile)
     __shared__ unsigned s_max[2][BLK / 64];
     const int tid = threadIdx.x;
     const int n = geo.n;
     const float nf = (float)n;
     const float scale = grad_scale<ORDER>(n);
     const TileId t = tile_of_key(key);
+    constexpr int R = GradReach<ORDER>::R;
+    constexpr int DX = PM_HI + 2 * R, DY = PM_HJ + 2 * R, DZ = PM_HK + 2 * R;  // potential tile
+    constexpr int NPHI = DX * DY * DZ;                                        // 6776 (R=2), 9216 (R=3)
+    constexpr int NQP = ORDER == 0 ? 1 : (NPHI + BLK - 1) / BLK;
+    float gphi[NQP];
+    if constexpr (ORDER != 0) {  // consecutive lanes read consecutive z (rows of DZ floats); all loads in flight
+        const int gi0 = t.ti * PM_TI - 1 - R, gj0 = t.tj * PM_TJ - 1 - R, gk0 = t.tk * PM_TK - 1 - R;
+#pragma unroll
+        for (int u = 0; u < NQP; ++u) {
+            const int f = u * BLK + tid;
+            if (f < NPHI) {
+                const int c = f % DZ, ab = f / DZ;
+                gphi[u] = src[pm_cell(geo, gi0 + ab / DY, gj0 + ab % DY, gk0 + c)];
+            }
+        }
+    }
+    unsigned ls = 0, le = 0;  // incoming stragglers (first workgroup of the tile only)
+    if (first_chunk) {
+        s = work.start[key];
+        e = min(work.start[key + 1], s + PM_RANGE_CHUNK);
+        has_range = s < e;
+        if (lists.use) ls = lists.lstart[key], le = lists.lstart[key + 1];
+        if (!has_range && ls == le) return;
+    }
     PosQueue q;
-    if (has_range) q.prime(pos, s + tid, e);
+    VelQueue qv;
+    if (has_range) {
+        q.prime(pos, s + tid, e);
+        if (KICK) qv.prime(vel, s + tid, e);
+    }
     if constexpr (ORDER == 0) {
         // tile fill, float-granular: consecutive lanes read consecutive floats of a tile row (18 cells x 3
         // components = 216 contiguous bytes), so a wave load is a few full lines instead of 64 scattered
@@ -1288,7 +1357,6 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         // flight before the first LDS write.
         constexpr int NF = PM_TILE * 3, NQ = (NF + BLK - 1) / BLK;  // 9720 floats, 38 per thread
         float g[NQ];
-        float *tile_f = reinterpret_cast<float *>(tile);
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int f = u * BLK + tid;
@@ -1302,32 +1370,16 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
             const int f = u * BLK + tid;
             if (f < NF) {
                 const int c = f / 3, m = f - 3 * c;
-                tile_f[4 * c + m] = g[u];
+                tile[m * PM_FSTRIDE + c] = g[u];
             }
         }
     } else {
-        constexpr int R = GradReach<ORDER>::R;
-        constexpr int DX = PM_HI + 2 * R, DY = PM_HJ + 2 * R, DZ = PM_HK + 2 * R;  // potential tile
-        constexpr int NPHI = DX * DY * DZ;                                        // 6776 (R=2), 9216 (R=3)
-        static_assert(NPHI * 4 <= PM_TILE * 16, "potential tile must fit in the force tile");
-        float *ptile = reinterpret_cast<float *>(tile);
-        {   // consecutive lanes read consecutive z (rows of DZ floats); all loads in flight first
-            constexpr int NQ = (NPHI + BLK - 1) / BLK;
-            const int gi0 = t.ti * PM_TI - 1 - R, gj0 = t.tj * PM_TJ - 1 - R, gk0 = t.tk * PM_TK - 1 - R;
-            float g[NQ];
+        static_assert(NPHI <= 3 * PM_FSTRIDE, "potential tile must fit in the force tile");
+        float *ptile = tile;
 #pragma unroll
-            for (int u = 0; u < NQ; ++u) {
-                const int f = u * BLK + tid;
-                if (f < NPHI) {
-                    const int c = f % DZ, ab = f / DZ;
-                    g[u] = src[pm_cell(geo, gi0 + ab / DY, gj0 + ab % DY, gk0 + c)];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < NQ; ++u) {
-                const int f = u * BLK + tid;
-                if (f < NPHI) ptile[f] = g[u];
-            }
+        for (int u = 0; u < NQP; ++u) {
+            const int f = u * BLK + tid;
+            if (f < NPHI) ptile[f] = gphi[u];
         }
         __syncthreads();
         // differentiate: thread owns force-tile cells tid, tid + BLK, ...
@@ -1358,14 +1410,14 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
             const int c = u * BLK + tid;
-            if (c < PM_TILE) tile[c] = make_float4(gx[u], gy[u], gz[u], 0.f);
+            if (c < PM_TILE) tile[c] = gx[u], tile[PM_FSTRIDE + c] = gy[u], tile[2 * PM_FSTRIDE + c] = gz[u];
         }
     }
     __syncthreads();
     // gather, second kick (utils.py:297, y += a*x) and the CFL maxima in one pass: the acceleration never
     // leaves its registers (PMC: re-reading it in a separate coalesced pass cost a further 12.9 GB of fetch)
     unsigned ma = 0, mv = 0;  // bit patterns of max|a|, max|v| (integer order == float order, NaN on top)
-    auto serve = [&](int64_t p, float x, float y, float z, bool own_range) {
+    auto serve = [&](int64_t p, float x, float y, float z, const float v[3], bool own_range) {
         const float xp = x * nf, yp = y * nf, zp = z * nf;
         const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
         const bool inside = in_tile(i, j, k, t);
@@ -1373,8 +1425,6 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         // through the LDS gather on a dummy cell and only its stores are suppressed: an early exit here
         // costs 10 % of the kernel (the compiler stops overlapping the loads with the LDS reads).
         const bool skip = !inside && own_range && lists.use;
-        float v[3] = {0.f, 0.f, 0.f};
-        if (KICK) v[0] = vel[3 * p], v[1] = vel[3 * p + 1], v[2] = vel[3 * p + 2];
         float a[3];
         if (inside || skip) {
             gather_lds<SCHEME>(xp, yp, zp, skip ? t.ti * PM_TI : i, skip ? t.tj * PM_TJ : j, skip ? t.tk * PM_TK : k, t,
@@ -1403,13 +1453,17 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         for (int64_t p = s + tid; p < e; p += BLK) {
             float x, y, z;
             q.pop(p, x, y, z);
-            serve(p, x, y, z, true);
+            float v[3] = {0.f, 0.f, 0.f};
+            if (KICK) qv.pop(p, v);
+            serve(p, x, y, z, v, true);
         }
     }
 #pragma unroll 1
     for (unsigned l = ls + tid; l < le; l += BLK) {
         const int64_t p = lists.idx[l];
-        serve(p, pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], false);
+        float v[3] = {0.f, 0.f, 0.f};
+        if (KICK) v[0] = vel[3 * p], v[1] = vel[3 * p + 1], v[2] = vel[3 * p + 2];
+        serve(p, pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], v, false);
     }
     for (int off = 32; off > 0; off >>= 1) {
         ma = max(ma, (unsigned)__shfl_down((int)ma, off, 64));
