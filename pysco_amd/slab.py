@@ -92,6 +92,22 @@ class HipOps:
         self.ctx.call("pm_last_maxabs", C.byref(a), C.byref(v))
         return out, float(a.value), float(v.value)
 
+    def gradient_interp_kick(self, order, scheme, phi_ext, x0_phi, pos, vel, half_dt):
+        """Gradient + gather + kick from the potential slab (with ghosts) without a force array."""
+        out = self.torch.empty_like(pos)
+        self.ctx.call("pm_gradient_interp_kick", int(order), scheme, L.ptr(phi_ext), phi_ext.shape[0], int(x0_phi),
+                      L.ptr(pos), pos.shape[0], L.ptr(out), L.ptr(vel) if vel is not None else None, float(half_dt))
+        a, v = C.c_float(0), C.c_float(0)
+        self.ctx.call("pm_last_maxabs", C.byref(a), C.byref(v))
+        return out, float(a.value), float(v.value)
+
+    def tile_lists(self, pos):
+        """Tile ranges + straggler lists for these positions (pmstep.h: pm_tile_lists); None drops them."""
+        if pos is None:
+            self.ctx.call("pm_tile_lists", None, 0)
+        else:
+            self.ctx.call("pm_tile_lists", L.ptr(pos), pos.shape[0])
+
     def max_abs(self, x) -> float:
         if x.numel() == 0:
             return 0.0
@@ -386,6 +402,19 @@ class Slab:
         param["save_pk"] = False
         param["parametrized_mu_z"] = np.float32(1)
 
+        lists = getattr(ops, "tile_lists", None)
+        if lists is not None:
+            lists(position)
+        try:
+            return self._pm_decomposed(position, param, scheme, kick)
+        finally:
+            if lists is not None:
+                lists(None)
+
+    def _pm_decomposed(self, position, param, scheme, kick):
+        import torch
+
+        n, nx, ops = self.n, self.nx, self.ops
         # deposit into the slab + one ghost plane each side, then fold the ghosts into the neighbours
         rho_ext = ops.deposit(scheme, position, nx + 2, self.x_lo - 1)
         from_left, from_right = exchange_planes(rho_ext[0], rho_ext[nx + 1])
@@ -407,10 +436,14 @@ class Slab:
         H = _REACH[order] + 1
         from_left, from_right = exchange_planes(phi[:H], phi[nx - H:])
         phi_ext = torch.cat([from_left, phi, from_right], dim=0)
-        force = ops.gradient(order, phi_ext, self.x_lo - H, nx + 2, self.x_lo - 1)
-        del phi_ext
         vel, half_dt = (kick if kick is not None else (None, 0.0))
-        acc, ma, mv = ops.interp_kick(scheme, force, nx + 2, self.x_lo - 1, position, vel, half_dt)
+        if hasattr(ops, "gradient_interp_kick") and n >= 16:  # the gather differentiates its own LDS tile
+            acc, ma, mv = ops.gradient_interp_kick(order, scheme, phi_ext, self.x_lo - H, position, vel, half_dt)
+        else:
+            force = ops.gradient(order, phi_ext, self.x_lo - H, nx + 2, self.x_lo - 1)
+            acc, ma, mv = ops.interp_kick(scheme, force, nx + 2, self.x_lo - 1, position, vel, half_dt)
+            del force
+        del phi_ext
         self.local_max = (ma, mv)
         empty = torch.empty(0, dtype=torch.float32, device=position.device)
         return acc, phi, empty
