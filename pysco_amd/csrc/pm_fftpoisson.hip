@@ -12,13 +12,14 @@
 //   P4  C[ky][kz][x]          --y inverse-->        B[kz][x][y]
 //   P5  B[kz][x][y]           --z c2r-->            phi[x][y][z] (real)
 //
-// 1-D FFTs: in place, radix-4 (+ one radix-2 stage when log2 n is odd); forward = decimation in
-// frequency (natural in, digit-reversed out), inverse = decimation in time (digit-reversed in,
-// natural out), so P3 needs no reordering and the other passes permute on their LDS side.
+// 1-D FFTs: one wavefront per line, Stockham autosort stages of radix 16 / 8 / 4 with the butterfly in
+// registers (1024 = 16 * 16 * 4: a lane holds 16 points) and the line exchanged through LDS between
+// stages.  Natural order in and out (no digit reversal, no permutation tables), no barrier inside a
+// stage: the lanes of a wave read all their inputs before the first output is written.
 // Replaces solver.fft (solver.py:453-522 without the P(k) branch) + fourier.py:104-147, 251-294, 460-595.
 #include "pm_common.h"
 
-#define FBLK 1024
+#define FBLK 512  // 8 wavefronts = 8 lines
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -29,118 +30,187 @@ __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
 __device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
 
-// position (after the forward DIF) of frequency k, and its inverse
-__device__ __forceinline__ int pos_of_freq(int k, int log2n) {
-    int pos = 0, L = 1 << log2n;
-    while (L >= 4) {
-        const int d = k & 3;
-        k >>= 2;
-        L >>= 2;
-        pos += d * L;
-    }
-    if (L == 2) pos += (k & 1);
-    return pos;
+// LDS addressing: element e of a line lives at PADI(e) = e + e/16 and lines are NP(n) = n + n/16 apart.
+// The extra slot per 16 elements spreads the stride-16 (and stride-8) scatter of a stage's outputs over
+// the banks (16 lanes x 128 B apart would be a 16-way conflict).
+#define PADI(e) ((e) + ((e) >> 4))
+#define NP(n) ((n) + ((n) >> 4))
+
+// R-point DFTs in registers, natural order in and out.  INV: conjugate transform (unnormalised).
+template <bool INV>
+__device__ __forceinline__ float2 mul_j(float2 a) {  // a * (-i) forward, a * (+i) inverse
+    return INV ? mul_pi(a) : mul_mi(a);
 }
-__device__ __forceinline__ int freq_of_pos(int pos, int log2n) {
-    int k = 0, mult = 1, L = 1 << log2n;
-    while (L >= 4) {
-        L >>= 2;
-        const int d = pos / L;
-        pos -= d * L;
-        k += d * mult;
-        mult <<= 2;
+template <bool INV>
+__device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
+    const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = mul_j<INV>(csub(a1, a3));
+    a0 = cadd(s02, s13), a1 = cadd(d02, d13), a2 = csub(s02, s13), a3 = csub(d02, d13);
+}
+template <bool INV>
+__device__ __forceinline__ float2 cmul_w(float2 a, float c, float sn) {  // a * exp(-/+ i theta), (c, sn) = (cos, sin) theta
+    return INV ? make_float2(a.x * c - a.y * sn, a.x * sn + a.y * c) : make_float2(a.x * c + a.y * sn, a.y * c - a.x * sn);
+}
+template <int R, bool INV>
+struct Dft;
+template <bool INV>
+struct Dft<4, INV> {
+    static __device__ __forceinline__ void run(float2 *a) { dft4<INV>(a[0], a[1], a[2], a[3]); }
+};
+template <bool INV>
+struct Dft<8, INV> {
+    static __device__ __forceinline__ void run(float2 *a) {
+        // even / odd subsequences, then X[k] = E[k] + w8^k O[k], X[k+4] = E[k] - w8^k O[k]
+        dft4<INV>(a[0], a[2], a[4], a[6]);
+        dft4<INV>(a[1], a[3], a[5], a[7]);
+        const float h = 0.70710678118654752f;
+        const float2 o0 = a[1], o1 = cmul_w<INV>(a[3], h, h), o2 = mul_j<INV>(a[5]), o3 = cmul_w<INV>(a[7], -h, h);
+        const float2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
+        a[0] = cadd(e0, o0), a[1] = cadd(e1, o1), a[2] = cadd(e2, o2), a[3] = cadd(e3, o3);
+        a[4] = csub(e0, o0), a[5] = csub(e1, o1), a[6] = csub(e2, o2), a[7] = csub(e3, o3);
     }
-    if (L == 2) k += pos * mult;
-    return k;
+};
+template <bool INV>
+struct Dft<16, INV> {
+    static __device__ __forceinline__ void run(float2 *a) {
+        // m = m0 + 4 m1, k = k1 + 4 k2:  Y[m0][k1] = DFT4 over m1;  X[k1 + 4 k2] = DFT4 over m0 of w16^(m0 k1) Y
+#pragma unroll
+        for (int m0 = 0; m0 < 4; ++m0) dft4<INV>(a[m0], a[m0 + 4], a[m0 + 8], a[m0 + 12]);  // a[m0 + 4 k1] = Y[m0][k1]
+        const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+        a[5] = cmul_w<INV>(a[5], c1, s1);    // w16^1
+        a[6] = cmul_w<INV>(a[6], h, h);      // w16^2
+        a[7] = cmul_w<INV>(a[7], s1, c1);    // w16^3
+        a[9] = cmul_w<INV>(a[9], h, h);      // w16^2
+        a[10] = mul_j<INV>(a[10]);           // w16^4
+        a[11] = cmul_w<INV>(a[11], -h, h);   // w16^6
+        a[13] = cmul_w<INV>(a[13], s1, c1);  // w16^3
+        a[14] = cmul_w<INV>(a[14], -h, h);   // w16^6
+        a[15] = cmul_w<INV>(a[15], -c1, -s1);  // w16^9
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) dft4<INV>(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);  // a[k2 + 4 k1]
+        // natural order: X[k1 + 4 k2] sits in a[k2 + 4 k1] (a 4 x 4 transpose of register names)
+        float2 t;
+#define FFTP_SWAP(i, j) t = a[i], a[i] = a[j], a[j] = t
+        FFTP_SWAP(1, 4), FFTP_SWAP(2, 8), FFTP_SWAP(3, 12), FFTP_SWAP(6, 9), FFTP_SWAP(7, 13), FFTP_SWAP(11, 14);
+#undef FFTP_SWAP
+    }
+};
+
+// One Stockham stage of radix R on the line `ln` (padded, LDS), executed by one wavefront: butterfly j
+// reads in[j + t n/R], multiplies by w^(t (j mod Ns)) (w = exp(-+2 pi i / (Ns R))), does the R-point DFT and
+// writes out[(j / Ns) Ns R + (j mod Ns) + t Ns].  BPL = butterflies per lane (n / R / 64, at least 1).
+// tw[k] = exp(-2 pi i k / n).
+template <int R, int BPL, bool INV>
+__device__ __forceinline__ void stockham_stage(float2 *ln, const float2 *tw, int n, int log2n, int lNs) {
+    const int lane = threadIdx.x & 63;
+    const int nb = n / R;              // butterflies in the line
+    const int Ns = 1 << lNs;
+    const int tstep = n >> (lNs + (R == 16 ? 4 : (R == 8 ? 3 : 2)));  // n / (Ns R)
+    float2 a[BPL][R];
+#pragma unroll
+    for (int i = 0; i < BPL; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nb) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) a[i][t] = ln[PADI(j + t * nb)];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BPL; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nb) {
+            if (lNs > 0) {  // twiddles w^t from one table entry: powers by repeated squaring / products
+                const int r = j & (Ns - 1);
+                float2 w1 = tw[r * tstep];
+                if (INV) w1 = cconj(w1);
+                float2 w[R];
+                w[1] = w1;
+#pragma unroll
+                for (int t = 2; t < R; ++t) w[t] = (t & 1) ? cmul(w[t - 1], w1) : cmul(w[t / 2], w[t / 2]);
+#pragma unroll
+                for (int t = 1; t < R; ++t) a[i][t] = cmul(a[i][t], w[t]);
+            }
+            Dft<R, INV>::run(a[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BPL; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nb) {
+            const int base = ((j >> lNs) << (lNs + (R == 16 ? 4 : (R == 8 ? 3 : 2)))) + (j & (Ns - 1));
+#pragma unroll
+            for (int t = 0; t < R; ++t) ln[PADI(base + (t << lNs))] = a[i][t];
+        }
+    }
 }
 
-// LDS addressing: element e of a line lives at PADI(e) = e + e/32 and lines are NP(n) = n + n/32
-// apart.  The extra slot per 32 elements breaks the power-of-two strides of the small-span stages
-// (span 4 and 16 butterflies are 4-way bank conflicts without it).
-#define PADI(e) ((e) + ((e) >> 5))
-#define NP(n) ((n) + ((n) >> 5))
-
-// forward DIF on `nlines` lines of length n in LDS, all threads of the workgroup.
-// tw[t] = exp(-2 pi i t / n).
-__device__ __forceinline__ void fft_forward_lds(float2 *buf, const float2 *tw, int n, int log2n, int nlines) {
-    const int nq = n >> 2, lnq = log2n - 2;
-    int L = n, lL = log2n;
-    for (; L >= 4; L >>= 2, lL -= 2) {
-        const int q = L >> 2, lq = lL - 2, lts = log2n - lL;
-        for (int b = threadIdx.x; b < nlines * nq; b += FBLK) {
-            const int line = b >> lnq, idx = b & (nq - 1);
-            const int g = (idx >> lq) << lL, j = idx & (q - 1);
-            float2 *ln = buf + line * NP(n);
-            const int e0 = g + j, i0 = PADI(e0), i1 = PADI(e0 + q), i2 = PADI(e0 + 2 * q), i3 = PADI(e0 + 3 * q);
-            const int ts = 1 << lts;
-            const float2 a0 = ln[i0], a1 = ln[i1], a2 = ln[i2], a3 = ln[i3];
-            const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
-            ln[i0] = cadd(s02, s13);
-            ln[i1] = cmul(cadd(d02, d13), tw[j * ts]);
-            ln[i2] = cmul(csub(s02, s13), tw[2 * j * ts]);
-            ln[i3] = cmul(csub(d02, d13), tw[3 * j * ts]);
-        }
-        __syncthreads();
-    }
-    if (L == 2) {
-        const int nh = n >> 1;
-        for (int b = threadIdx.x; b < nlines * nh; b += FBLK) {
-            const int line = b >> (log2n - 1), e = (b & (nh - 1)) << 1;
-            float2 *p = buf + line * NP(n) + PADI(e);  // e even: e and e+1 share a 32-group
-            const float2 a0 = p[0], a1 = p[1];
-            p[0] = cadd(a0, a1);
-            p[1] = csub(a0, a1);
-        }
-        __syncthreads();
-    }
+// forward / inverse FFT of the 8 lines of the workgroup (wave w owns line w); barriers only publish a
+// stage's outputs (the next stage of the same wave reads what other lanes of that wave wrote)
+// Orders a wavefront's LDS writes before its later LDS reads (the hardware executes one wave's LDS
+// operations in order; this only stops the compiler from moving them) without stopping the other waves.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// inverse DIT (unnormalised), digit-reversed in, natural out
-__device__ __forceinline__ void fft_inverse_lds(float2 *buf, const float2 *tw, int n, int log2n, int nlines) {
-    const int nq = n >> 2, lnq = log2n - 2;
-    int L = 4, lL = 2;
-    if (log2n & 1) {
-        const int nh = n >> 1;
-        for (int b = threadIdx.x; b < nlines * nh; b += FBLK) {
-            const int line = b >> (log2n - 1), e = (b & (nh - 1)) << 1;
-            float2 *p = buf + line * NP(n) + PADI(e);  // e even: e and e+1 share a 32-group
-            const float2 a0 = p[0], a1 = p[1];
-            p[0] = cadd(a0, a1);
-            p[1] = csub(a0, a1);
-        }
-        __syncthreads();
-        L = 8, lL = 3;
+// WAVE_ONLY: the line was loaded by, and will be stored by, its own wave (contiguous lines): no workgroup
+// barrier at all, so the 8 waves drift apart and one wave's loads overlap another's butterflies.
+template <bool INV, bool WAVE_ONLY = false>
+__device__ __forceinline__ void fft_lines_lds(float2 *buf, const float2 *tw, int n, int log2n) {
+#define FFTP_SYNC() (WAVE_ONLY ? wave_lds_fence() : __syncthreads())
+    float2 *ln = buf + (threadIdx.x >> 6) * NP(n);
+    switch (log2n) {
+        case 10:  // 16 * 16 * 4
+            stockham_stage<16, 1, INV>(ln, tw, n, log2n, 0);
+            FFTP_SYNC();
+            stockham_stage<16, 1, INV>(ln, tw, n, log2n, 4);
+            FFTP_SYNC();
+            stockham_stage<4, 4, INV>(ln, tw, n, log2n, 8);
+            break;
+        case 9:  // 8 * 8 * 8
+            stockham_stage<8, 1, INV>(ln, tw, n, log2n, 0);
+            FFTP_SYNC();
+            stockham_stage<8, 1, INV>(ln, tw, n, log2n, 3);
+            FFTP_SYNC();
+            stockham_stage<8, 1, INV>(ln, tw, n, log2n, 6);
+            break;
+        case 8:  // 16 * 16
+            stockham_stage<16, 1, INV>(ln, tw, n, log2n, 0);
+            FFTP_SYNC();
+            stockham_stage<16, 1, INV>(ln, tw, n, log2n, 4);
+            break;
+        case 7:  // 8 * 16
+            stockham_stage<8, 1, INV>(ln, tw, n, log2n, 0);
+            FFTP_SYNC();
+            stockham_stage<16, 1, INV>(ln, tw, n, log2n, 3);
+            break;
+        case 6:  // 8 * 8
+            stockham_stage<8, 1, INV>(ln, tw, n, log2n, 0);
+            FFTP_SYNC();
+            stockham_stage<8, 1, INV>(ln, tw, n, log2n, 3);
+            break;
+        default:  // 32 = 8 * 4
+            stockham_stage<8, 1, INV>(ln, tw, n, log2n, 0);
+            FFTP_SYNC();
+            stockham_stage<4, 1, INV>(ln, tw, n, log2n, 3);
+            break;
     }
-    for (; L <= n; L <<= 2, lL += 2) {
-        const int q = L >> 2, lq = lL - 2, ts = 1 << (log2n - lL);
-        for (int b = threadIdx.x; b < nlines * nq; b += FBLK) {
-            const int line = b >> lnq, idx = b & (nq - 1);
-            const int g = (idx >> lq) << lL, j = idx & (q - 1);
-            float2 *ln = buf + line * NP(n);
-            const int e0 = g + j, i0 = PADI(e0), i1 = PADI(e0 + q), i2 = PADI(e0 + 2 * q), i3 = PADI(e0 + 3 * q);
-            const float2 t0 = ln[i0], t1 = cmul(ln[i1], cconj(tw[j * ts])), t2 = cmul(ln[i2], cconj(tw[2 * j * ts])),
-                         t3 = cmul(ln[i3], cconj(tw[3 * j * ts]));
-            const float2 s02 = cadd(t0, t2), d02 = csub(t0, t2), s13 = cadd(t1, t3), d13 = mul_pi(csub(t1, t3));
-            ln[i0] = cadd(s02, s13);
-            ln[i1] = cadd(d02, d13);
-            ln[i2] = csub(s02, s13);
-            ln[i3] = csub(d02, d13);
-        }
-        __syncthreads();
-    }
+    FFTP_SYNC();
+#undef FFTP_SYNC
+}
+__device__ __forceinline__ void fft_forward_lds(float2 *buf, const float2 *tw, int n, int log2n, int) {
+    fft_lines_lds<false>(buf, tw, n, log2n);
+}
+__device__ __forceinline__ void fft_inverse_lds(float2 *buf, const float2 *tw, int n, int log2n, int) {
+    fft_lines_lds<true>(buf, tw, n, log2n);
 }
 
-// twiddles, then the frequency -> position permutation (n ints right behind the n twiddles)
-__device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restrict__ g_tw, int n, int log2n) {
-    int *perm = reinterpret_cast<int *>(tw + n);
-    for (int t = threadIdx.x; t < n; t += FBLK) {
-        tw[t] = g_tw[t];
-        perm[t] = pos_of_freq(t, log2n);
-    }
+__device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restrict__ g_tw, int n, int) {
+    for (int t = threadIdx.x; t < n; t += FBLK) tw[t] = g_tw[t];
 }
 
 // 8 contiguous complex lines <-> LDS: 16-byte global accesses, two 8-byte LDS accesses (a pair
-// (e, e+1) with e even never straddles a 32-group, but its padded address may be odd)
+// (e, e+1) with e even never straddles a 16-group, but its padded address may be odd)
 __device__ __forceinline__ void lds_load_lines(float2 *buf, const float2 *__restrict__ src, int n, int log2n) {
     const float4 *src4 = reinterpret_cast<const float4 *>(src);
     for (int t = threadIdx.x; t < 8 * n / 2; t += FBLK) {
@@ -169,14 +239,13 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
     const int nh = (n >> 1) + 1;
     const int64_t line0 = (int64_t)blockIdx.x * 16;  // flat (x*n + y) index of the first real line
     load_twiddles(tw, g_tw, n, log2n);
-    const int *perm = reinterpret_cast<const int *>(tw + n);
     {   // contiguous load of 16*n floats; real line 2m -> re, 2m+1 -> im of complex line m
         const float4 *src = reinterpret_cast<const float4 *>(rho + line0 * n);
         const int nq = n >> 2;
         for (int t = threadIdx.x; t < 16 * nq; t += FBLK) {
             const int rl = t / nq, z0 = (t - rl * nq) << 2;
             const float4 v = src[t];
-            // z0 is a multiple of 4: z0..z0+3 share a 32-group, so the four slots stay contiguous
+            // z0 is a multiple of 4: z0..z0+3 share a 16-group, so the four slots stay contiguous
             float *dst = reinterpret_cast<float *>(buf + (rl >> 1) * NP(n) + PADI(z0)) + (rl & 1);
             dst[0] = v.x, dst[2] = v.y, dst[4] = v.z, dst[6] = v.w;
         }
@@ -189,7 +258,7 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
     const int m = threadIdx.x & 7;
     const float2 *ln = buf + m * NP(n);
     for (int kz = threadIdx.x >> 3; kz < nh; kz += FBLK / 8) {
-        const float2 zk = ln[PADI(perm[kz])], zn = cconj(ln[PADI(perm[(n - kz) & (n - 1)])]);
+        const float2 zk = ln[PADI(kz)], zn = cconj(ln[PADI((n - kz) & (n - 1))]);
         const float2 d = csub(zk, zn);
         // A[k] = (Z[k] + conj Z[n-k]) / 2 ;  B[k] = (Z[k] - conj Z[n-k]) / (2i)
         const float4 v = make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y), 0.5f * d.y, -0.5f * d.x);
@@ -205,51 +274,34 @@ __global__ __launch_bounds__(FBLK) void fftp_y(float2 *__restrict__ B, float2 *_
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *buf = lds, *tw = lds + 8 * NP(n);
     const int nh = (n >> 1) + 1;
-    const int64_t line0 = (int64_t)blockIdx.x * 8;  // flat (kz*nx + x), nx = local x planes (multiple of 8)
+    // A workgroup touches C in 64-byte pieces (8 x-values per (ky, kz)); the other half of each 128-byte
+    // line belongs to the next group of 8 lines.  Workgroups b and b + 8 land on the same XCD back to back
+    // (round-robin dispatch), so they are given such neighbouring groups: the halves meet in that XCD's L2
+    // and HBM sees whole lines (PMC before: the inverse pass fetched 2x its bytes).
+    unsigned grp = blockIdx.x;
+    if (grp < (gridDim.x & ~15u)) grp = (grp & ~15u) + ((grp & 7u) << 1) + ((grp >> 3) & 1u);
+    const int64_t line0 = (int64_t)grp * 8;  // flat (kz*nx + x), nx = local x planes (multiple of 8)
     const int kz = (int)(line0 / nx), x0 = (int)(line0 - (int64_t)kz * nx);
     load_twiddles(tw, g_tw, n, log2n);
-    const int *perm = reinterpret_cast<const int *>(tw + n);
     const int lx = threadIdx.x & 7;
-    if (!FORWARD) __syncthreads();  // the transposed load below reads the permutation table
     if (FORWARD) {
         lds_load_lines(buf, B + line0 * n, n, log2n);
         __syncthreads();
         fft_forward_lds(buf, tw, n, log2n, 8);
         for (int ky = threadIdx.x >> 3; ky < n; ky += FBLK / 8)
-            C[((int64_t)ky * nh + kz) * nx + x0 + lx] = buf[lx * NP(n) + PADI(perm[ky])];
+            C[((int64_t)ky * nh + kz) * nx + x0 + lx] = buf[lx * NP(n) + PADI(ky)];
     } else {
         for (int ky = threadIdx.x >> 3; ky < n; ky += FBLK / 8)
-            buf[lx * NP(n) + PADI(perm[ky])] = C[((int64_t)ky * nh + kz) * nx + x0 + lx];
+            buf[lx * NP(n) + PADI(ky)] = C[((int64_t)ky * nh + kz) * nx + x0 + lx];
         __syncthreads();
         fft_inverse_lds(buf, tw, n, log2n, 8);
         lds_store_lines(buf, B + line0 * n, n, log2n);
     }
 }
 
-// 8 x-lines <-> LDS when a line is stored as nseg segments of nx elements: element x of line l lives
-// at ((x / nx) * nlines_total + l) * nx + x % nx (nseg = 1: plain contiguous lines).  This is the
-// layout an all-to-all over x-slabs delivers: [source rank][ky_local][kz][x_local].
-__device__ __forceinline__ void lds_load_seg_lines(float2 *buf, const float2 *__restrict__ base, int64_t line0,
-                                                   int64_t nlines_total, int n, int log2n, int nx) {
-    for (int t = threadIdx.x; t < 8 * n / 2; t += FBLK) {
-        const int line = (2 * t) >> log2n, e = (2 * t) & (n - 1);
-        const int seg = e / nx, xl = e - seg * nx;
-        const float4 v = *reinterpret_cast<const float4 *>(base + ((int64_t)seg * nlines_total + line0 + line) * nx + xl);
-        float2 *d = buf + line * NP(n) + PADI(e);
-        d[0] = make_float2(v.x, v.y);
-        d[1] = make_float2(v.z, v.w);
-    }
-}
-__device__ __forceinline__ void lds_store_seg_lines(const float2 *buf, float2 *__restrict__ base, int64_t line0,
-                                                    int64_t nlines_total, int n, int log2n, int nx) {
-    for (int t = threadIdx.x; t < 8 * n / 2; t += FBLK) {
-        const int line = (2 * t) >> log2n, e = (2 * t) & (n - 1);
-        const int seg = e / nx, xl = e - seg * nx;
-        const float2 *s2 = buf + line * NP(n) + PADI(e);
-        *reinterpret_cast<float4 *>(base + ((int64_t)seg * nlines_total + line0 + line) * nx + xl) =
-            make_float4(s2[0].x, s2[0].y, s2[1].x, s2[1].y);
-    }
-}
+// A line of the x pass is stored as nseg segments of nx elements: element x of line l lives at
+// ((x / nx) * nlines_total + l) * nx + x % nx (nseg = 1: plain contiguous lines).  This is the layout an
+// all-to-all over x-slabs delivers: [source rank][ky_local][kz][x_local].
 
 // ---- P3: x forward, Green's function, x inverse, in place ----------------------------------------------
 // workgroup = 8 consecutive lines (ky_local, kz) of C viewed as [nseg][nky*nh lines][nx]; ky0 = global
@@ -264,43 +316,48 @@ __global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, con
     const int nh = (n >> 1) + 1;
     const int64_t line0 = (int64_t)blockIdx.x * 8;
     load_twiddles(tw, g_tw, n, log2n);
-    const int *perm = reinterpret_cast<const int *>(tw + n);
     const int64_t nlines_total = (int64_t)nky * nh;
-    lds_load_seg_lines(buf, C, line0, nlines_total, n, log2n, nx);
-    __syncthreads();
-    // this pass needs position -> frequency: invert the table in place (each slot written once)
-    int *kxof = reinterpret_cast<int *>(tw + n);
+    __syncthreads();  // twiddle table; from here on every wave works on its own line, no workgroup barrier
+    const int l = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t line = line0 + l;
+    float2 *ln = buf + l * NP(n);
+    for (int e = 2 * lane; e < n; e += 128) {  // 16-byte accesses: elements (e, e+1), e even
+        const int seg = e / nx, xl = e - seg * nx;
+        const float4 v = *reinterpret_cast<const float4 *>(C + ((int64_t)seg * nlines_total + line) * nx + xl);
+        float2 *d = ln + PADI(e);
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
+    }
+    wave_lds_fence();
+    fft_lines_lds<false, true>(buf, tw, n, log2n);
     {
-        int mine[(1024 + FBLK - 1) / FBLK];
-        for (int t = threadIdx.x, u = 0; t < n; t += FBLK, ++u) mine[u] = perm[t];
-        __syncthreads();
-        for (int t = threadIdx.x, u = 0; t < n; t += FBLK, ++u) kxof[mine[u]] = t;
-    }
-    fft_forward_lds(buf, tw, n, log2n, 8);
-    for (int t = threadIdx.x; t < 8 * n; t += FBLK) {
-        const int l = t >> log2n, pos = t & (n - 1);
-        const int64_t line = line0 + l;
         const int kyl = (int)(line / nh), kz = (int)(line - (int64_t)kyl * nh), ky = ky0 + kyl;
-        const int kx = kxof[pos];
-        float g;  // fourier.py:460-595; for the compensated kernel `s` already holds sinc^(-2p) per axis
-        if (KIND == PM_GREEN_7PT) {
-            g = c0 / ((s[kx] + s[ky]) + s[kz]);
-        } else {
-            const float invk2 = c0 / ((k2[kx] + k2[ky]) + k2[kz]);
-            g = (KIND == PM_GREEN_COMPENSATED) ? ((s[kx] * s[ky]) * s[kz]) * invk2 : invk2;
+        for (int kx = lane; kx < n; kx += 64) {
+            float g;  // fourier.py:460-595; for the compensated kernel `s` already holds sinc^(-2p) per axis
+            if (KIND == PM_GREEN_7PT) {
+                g = c0 / ((s[kx] + s[ky]) + s[kz]);
+            } else {
+                const float invk2 = c0 / ((k2[kx] + k2[ky]) + k2[kz]);
+                g = (KIND == PM_GREEN_COMPENSATED) ? ((s[kx] * s[ky]) * s[kz]) * invk2 : invk2;
+            }
+            g *= norm;  // 1/n^3 of the inverse transform
+            float2 *slot = ln + PADI(kx);
+            float2 v = *slot;
+            if ((kx | ky | kz) == 0)
+                v = make_float2(0.f, 0.f);
+            else
+                v.x *= g, v.y *= g;
+            *slot = v;
         }
-        g *= norm;  // 1/n^3 of the inverse transform
-        float2 *slot = buf + l * NP(n) + PADI(pos);
-        float2 v = *slot;
-        if ((kx | ky | kz) == 0)
-            v = make_float2(0.f, 0.f);
-        else
-            v.x *= g, v.y *= g;
-        *slot = v;
     }
-    __syncthreads();
-    fft_inverse_lds(buf, tw, n, log2n, 8);
-    lds_store_seg_lines(buf, C, line0, nlines_total, n, log2n, nx);
+    wave_lds_fence();
+    fft_lines_lds<true, true>(buf, tw, n, log2n);
+    for (int e = 2 * lane; e < n; e += 128) {
+        const int seg = e / nx, xl = e - seg * nx;
+        const float2 *s2 = ln + PADI(e);
+        *reinterpret_cast<float4 *>(C + ((int64_t)seg * nlines_total + line) * nx + xl) =
+            make_float4(s2[0].x, s2[0].y, s2[1].x, s2[1].y);
+    }
 }
 
 // ---- P5: z c2r, transposed read ---------------------------------------------------------------------------
@@ -312,10 +369,8 @@ __global__ __launch_bounds__(FBLK) void fftp_z_c2r(const float2 *__restrict__ B,
     const int64_t line0 = (int64_t)blockIdx.x * 16;
     const int x = (int)(line0 >> log2n), y0 = (int)(line0 & (n - 1));
     load_twiddles(tw, g_tw, n, log2n);
-    const int *perm = reinterpret_cast<const int *>(tw + n);
     // Z = A + iB: thread = (complex line m, kz) loads the adjacent pair (A[kz], B[kz]) with one 16-byte
     // load and writes Z[k] = A + iB and Z[n-k] = conj(A) + i conj(B)
-    __syncthreads();  // permutation table ready
     {
         const int m = threadIdx.x & 7;
         float2 *ln = buf + m * NP(n);
@@ -324,9 +379,9 @@ __global__ __launch_bounds__(FBLK) void fftp_z_c2r(const float2 *__restrict__ B,
             const bool edge = (kz == 0) || (kz == (n >> 1));
             if (edge) v.y = 0.f, v.w = 0.f;  // c2r ignores the imaginary part of DC / Nyquist
             // A = (v.x, v.y), Bh = (v.z, v.w):  A + i Bh = (v.x - v.w, v.y + v.z)
-            ln[PADI(perm[kz])] = make_float2(v.x - v.w, v.y + v.z);
+            ln[PADI(kz)] = make_float2(v.x - v.w, v.y + v.z);
             // conj(A) + i conj(Bh) = (v.x + v.w, -v.y + v.z)
-            if (!edge) ln[PADI(perm[n - kz])] = make_float2(v.x + v.w, v.z - v.y);
+            if (!edge) ln[PADI(n - kz)] = make_float2(v.x + v.w, v.z - v.y);
         }
     }
     __syncthreads();
@@ -382,7 +437,7 @@ static int ensure_fused_buffers(pm_ctx *c, size_t b_bytes, size_t c_bytes) {
 }
 
 static inline size_t fftp_lds_bytes(int n) {
-    return (size_t)(8 * (n + n / 32) + n) * sizeof(float2) + (size_t)n * sizeof(int);
+    return (size_t)(8 * (n + n / 16) + n) * sizeof(float2);
 }
 
 #define FFTP_CHECK_N(c)                                                                                        \
