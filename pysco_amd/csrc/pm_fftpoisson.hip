@@ -6,11 +6,17 @@
 // array is never transposed on its own, and the x pass does forward FFT -> Green's function ->
 // inverse FFT on each line while it sits in LDS:
 //
-//   P1  rho[x][y][z] (real)   --z r2c-->            B[kz][x][y]        two real lines per complex FFT
-//   P2  B[kz][x][y]           --y forward-->        C[ky][kz][x]
+//   P1  rho[x][y][z] (real)   --z r2c-->            B[x/8][kz][x%8][y] two real lines per complex FFT
+//   P2  B                     --y forward-->        C[ky][kz][x]  (single GPU: C[kz][ky][x])
 //   P3  C[ky][kz][x]          --x forward, *G(k)/n^3, x inverse-->  C   (in place, contiguous lines)
-//   P4  C[ky][kz][x]          --y inverse-->        B[kz][x][y]
-//   P5  B[kz][x][y]           --z c2r-->            phi[x][y][z] (real)
+//   P4  C                     --y inverse-->        B
+//   P5  B                     --z c2r-->            phi[x][y][z] (real)
+// Layouts are chosen for the locality of the transposed (scattered) side of each pass -- measured: the
+// 64/128-byte pieces of one workgroup a whole plane apart cost 15-20 % of the pass against a few KB apart.
+// B is blocked by 8 x-planes, so the 8 lines of a y-pass workgroup are one contiguous 64 KB and the pieces a
+// z-pass workgroup scatters over kz are 64 KB apart; on a single GPU C is kz-major, so the pieces a y-pass
+// workgroup scatters over ky are one x-line apart (the slab entry points keep C[ky][kz][x_local], whose
+// ky blocks are what the all-to-all ships).
 //
 // 1-D FFTs: one wavefront per line, Stockham autosort stages of radix 16 / 8 / 4 with the butterfly in
 // registers (1024 = 16 * 16 * 4: a lane holds 16 points) and the line exchanged through LDS between
@@ -30,11 +36,13 @@ __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
 __device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
 
-// LDS addressing: element e of a line lives at PADI(e) = e + e/16 and lines are NP(n) = n + n/16 apart.
+// LDS addressing: element e of a line lives at PADI(e) = e + e/16 and lines are NP(n) = n + n/16 + 4 apart.
 // The extra slot per 16 elements spreads the stride-16 (and stride-8) scatter of a stage's outputs over
-// the banks (16 lanes x 128 B apart would be a 16-way conflict).
+// the banks (16 lanes x 128 B apart would be a 16-way conflict); the 4 extra elements per line put the
+// 8 lines 8 banks apart, so the transposed passes' (line, frequency) accesses -- 8 lines x 4 consecutive
+// frequencies per 32-lane group -- hit 32 different bank pairs instead of 4.
 #define PADI(e) ((e) + ((e) >> 4))
-#define NP(n) ((n) + ((n) >> 4))
+#define NP(n) ((n) + ((n) >> 4) + 4)
 
 // R-point DFTs in registers, natural order in and out.  INV: conjugate transform (unnormalised).
 template <bool INV>
@@ -211,22 +219,22 @@ __device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restri
 
 // 8 contiguous complex lines <-> LDS: 16-byte global accesses, two 8-byte LDS accesses (a pair
 // (e, e+1) with e even never straddles a 16-group, but its padded address may be odd)
-__device__ __forceinline__ void lds_load_lines(float2 *buf, const float2 *__restrict__ src, int n, int log2n) {
-    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+__device__ __forceinline__ void lds_load_lines(float2 *buf, const float2 *__restrict__ src, int64_t line_stride,
+                                               int n, int log2n) {
     for (int t = threadIdx.x; t < 8 * n / 2; t += FBLK) {
-        const float4 v = src4[t];
         const int line = (2 * t) >> log2n, e = (2 * t) & (n - 1);
+        const float4 v = *reinterpret_cast<const float4 *>(src + line * line_stride + e);
         float2 *d = buf + line * NP(n) + PADI(e);
         d[0] = make_float2(v.x, v.y);
         d[1] = make_float2(v.z, v.w);
     }
 }
-__device__ __forceinline__ void lds_store_lines(const float2 *buf, float2 *__restrict__ dst, int n, int log2n) {
-    float4 *dst4 = reinterpret_cast<float4 *>(dst);
+__device__ __forceinline__ void lds_store_lines(const float2 *buf, float2 *__restrict__ dst, int64_t line_stride, int n,
+                                                int log2n) {
     for (int t = threadIdx.x; t < 8 * n / 2; t += FBLK) {
         const int line = (2 * t) >> log2n, e = (2 * t) & (n - 1);
         const float2 *s2 = buf + line * NP(n) + PADI(e);
-        dst4[t] = make_float4(s2[0].x, s2[0].y, s2[1].x, s2[1].y);
+        *reinterpret_cast<float4 *>(dst + line * line_stride + e) = make_float4(s2[0].x, s2[0].y, s2[1].x, s2[1].y);
     }
 }
 
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
     }
     __syncthreads();
     fft_forward_lds(buf, tw, n, log2n, 8);
-    // unpack and write B[kz][x][y]: thread = (complex line m, kz) -> the two real lines' spectra A, B are
+    // unpack and write B[x][kz][y]: thread = (complex line m, kz) -> the two real lines' spectra A, B are
     // adjacent in y: one 16-byte store; 8 threads cover the 128 B of one kz
     const int x = (int)(line0 >> log2n), y0 = (int)(line0 & (n - 1));
     const int m = threadIdx.x & 7;
@@ -262,15 +270,23 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
         const float2 d = csub(zk, zn);
         // A[k] = (Z[k] + conj Z[n-k]) / 2 ;  B[k] = (Z[k] - conj Z[n-k]) / (2i)
         const float4 v = make_float4(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y), 0.5f * d.y, -0.5f * d.x);
-        *reinterpret_cast<float4 *>(B + ((int64_t)kz * nx + x) * n + y0 + 2 * m) = v;
+        *reinterpret_cast<float4 *>(B + ((((int64_t)(x >> 3) * nh + kz) << 3) + (x & 7)) * n + y0 + 2 * m) = v;
     }
+}
+
+// element (ky, kz, x) of C: C[ky][kz][x] with nx local x values (slab layout), C[kz][ky][x] on a single GPU.
+// (Tried: (ky pair, 8 x) tiles so that a y-pass workgroup moves whole 128-byte lines -- the y passes gained
+// what the x pass, then reading 64-byte pieces, lost.)
+__device__ __forceinline__ int64_t c_index(int ky, int kz, int x, int n, int nh, int nx, int kzmajor) {
+    return (kzmajor ? (int64_t)kz * n + ky : (int64_t)ky * nh + kz) * nx + x;
 }
 
 // ---- P2 / P4: y transform with transposed global side ------------------------------------------------
 // workgroup = 8 lines (kz fixed, x0..x0+7).  FORWARD: B -> C, else C -> B.
 template <bool FORWARD>
 __global__ __launch_bounds__(FBLK) void fftp_y(float2 *__restrict__ B, float2 *__restrict__ C,
-                                               const float2 *__restrict__ g_tw, int n, int log2n, int nx) {
+                                               const float2 *__restrict__ g_tw, int n, int log2n, int nx,
+                                               int kzmajor) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *buf = lds, *tw = lds + 8 * NP(n);
     const int nh = (n >> 1) + 1;
@@ -283,19 +299,25 @@ __global__ __launch_bounds__(FBLK) void fftp_y(float2 *__restrict__ B, float2 *_
     const int64_t line0 = (int64_t)grp * 8;  // flat (kz*nx + x), nx = local x planes (multiple of 8)
     const int kz = (int)(line0 / nx), x0 = (int)(line0 - (int64_t)kz * nx);
     load_twiddles(tw, g_tw, n, log2n);
-    const int lx = threadIdx.x & 7;
+    // transposed side: thread = (ky, pair of x) -> one 16-byte access; 4 lanes cover the 64-byte piece
+    const int lx = (threadIdx.x & 3) << 1;
     if (FORWARD) {
-        lds_load_lines(buf, B + line0 * n, n, log2n);
+        lds_load_lines(buf, B + (((int64_t)(x0 >> 3) * nh + kz) << 3) * n, n, n, log2n);
         __syncthreads();
         fft_forward_lds(buf, tw, n, log2n, 8);
-        for (int ky = threadIdx.x >> 3; ky < n; ky += FBLK / 8)
-            C[((int64_t)ky * nh + kz) * nx + x0 + lx] = buf[lx * NP(n) + PADI(ky)];
+        for (int ky = threadIdx.x >> 2; ky < n; ky += FBLK / 4) {
+            const float2 a = buf[lx * NP(n) + PADI(ky)], b = buf[(lx + 1) * NP(n) + PADI(ky)];
+            *reinterpret_cast<float4 *>(C + c_index(ky, kz, x0 + lx, n, nh, nx, kzmajor)) = make_float4(a.x, a.y, b.x, b.y);
+        }
     } else {
-        for (int ky = threadIdx.x >> 3; ky < n; ky += FBLK / 8)
-            buf[lx * NP(n) + PADI(ky)] = C[((int64_t)ky * nh + kz) * nx + x0 + lx];
+        for (int ky = threadIdx.x >> 2; ky < n; ky += FBLK / 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(C + c_index(ky, kz, x0 + lx, n, nh, nx, kzmajor));
+            buf[lx * NP(n) + PADI(ky)] = make_float2(v.x, v.y);
+            buf[(lx + 1) * NP(n) + PADI(ky)] = make_float2(v.z, v.w);
+        }
         __syncthreads();
         fft_inverse_lds(buf, tw, n, log2n, 8);
-        lds_store_lines(buf, B + line0 * n, n, log2n);
+        lds_store_lines(buf, B + (((int64_t)(x0 >> 3) * nh + kz) << 3) * n, n, n, log2n);
     }
 }
 
@@ -310,7 +332,7 @@ template <int KIND>
 __global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, const float2 *__restrict__ g_tw, int n,
                                                      int log2n, int p, const float *__restrict__ k2,
                                                      const float *__restrict__ s, float c0, float norm, int nx,
-                                                     int nky, int ky0) {
+                                                     int nky, int ky0, int kzmajor) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *buf = lds, *tw = lds + 8 * NP(n);
     const int nh = (n >> 1) + 1;
@@ -321,9 +343,16 @@ __global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, con
     const int l = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t line = line0 + l;
     float2 *ln = buf + l * NP(n);
-    for (int e = 2 * lane; e < n; e += 128) {  // 16-byte accesses: elements (e, e+1), e even
+    // line index: ky_local * nh + kz, or kz * n + ky on a single GPU (kzmajor, where nseg = 1)
+    const int kyl = kzmajor ? (int)(line & (n - 1)) : (int)(line / nh);
+    const int kz = kzmajor ? (int)(line >> log2n) : (int)(line - (int64_t)kyl * nh), ky = ky0 + kyl;
+    auto xaddr = [&](int e) -> int64_t {
+        if (kzmajor) return c_index(kyl, kz, e, n, nh, nx, 1);
         const int seg = e / nx, xl = e - seg * nx;
-        const float4 v = *reinterpret_cast<const float4 *>(C + ((int64_t)seg * nlines_total + line) * nx + xl);
+        return ((int64_t)seg * nlines_total + line) * nx + xl;
+    };
+    for (int e = 2 * lane; e < n; e += 128) {  // 16-byte accesses: elements (e, e+1), e even
+        const float4 v = *reinterpret_cast<const float4 *>(C + xaddr(e));
         float2 *d = ln + PADI(e);
         d[0] = make_float2(v.x, v.y);
         d[1] = make_float2(v.z, v.w);
@@ -331,7 +360,6 @@ __global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, con
     wave_lds_fence();
     fft_lines_lds<false, true>(buf, tw, n, log2n);
     {
-        const int kyl = (int)(line / nh), kz = (int)(line - (int64_t)kyl * nh), ky = ky0 + kyl;
         for (int kx = lane; kx < n; kx += 64) {
             float g;  // fourier.py:460-595; for the compensated kernel `s` already holds sinc^(-2p) per axis
             if (KIND == PM_GREEN_7PT) {
@@ -353,10 +381,8 @@ __global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, con
     wave_lds_fence();
     fft_lines_lds<true, true>(buf, tw, n, log2n);
     for (int e = 2 * lane; e < n; e += 128) {
-        const int seg = e / nx, xl = e - seg * nx;
         const float2 *s2 = ln + PADI(e);
-        *reinterpret_cast<float4 *>(C + ((int64_t)seg * nlines_total + line) * nx + xl) =
-            make_float4(s2[0].x, s2[0].y, s2[1].x, s2[1].y);
+        *reinterpret_cast<float4 *>(C + xaddr(e)) = make_float4(s2[0].x, s2[0].y, s2[1].x, s2[1].y);
     }
 }
 
@@ -375,7 +401,7 @@ __global__ __launch_bounds__(FBLK) void fftp_z_c2r(const float2 *__restrict__ B,
         const int m = threadIdx.x & 7;
         float2 *ln = buf + m * NP(n);
         for (int kz = threadIdx.x >> 3; kz < nh; kz += FBLK / 8) {
-            float4 v = *reinterpret_cast<const float4 *>(B + ((int64_t)kz * nx + x) * n + y0 + 2 * m);
+            float4 v = *reinterpret_cast<const float4 *>(B + ((((int64_t)(x >> 3) * nh + kz) << 3) + (x & 7)) * n + y0 + 2 * m);
             const bool edge = (kz == 0) || (kz == (n >> 1));
             if (edge) v.y = 0.f, v.w = 0.f;  // c2r ignores the imaginary part of DC / Nyquist
             // A = (v.x, v.y), Bh = (v.z, v.w):  A + i Bh = (v.x - v.w, v.y + v.z)
@@ -437,14 +463,14 @@ static int ensure_fused_buffers(pm_ctx *c, size_t b_bytes, size_t c_bytes) {
 }
 
 static inline size_t fftp_lds_bytes(int n) {
-    return (size_t)(8 * (n + n / 16) + n) * sizeof(float2);
+    return (size_t)(8 * NP(n) + n) * sizeof(float2);
 }
 
 #define FFTP_CHECK_N(c)                                                                                        \
     PM_REQUIRE((c)->n >= 32 && (c)->n <= 1024, "LDS-FFT passes support 32 <= n <= 1024 (use the rocFFT entry points otherwise)")
 
 // P1 + P2 on nx local x-planes: d_rhs [nx, n, n] real -> d_C [n (ky), n/2+1 (kz), nx] complex
-extern "C" int pm_fftp_forward(pm_ctx *c, const float *d_rhs, int nx, void *d_C) {
+static int fftp_forward_impl(pm_ctx *c, const float *d_rhs, int nx, void *d_C, int kzmajor) {
     PM_REQUIRE(c && d_rhs && d_C, "NULL argument");
     FFTP_CHECK_N(c);
     const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
@@ -457,13 +483,17 @@ extern "C" int pm_fftp_forward(pm_ctx *c, const float *d_rhs, int nx, void *d_C)
     hipLaunchKernelGGL(fftp_z_r2c, dim3((unsigned)((int64_t)nx * n / 16)), dim3(FBLK), lds, c->stream, d_rhs,
                        (float2 *)c->fp_B, tw, n, log2n, nx);
     hipLaunchKernelGGL((fftp_y<true>), dim3((unsigned)((int64_t)nh * nx / 8)), dim3(FBLK), lds, c->stream,
-                       (float2 *)c->fp_B, (float2 *)d_C, tw, n, log2n, nx);
+                       (float2 *)c->fp_B, (float2 *)d_C, tw, n, log2n, nx, kzmajor);
     PM_LAUNCH_CHECK();
     return PM_OK;
 }
 
+extern "C" int pm_fftp_forward(pm_ctx *c, const float *d_rhs, int nx, void *d_C) {
+    return fftp_forward_impl(c, d_rhs, nx, d_C, 0);
+}
+
 // P4 + P5: d_C [n, n/2+1, nx] -> d_phi [nx, n, n] real (d_C is read only)
-extern "C" int pm_fftp_inverse(pm_ctx *c, const void *d_C, int nx, float *d_phi) {
+static int fftp_inverse_impl(pm_ctx *c, const void *d_C, int nx, float *d_phi, int kzmajor) {
     PM_REQUIRE(c && d_phi && d_C, "NULL argument");
     FFTP_CHECK_N(c);
     const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
@@ -474,16 +504,20 @@ extern "C" int pm_fftp_inverse(pm_ctx *c, const void *d_C, int nx, float *d_phi)
     const float2 *tw = (const float2 *)c->fp_tw;
     const size_t lds = fftp_lds_bytes(n);
     hipLaunchKernelGGL((fftp_y<false>), dim3((unsigned)((int64_t)nh * nx / 8)), dim3(FBLK), lds, c->stream,
-                       (float2 *)c->fp_B, (float2 *)const_cast<void *>(d_C), tw, n, log2n, nx);
+                       (float2 *)c->fp_B, (float2 *)const_cast<void *>(d_C), tw, n, log2n, nx, kzmajor);
     hipLaunchKernelGGL(fftp_z_c2r, dim3((unsigned)((int64_t)nx * n / 16)), dim3(FBLK), lds, c->stream,
                        (const float2 *)c->fp_B, d_phi, tw, n, log2n, nx);
     PM_LAUNCH_CHECK();
     return PM_OK;
 }
 
+extern "C" int pm_fftp_inverse(pm_ctx *c, const void *d_C, int nx, float *d_phi) {
+    return fftp_inverse_impl(c, d_C, nx, d_phi, 0);
+}
+
 // P3 in place on d_C laid out [nseg = n/nx][nky][n/2+1][nx]: the lines (ky0 + ky_local, kz) along x
-extern "C" int pm_fftp_xgreen(pm_ctx *c, int kind, int p, void *d_C, int nx, int nky, int ky0, const float *h_k2,
-                              const float *h_s, float c0) {
+static int fftp_xgreen_impl(pm_ctx *c, int kind, int p, void *d_C, int nx, int nky, int ky0, const float *h_k2,
+                            const float *h_s, float c0, int kzmajor) {
     PM_REQUIRE(c && d_C && h_k2 && h_s, "NULL argument");
     FFTP_CHECK_N(c);
     const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
@@ -512,19 +546,24 @@ extern "C" int pm_fftp_xgreen(pm_ctx *c, int kind, int p, void *d_C, int nx, int
     switch (kind) {
         case PM_GREEN_PLAIN:
             hipLaunchKernelGGL((fftp_x_green<PM_GREEN_PLAIN>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n, log2n, p,
-                               c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0);
+                               c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0, kzmajor);
             break;
         case PM_GREEN_COMPENSATED:
             hipLaunchKernelGGL((fftp_x_green<PM_GREEN_COMPENSATED>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n,
-                               log2n, p, c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0);
+                               log2n, p, c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0, kzmajor);
             break;
         default:
             hipLaunchKernelGGL((fftp_x_green<PM_GREEN_7PT>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n, log2n, p,
-                               c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0);
+                               c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0, kzmajor);
             break;
     }
     PM_LAUNCH_CHECK();
     return PM_OK;
+}
+
+extern "C" int pm_fftp_xgreen(pm_ctx *c, int kind, int p, void *d_C, int nx, int nky, int ky0, const float *h_k2,
+                              const float *h_s, float c0) {
+    return fftp_xgreen_impl(c, kind, p, d_C, nx, nky, ky0, h_k2, h_s, c0, 0);
 }
 
 extern "C" int pm_poisson_fft_fused(pm_ctx *c, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
@@ -534,9 +573,9 @@ extern "C" int pm_poisson_fft_fused(pm_ctx *c, int kind, int p, const float *d_r
     const int n = c->n;
     int rc = ensure_fused_buffers(c, 0, (size_t)n * n * (n / 2 + 1) * sizeof(float2));
     if (rc) return rc;
-    rc = pm_fftp_forward(c, d_rhs, n, c->fp_C);
+    rc = fftp_forward_impl(c, d_rhs, n, c->fp_C, 1);  // single GPU: C is kz-major (see the header)
     if (rc) return rc;
-    rc = pm_fftp_xgreen(c, kind, p, c->fp_C, n, n, 0, h_k2, h_s, c0);
+    rc = fftp_xgreen_impl(c, kind, p, c->fp_C, n, n, 0, h_k2, h_s, c0, 1);
     if (rc) return rc;
-    return pm_fftp_inverse(c, c->fp_C, n, d_phi);
+    return fftp_inverse_impl(c, c->fp_C, n, d_phi, 1);
 }
