@@ -225,8 +225,21 @@ def main():
                       "alg_GBps": None if gbs is None else round(gbs, 1)})
     dom = table[0]
     achieved = dom["alg_GBps"] or 0.0
+    # HBM bytes the PMC counters saw for the dominant stage's kernels (per launch), from the committed
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/, tools/pmc_summary.py);
+    # only meaningful for the configuration they were collected on
+    traffic = None
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")
+    if world == 1 and n == 1024 and os.path.exists(pmc_path):
+        kernels = json.load(open(pmc_path))["kernels"]
+        stage_kernels = {"pm_gradient_interp_kick": ["interp_ranges_kernel<3, 5, true>"],
+                         "pm_kick_drift_wrap_deposit": ["kdw_deposit_kernel<3>", "deposit_list_kernel<3>"],
+                         "pm_poisson_fft_fused": ["fftp_z_r2c", "fftp_y<true>", "fftp_x_green<1>", "fftp_y<false>",
+                                                  "fftp_z_c2r"]}.get(dom["stage"], [])
+        if stage_kernels and all(k in kernels for k in stage_kernels):
+            traffic = sum(kernels[k]["hbm_bytes"] for k in stage_kernels)
     roofline = {"bound": "hbm", "kernel": dom["stage"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": round(achieved / (HBM_PEAK / 1e9), 4), "traffic": None,
+                "frac": round(achieved / (HBM_PEAK / 1e9), 4), "traffic": traffic,
                 "alg_bytes_per_launch": ab.get(dom["stage"]),
                 "step_frac": round(B_ALG_PER_PARTICLE * npart / (wall / args.steps) / (HBM_PEAK * world), 4),
                 "step_alg_bytes_per_particle": B_ALG_PER_PARTICLE, "stages": table}

@@ -24,7 +24,8 @@ def short(name):
 
 fetch, write, out = sys.argv[1:4]
 F, W = last_per_kernel(fetch), last_per_kernel(write)
-keep = ("kick_drift_wrap", "deposit_ranges", "interp_ranges", "gradient_march", "fftp_", "greens_kernel", "ew_kernel",
+keep = ("kick_drift_wrap", "kdw_deposit", "deposit_list", "deposit_ranges", "interp_ranges", "gradient_march", "fftp_",
+        "greens_kernel", "ew_kernel", "straggler_scan",
         "tile_bounds", "max_abs")
 res = {}
 for k in F:
