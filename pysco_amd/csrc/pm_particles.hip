@@ -423,7 +423,7 @@ __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, 
 // path and must not set the register budget of the kernels that call it.
 template <int SCHEME>
 __device__ __noinline__ void gather_global(const float *__restrict__ grid, float xp, float yp, float zp, int i, int j,
-                                           int k, const pm_geom &geo, float acc[3]) {
+                                           int k, pm_geom geo, float acc[3]) {
     auto at = [&](int ii, int jj, int kk) -> const float * { return grid + 3 * pm_cell(geo, ii, jj, kk); };
     acc[0] = acc[1] = acc[2] = 0.f;
     if (SCHEME == PM_NGP) {
@@ -1253,7 +1253,7 @@ struct PhiFetch {
 
 template <int SCHEME, int ORDER>
 __device__ __noinline__ void gather_phi_global(const float *__restrict__ phi, float scale, float xp, float yp, float zp,
-                                               int i, int j, int k, const pm_geom &geo, float acc[3]) {
+                                               int i, int j, int k, pm_geom geo, float acc[3]) {
     PhiFetch<ORDER> fetch{phi, geo, scale};
     acc[0] = acc[1] = acc[2] = 0.f;
     float g[3];
@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     }
     PosQueue q;
     VelQueue qv;
-    if (has_range) {
+    if (ORDER == 0 && has_range) {
         q.prime(pos, s + tid, e);
         if (KICK) qv.prime(vel, s + tid, e);
     }
@@ -1405,6 +1405,12 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                 for (int o = -R; o <= R; ++o) sa[o + 3] = ctr[o];
                 gz[u] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
             }
+        }
+        // the particle queues are primed only now: held across the fill and the differentiation their 24
+        // registers pushed the kernel into scratch (20 bytes per lane written and read back by every thread)
+        if (has_range) {
+            q.prime(pos, s + tid, e);
+            if (KICK) qv.prime(vel, s + tid, e);
         }
         __syncthreads();  // every stencil has read its potential: the buffer becomes the force tile
 #pragma unroll
