@@ -30,6 +30,14 @@ static inline int wrapn(int i, int n) {
     return i < 0 ? i + n : i;
 }
 
+void pmo_set_num_threads(int t) {
+#ifdef _OPENMP
+    if (t > 0) omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
+}
+
 int pmo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -88,10 +96,35 @@ static inline void tsc_w(float xp, int *i, float w[3]) {
     w[2] = half * (b * b);
 }
 
-/* mesh.py:2363-2462 TSC_seq (== TSC mesh.py:2468-2595 with a fixed summation order) */
+/* mesh.py:2363-2462 TSC_seq (== TSC mesh.py:2468-2595 with a fixed summation order).  The OpenMP build
+ * (cpu_baseline timing only) is the reference's parallel TSC: prange over particles + atomic adds
+ * (mesh.py:2468-2595, numpy_atomic.atomic_add), whose summation order is not fixed. */
 void pmo_tsc(const float *pos, int64_t np_, int n, float *rho) {
     const float nf = (float)n;
     memset(rho, 0, sizeof(float) * (size_t)n * n * n);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < np_; ++p) {
+        int i, j, k;
+        float wx[3], wy[3], wz[3];
+        tsc_w(pos[3 * p + 0] * nf, &i, wx);
+        tsc_w(pos[3 * p + 1] * nf, &j, wy);
+        tsc_w(pos[3 * p + 2] * nf, &k, wz);
+        int ii[3] = {wrap_m1(i, n), i, wrap_p1(i, n)};
+        int jj[3] = {wrap_m1(j, n), j, wrap_p1(j, n)};
+        int kk[3] = {wrap_m1(k, n), k, wrap_p1(k, n)};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                float wxy = wx[a] * wy[b];
+                for (int c = 0; c < 3; ++c) {
+                    const float w = wxy * wz[c];
+#pragma omp atomic
+                    rho[IDX3(ii[a], jj[b], kk[c], n)] += w;
+                }
+            }
+    }
+    return;
+#endif
     for (int64_t p = 0; p < np_; ++p) {
         int i, j, k;
         float wx[3], wy[3], wz[3];

@@ -59,6 +59,11 @@ def use_openmp(flag: bool) -> None:
     _use_omp = bool(flag)
 
 
+def set_num_threads(t: int) -> None:
+    """Thread count of the OpenMP build (the OpenMP runtime may have read its environment long ago)."""
+    _lib(True).pmo_set_num_threads(C.c_int(int(t)))
+
+
 def num_threads() -> int:
     return int(_lib(_use_omp).pmo_num_threads())
 
@@ -222,10 +227,19 @@ def set_units(param) -> None:  # utils.py:167-192 (G, pc: CODATA 2018 as astropy
 
 
 def fft_3D_real(x, threads: int = 1) -> np.ndarray:  # fourier.py:104 (NumPy fallback :129-130)
+    if _use_omp:  # cpu_baseline timing: the multi-threaded stand-in for the reference's FFTW threads (:133-147)
+        import scipy.fft
+
+        return np.ascontiguousarray(scipy.fft.rfftn(x.astype(np.float64), workers=num_threads()).astype(np.complex64))
     return np.ascontiguousarray(np.fft.rfftn(x).astype(np.complex64))
 
 
 def ifft_3D_real(x, threads: int = 1) -> np.ndarray:  # fourier.py:251 (NumPy fallback :276-277)
+    if _use_omp:
+        import scipy.fft
+
+        return np.ascontiguousarray(scipy.fft.irfftn(x.astype(np.complex128), s=(x.shape[0],) * 3,
+                                                     workers=num_threads()).astype(np.float32))
     return np.ascontiguousarray(np.fft.irfftn(x).astype(np.float32))
 
 
