@@ -417,6 +417,53 @@ def test_full_size_properties(amd):
     assert abs(lhs - rhs) < 1e-6 * n**3
 
 
+def test_bench_size_fused_step_properties(amd):
+    """BASELINE config 3 size (1024^3 mesh, 1024^3 particles), where the oracle cannot go: two leapfrog steps
+    with the fused kernels (kick+drift+wrap+deposit; LDS-FFT solve; gradient+gather+kick) against the same
+    steps with the separate kernels (kick_drift_wrap, deposit, force grid, interp_kick).  The streaming update
+    is the same arithmetic (positions bit-identical), the potential differs only by the order of the deposit's
+    atomics, and the gather is the reference's summation order on either path; plus mass conservation and zero
+    net force."""
+    torch = amd.torch
+    if torch.cuda.get_device_properties(0).total_memory < 150e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    import bench
+
+    n = 1024
+    pos, vel = bench.zeldovich_device(n)
+    amd.utils.periodic_wrap(pos)
+    pos, vel = amd.utils.reorder_particles(pos, vel)
+    results = {}
+    for fused in (True, False):
+        amd.integration._FUSE_DEPOSIT = fused
+        amd.solver._FUSE_GRADIENT = fused
+        try:
+            param, tables = bench.make_param(n, n**3)
+            p, v = pos.clone(), vel.clone()
+            acc, phi, extra = amd.solver.pm(p, param, tables=tables)
+            for _ in range(2):
+                p, v, acc, phi, extra = amd.integration.integrate(p, v, acc, phi, extra, tables, param, np.float32(1))
+            results[fused] = (p, v, acc, phi)
+        finally:
+            amd.integration._FUSE_DEPOSIT = True
+            amd.solver._FUSE_GRADIENT = True
+        del p, v, acc, phi
+    (p1, v1, a1, f1), (p0, v0, a0, f0) = results[True], results[False]
+    assert torch.isfinite(a1).all() and torch.isfinite(p1).all()
+    scale_phi, scale_a = float(f0.abs().max()), float(a0.abs().max())
+    assert float((f1 - f0).abs().max()) < 2e-5 * scale_phi
+    assert float((a1 - a0).abs().max()) < 2e-4 * scale_a
+    d = (p1 - p0).abs()
+    d = torch.minimum(d, 1 - d)
+    assert float(d.max()) < 1e-6                      # a few ulp: differences enter only through the potential
+    assert float((v1 - v0).abs().max()) < 2e-4 * float(v0.abs().max())
+    # momentum conservation of the PM force, mass conservation of the fused deposit
+    assert float(a1.double().sum(0).abs().max()) < 1e-4 * float(a1.double().abs().sum(0).max())
+    rho = amd.mesh.TSC(p1, n)
+    assert abs(float(rho.double().sum()) - n**3) < 1e-6 * n**3
+    assert float(p1.min()) >= 0.0 and float(p1.max()) < 1.0
+
+
 @pytest.mark.parametrize("n", [32, 64, 128, 256])
 def test_fused_fft_poisson_vs_numpy_and_rocfft(amd, n):
     """csrc/pm_fftpoisson.hip (radix-4/2 LDS FFTs, two-for-one r2c, Green's function inside the x pass)
