@@ -252,12 +252,80 @@ __global__ __launch_bounds__(BLK) void lap_gauss_seidel_kernel(float *__restrict
     }
 }
 
+// Row form of the same half-sweep for n >= 16: a thread owns 8 consecutive k-cells of one (i, j) row, four
+// of which have the launch's colour and all four the same parity class (so one summation order per thread).
+// Everything is 16-byte accesses -- the row itself, its four neighbour rows, the rhs -- against 28 scalar
+// stride-2 loads per 2x2x2 block above, which left the kernel L1-bound at a quarter of the HBM rate.  The
+// four cells of the other colour are written back unchanged (nobody writes them during this launch).
+template <int O0, int O1, int O2, int O3, int O4, int O5, int O6>
+__device__ __forceinline__ float gs_update(float xm, float xp, float ym, float yp, float zm, float zp, float mh2b,
+                                           float xc, float invsix, float f_relax) {
+    const float t[7] = {xm, xp, ym, yp, zm, zp, mh2b};
+    const float s = (((((t[O0] + t[O1]) + t[O2]) + t[O3]) + t[O4]) + t[O5]) + t[O6];
+    return xc + f_relax * (s * invsix - xc);
+}
+
+template <int COLOUR>
+__global__ __launch_bounds__(BLK) void lap_gauss_seidel_rows_kernel(float *__restrict__ x, const float *__restrict__ b,
+                                                                    int log2n, float h2, float invsix, float f_relax) {
+    const int n = 1 << log2n, m = n - 1, lseg = log2n - 3;
+    const int64_t total = (int64_t)n * n << lseg;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k0 = (int)(t & ((1 << lseg) - 1)) << 3;
+        const int64_t row = t >> lseg;
+        const int j = (int)(row & m), i = (int)(row >> log2n);
+        auto rowp = [&](int ii, int jj) -> const float * { return x + ((((int64_t)(ii & m) << log2n) + (jj & m)) << log2n); };
+        float *mine = x + (row << log2n);
+        float v[10], xm[8], xp[8], ym[8], yp[8], bb[8];
+        auto ld8 = [&](const float *p, float *d) {
+            const float4 q0 = *reinterpret_cast<const float4 *>(p + k0), q1 = *reinterpret_cast<const float4 *>(p + k0 + 4);
+            d[0] = q0.x, d[1] = q0.y, d[2] = q0.z, d[3] = q0.w, d[4] = q1.x, d[5] = q1.y, d[6] = q1.z, d[7] = q1.w;
+        };
+        ld8(mine, v + 1);
+        v[0] = mine[(k0 - 1) & m], v[9] = mine[(k0 + 8) & m];
+        ld8(rowp(i - 1, j), xm), ld8(rowp(i + 1, j), xp), ld8(rowp(i, j - 1), ym), ld8(rowp(i, j + 1), yp);
+        ld8(b + (row << log2n), bb);
+        const int o = (COLOUR + i + j) & 1;  // k parity of this row's cells of the launch's colour
+        const int cls = ((i & 1) << 2) | ((j & 1) << 1) | o;
+#define GS_ROW(O0, O1, O2, O3, O4, O5, O6)                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
+        const int l = 2 * q + o;                                                                                   \
+        v[l + 1] = gs_update<O0, O1, O2, O3, O4, O5, O6>(xm[l], xp[l], ym[l], yp[l], v[l], v[l + 2], -(h2 * bb[l]),  \
+                                                         v[l + 1], invsix, f_relax);                              \
+    }
+        // same orders as gs_cell above, by (i & 1, j & 1, k & 1)
+        switch (cls) {
+            case 7: GS_ROW(5, 3, 1, 0, 2, 4, 6) break;  // 111
+            case 4: GS_ROW(2, 4, 1, 0, 6, 5, 3) break;  // 100
+            case 2: GS_ROW(0, 3, 4, 1, 2, 5, 6) break;  // 010
+            case 1: GS_ROW(0, 2, 5, 4, 6, 3, 1) break;  // 001
+            case 6: GS_ROW(4, 3, 1, 0, 2, 6, 5) break;  // 110
+            case 5: GS_ROW(2, 5, 1, 0, 4, 6, 3) break;  // 101
+            case 3: GS_ROW(0, 5, 3, 2, 4, 6, 1) break;  // 011
+            default: GS_ROW(0, 2, 4, 6, 5, 3, 1) break;  // 000
+        }
+#undef GS_ROW
+        *reinterpret_cast<float4 *>(mine + k0) = make_float4(v[1], v[2], v[3], v[4]);
+        *reinterpret_cast<float4 *>(mine + k0 + 4) = make_float4(v[5], v[6], v[7], v[8]);
+    }
+}
+
 extern "C" int pm_lap_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, int n, float f_relax) {
     PM_REQUIRE(c && d_x && d_b, "NULL argument");
     PM_CHECK_GRID(n);
+    const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
+    if (n >= 16 && pm_aligned16(d_x) && pm_aligned16(d_b)) {
+        const int64_t threads = (int64_t)n * n * (n / 8);
+        const int blocks = pm_stream_blocks(threads, BLK);
+        hipLaunchKernelGGL((lap_gauss_seidel_rows_kernel<1>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), h2,
+                           invsix, f_relax);
+        hipLaunchKernelGGL((lap_gauss_seidel_rows_kernel<0>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), h2,
+                           invsix, f_relax);
+        PM_LAUNCH_CHECK();
+        return PM_OK;
+    }
     const int64_t total = (int64_t)(n / 2) * (n / 2) * (n / 2);
     const int blocks = pm_stream_blocks(total, BLK);
-    const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
     hipLaunchKernelGGL((lap_gauss_seidel_kernel<1>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), h2,
                        invsix, f_relax);
     hipLaunchKernelGGL((lap_gauss_seidel_kernel<0>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), h2,
