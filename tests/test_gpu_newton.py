@@ -161,6 +161,48 @@ def test_fused_gradient_gather_kick_bit_exact(amd, n):
     np.testing.assert_array_equal(acc.cpu().numpy(), orc.invTSC_vec(orc.derivative(phi, order), p_own))
 
 
+def test_empty_and_tiny_particle_sets(amd):
+    """No particles, one particle, and a handful sitting exactly on cell faces / the box edge (the reference
+    loops simply do nothing for an empty set; its kernels have no special cases for the others)."""
+    from pysco_amd import _lib as L
+
+    n = 32
+    t = amd.torch
+    rng = np.random.default_rng(1)
+    phi = rng.normal(size=(n, n, n)).astype(np.float32)
+    F = orc.derivative(phi, 5)
+    ctx = L.context(n)
+    empty = np.zeros((0, 3), dtype=np.float32)
+    assert float(np.abs(amd.mesh.TSC(empty, n)).max()) == 0.0
+    assert float(np.abs(amd.mesh.CIC(empty, n)).max()) == 0.0
+    assert amd.mesh.invTSC_vec(F, empty).shape == (0, 3)
+    e_d = t.from_numpy(empty).cuda()
+    ctx.call("pm_tile_lists", L.ptr(e_d), 0)
+    assert amd.mesh.derivative_interp_vec_kick("tsc", t.from_numpy(phi).cuda(), 5, e_d).shape == (0, 3)
+    edge = np.array([[0.0, 0.0, 0.0], [np.nextafter(np.float32(1), np.float32(0))] * 3, [0.5, 0.5, 0.5],
+                     [1.0 / n, 2.0 / n, 3.0 / n], [0.25, np.nextafter(np.float32(1), np.float32(0)), 0.0]],
+                    dtype=np.float32)
+    for pos in (edge[:1], edge):
+        for dep, odep in ((amd.mesh.TSC, orc.TSC), (amd.mesh.CIC, orc.CIC), (amd.mesh.NGP, orc.NGP)):
+            np.testing.assert_allclose(dep(pos, n), odep(pos, n), rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(amd.mesh.invTSC_vec(F, pos), orc.invTSC_vec(F, pos))
+        pd = t.from_numpy(pos).cuda()
+        for lists in (False, True):
+            ctx.call("pm_tile_lists", L.ptr(pd) if lists else None, len(pos) if lists else 0)
+            acc = amd.mesh.derivative_interp_vec_kick("tsc", t.from_numpy(phi).cuda(), 5, pd)
+            np.testing.assert_array_equal(acc.cpu().numpy(), orc.invTSC_vec(F, pos))
+        ctx.call("pm_tile_lists", None, 0)
+        # fused kick + drift + deposit on the tiny set
+        v = t.zeros_like(pd)
+        a = t.zeros_like(pd)
+        rho = t.empty((n, n, n), dtype=t.float32, device="cuda")
+        p2 = pd.clone()
+        ctx.call("pm_kick_drift_wrap_deposit", L.TSC, L.ptr(p2), L.ptr(v), L.ptr(a), 0.0, 0.0, len(pos), L.ptr(rho))
+        ctx.call("pm_tile_lists", None, 0)
+        assert t.equal(p2, pd)
+        np.testing.assert_allclose(rho.cpu().numpy(), orc.TSC(pos, n), rtol=0, atol=1e-6)
+
+
 @pytest.mark.parametrize("drift_cells", [0.3, 3.0])
 def test_drifted_sorted_stream_stragglers(amd, drift_cells):
     """A stream sorted once and then drifted (what integrate() produces between re-orderings): a few per
