@@ -211,6 +211,26 @@ int pm_gradient_slab(pm_ctx *ctx, int order, const float *d_phi, int nx_phi, int
  * were (synchronises; if it exceeds cap the caller rescans). */
 int pm_kick_drift_wrap_slab(pm_ctx *ctx, float *d_pos, float *d_vel, const float *d_acc, float half_dt, float dt,
                             int64_t np, float x_lo, float x_hi, int64_t *d_leave_idx, int cap, int *h_count);
+/* Multigrid level operations on a slab (linear V-cycle and the QUMOND source with halo exchange): every
+ * level array is [nx + 2, n, n] -- the nx owned planes of that level plus one ghost plane on each side,
+ * which the caller fills from its ring neighbours before each call that reads x-neighbours.  Same
+ * kernels and the same arithmetic per cell as the single-GPU entry points (laplacian.py:12-226, 327-381,
+ * 844-1022; mesh.py:14-455; mond.py:171-932).
+ *   pm_lap_gauss_seidel_slab: ONE colour half-sweep (1 = red, i+j+k odd; 0 = black), x_lo = global index of
+ *                             the first owned plane; the ghosts must be refreshed between the two halves
+ *   pm_lap_restrict_residual_slab / pm_restriction_slab: fine [nx+2] -> coarse [nx/2+2] (nx even)
+ *   pm_prolongation_slab: coarse [nxc+2] (ghosts filled) -> fine [2 nxc + 2]
+ *   pm_lap_residual_sumsq_slab / pm_diff_sumsq: local fp64 sum of squares (ranks add them, then sqrt) */
+int pm_lap_gauss_seidel_slab(pm_ctx *ctx, float *d_x, const float *d_b, int n, int nx, int x_lo, int colour,
+                             float f_relax);
+int pm_lap_restrict_residual_slab(pm_ctx *ctx, const float *d_x, const float *d_b, int n, int nx, float *d_out);
+int pm_restriction_slab(pm_ctx *ctx, const float *d_x, int nf, int nxf, float scale, float *d_out);
+int pm_prolongation_slab(pm_ctx *ctx, float *d_y, const float *d_xc, int nc, int nxc, int add);
+int pm_lap_operator_slab(pm_ctx *ctx, const float *d_x, const float *d_b, int n, int nx, int mode, float *d_out);
+int pm_lap_residual_sumsq_slab(pm_ctx *ctx, const float *d_x, const float *d_b, int n, int nx, double *h_sum);
+int pm_diff_sumsq(pm_ctx *ctx, const float *d_a, const float *d_b, float f, int64_t count, double *h_sum);
+int pm_mond_rhs_slab(pm_ctx *ctx, const float *d_pot, float *d_out, int n, int nx, float g0, int kind, float alpha);
+
 /* slab FFT pieces: batched 2-D r2c / c2r over (y,z) on nplanes x-planes ([np,n,n] <-> [np,n,n/2+1]; the
  * c2r carries 1/n^3), and the in-place strided 1-D c2c along x of an [n, ncolumns] complex array
  * (the layout after the all-to-all transpose, ncolumns = (n/G)*(n/2+1)). */

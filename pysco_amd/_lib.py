@@ -77,6 +77,14 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_quartic_gauss_seidel": (_vp, _vp, _vp, _f, _vp, _i, _f),
     "pm_mond_rhs": (_vp, _vp, _vp, _i, _f, _i, _f),
     "pm_set_slab": (_vp, _i, _i),
+    "pm_lap_gauss_seidel_slab": (_vp, _vp, _vp, _i, _i, _i, _i, _f),
+    "pm_lap_restrict_residual_slab": (_vp, _vp, _vp, _i, _i, _vp),
+    "pm_restriction_slab": (_vp, _vp, _i, _i, _f, _vp),
+    "pm_prolongation_slab": (_vp, _vp, _vp, _i, _i, _i),
+    "pm_lap_operator_slab": (_vp, _vp, _vp, _i, _i, _i, _vp),
+    "pm_lap_residual_sumsq_slab": (_vp, _vp, _vp, _i, _i, C.POINTER(C.c_double)),
+    "pm_diff_sumsq": (_vp, _vp, _vp, _f, _i64, C.POINTER(C.c_double)),
+    "pm_mond_rhs_slab": (_vp, _vp, _vp, _i, _i, _f, _i, _f),
     "pm_kick_drift_wrap_slab": (_vp, _vp, _vp, _vp, _f, _f, _i64, _f, _f, _vp, _i, C.POINTER(_i)),
     "pm_gradient_slab": (_vp, _i, _vp, _i, _i, _vp, _i, _i),
     "pm_fft2d_r2c": (_vp, _vp, _vp, _i),

@@ -14,6 +14,15 @@ __device__ __forceinline__ int64_t cidx(int i, int j, int k, int log2n) {
 
 static inline int ilog2(int n) { return __builtin_ctz((unsigned)n); }
 
+// Which planes of a level array a kernel works on.  Single GPU: the periodic cube {0, n, n - 1}.  x-slab
+// (multi-GPU): the array holds one ghost plane on each side of the ni owned ones and x never wraps
+// {1, ni, INT_MAX}; the host fills the ghosts (ring exchange) before every kernel that reads neighbours.
+struct XRange {
+    int i0, ni, xmask;
+};
+static inline XRange xr_cube(int n) { return XRange{0, n, n - 1}; }
+static inline XRange xr_slab(int nx) { return XRange{1, nx, 0x7fffffff}; }
+
 #define PM_CHECK_GRID(n) PM_REQUIRE((n) >= 2 && (n) <= 16384 && (((n) & ((n)-1)) == 0), "grid size must be a power of two")
 
 // ------------------------------------------------------------------------------------------------
@@ -21,58 +30,79 @@ static inline int ilog2(int n) { return __builtin_ctz((unsigned)n); }
 
 // mesh.py:14-60 restriction (scale 1/8), :63-110 minus_restriction (scale -1/8)
 __global__ __launch_bounds__(BLK) void restriction_kernel(const float *__restrict__ x, int log2nf, float scale,
-                                                          float *__restrict__ out) {
+                                                          float *__restrict__ out, XRange xf, XRange xc) {
     const int log2nc = log2nf - 1, nc = 1 << log2nc;
-    const int64_t total = (int64_t)nc * nc * nc;
+    const int64_t total = (int64_t)xc.ni << (2 * log2nc);
     for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
-        const int k = (int)(t & (nc - 1)), j = (int)((t >> log2nc) & (nc - 1)), i = (int)(t >> (2 * log2nc));
-        const int ii = 2 * i, jj = 2 * j, kk = 2 * k;
+        const int k = (int)(t & (nc - 1)), j = (int)((t >> log2nc) & (nc - 1)), ic = (int)(t >> (2 * log2nc));
+        const int ii = xf.i0 + 2 * ic, jj = 2 * j, kk = 2 * k;
         const float2 a = *reinterpret_cast<const float2 *>(x + cidx(ii, jj, kk, log2nf));
         const float2 b = *reinterpret_cast<const float2 *>(x + cidx(ii, jj + 1, kk, log2nf));
         const float2 c = *reinterpret_cast<const float2 *>(x + cidx(ii + 1, jj, kk, log2nf));
         const float2 d = *reinterpret_cast<const float2 *>(x + cidx(ii + 1, jj + 1, kk, log2nf));
-        out[t] = scale * (a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y);
+        out[cidx(xc.i0 + ic, j, k, log2nc)] = scale * (a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y);
     }
+}
+
+static int restriction_launch(pm_ctx *c, const float *d_x, int nf, float scale, float *d_out, XRange xf, XRange xc) {
+    const int64_t total = (int64_t)xc.ni * (nf / 2) * (nf / 2);
+    hipLaunchKernelGGL(restriction_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_x, ilog2(nf),
+                       scale, d_out, xf, xc);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
 }
 
 extern "C" int pm_restriction(pm_ctx *c, const float *d_x, int nf, float scale, float *d_out) {
     PM_REQUIRE(c && d_x && d_out, "NULL argument");
     PM_CHECK_GRID(nf);
-    const int64_t total = (int64_t)(nf / 2) * (nf / 2) * (nf / 2);
-    hipLaunchKernelGGL(restriction_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_x, ilog2(nf),
-                       scale, d_out);
-    PM_LAUNCH_CHECK();
-    return PM_OK;
+    return restriction_launch(c, d_x, nf, scale, d_out, xr_cube(nf), xr_cube(nf / 2));
+}
+
+extern "C" int pm_restriction_slab(pm_ctx *c, const float *d_x, int nf, int nxf, float scale, float *d_out) {
+    PM_REQUIRE(c && d_x && d_out && nxf >= 2 && (nxf % 2) == 0, "bad argument (even number of owned fine planes)");
+    PM_CHECK_GRID(nf);
+    return restriction_launch(c, d_x, nf, scale, d_out, xr_slab(nxf), xr_slab(nxf / 2));
 }
 
 // mesh.py:206-330 prolongation / :334-455 add_prolongation: one thread per FINE cell
 __global__ __launch_bounds__(BLK) void prolongation_kernel(float *__restrict__ y, const float *__restrict__ xc,
-                                                           int log2nc, int add) {
+                                                           int log2nc, int add, XRange xf, XRange xcr) {
     const int log2nf = log2nc + 1, nf = 1 << log2nf, nc = 1 << log2nc, mc = nc - 1;
     const float f0 = (float)(27.0 / 64), f1 = (float)(9.0 / 64), f2 = (float)(3.0 / 64), f3 = (float)(1.0 / 64);
-    const int64_t total = (int64_t)nf * nf * nf;
+    const int64_t total = (int64_t)xf.ni << (2 * log2nf);
     for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
         const int kf = (int)(t & (nf - 1)), jf = (int)((t >> log2nf) & (nf - 1)), fi = (int)(t >> (2 * log2nf));
-        const int i = fi >> 1, j = jf >> 1, k = kf >> 1;
-        const int ia = (i + ((fi & 1) ? 1 : -1)) & mc, jb = (j + ((jf & 1) ? 1 : -1)) & mc,
+        const int i = xcr.i0 + (fi >> 1), j = jf >> 1, k = kf >> 1;
+        const int ia = (i + ((fi & 1) ? 1 : -1)) & xcr.xmask, jb = (j + ((jf & 1) ? 1 : -1)) & mc,
                   kd = (k + ((kf & 1) ? 1 : -1)) & mc;
         const float tmp0 = f0 * xc[cidx(i, j, k, log2nc)];
         const float X = xc[cidx(ia, j, k, log2nc)], Y = xc[cidx(i, jb, k, log2nc)], Z = xc[cidx(i, j, kd, log2nc)];
         const float XY = xc[cidx(ia, jb, k, log2nc)], XZ = xc[cidx(ia, j, kd, log2nc)], YZ = xc[cidx(i, jb, kd, log2nc)];
         const float XYZ = xc[cidx(ia, jb, kd, log2nc)];
         const float v = tmp0 + f1 * (X + Y + Z) + f2 * (XY + XZ + YZ) + f3 * XYZ;
-        y[t] = add ? y[t] + v : v;
+        float *dst = y + cidx(xf.i0 + fi, jf, kf, log2nf);
+        *dst = add ? *dst + v : v;
     }
+}
+
+static int prolongation_launch(pm_ctx *c, float *d_y, const float *d_xc, int nc, int add, XRange xf, XRange xcr) {
+    const int64_t total = (int64_t)xf.ni * (2 * nc) * (2 * nc);
+    hipLaunchKernelGGL(prolongation_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_y, d_xc,
+                       ilog2(nc), add, xf, xcr);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
 }
 
 extern "C" int pm_prolongation(pm_ctx *c, float *d_y, const float *d_xc, int nc, int add) {
     PM_REQUIRE(c && d_y && d_xc, "NULL argument");
     PM_CHECK_GRID(nc);
-    const int64_t total = (int64_t)8 * nc * nc * nc;
-    hipLaunchKernelGGL(prolongation_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_y, d_xc,
-                       ilog2(nc), add);
-    PM_LAUNCH_CHECK();
-    return PM_OK;
+    return prolongation_launch(c, d_y, d_xc, nc, add, xr_cube(2 * nc), xr_cube(nc));
+}
+
+extern "C" int pm_prolongation_slab(pm_ctx *c, float *d_y, const float *d_xc, int nc, int nxc, int add) {
+    PM_REQUIRE(c && d_y && d_xc && nxc >= 1, "bad argument");
+    PM_CHECK_GRID(nc);
+    return prolongation_launch(c, d_y, d_xc, nc, add, xr_slab(2 * nxc), xr_slab(nxc));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -81,39 +111,52 @@ extern "C" int pm_prolongation(pm_ctx *c, float *d_y, const float *d_xc, int nc,
 // laplacian.py:12-59 operator (mode 0) / :63-121 residual b - Ax (mode 1)
 __global__ __launch_bounds__(BLK) void lap_operator_kernel(const float *__restrict__ x, const float *__restrict__ b,
                                                            int log2n, int mode, float invh2,
-                                                           float *__restrict__ out) {
+                                                           float *__restrict__ out, XRange xr) {
     const int n = 1 << log2n, m = n - 1;
-    const int64_t total = (int64_t)n * n * n;
-    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
-        const int k = (int)(t & m), j = (int)((t >> log2n) & m), i = (int)(t >> (2 * log2n));
-        const float s = x[cidx((i - 1) & m, j, k, log2n)] + x[cidx(i, (j - 1) & m, k, log2n)] +
+    const int64_t total = (int64_t)xr.ni << (2 * log2n);
+    for (int64_t t0 = (int64_t)blockIdx.x * BLK + threadIdx.x; t0 < total; t0 += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t0 & m), j = (int)((t0 >> log2n) & m), i = xr.i0 + (int)(t0 >> (2 * log2n));
+        const int64_t t = cidx(i, j, k, log2n);
+        const float s = x[cidx((i - 1) & xr.xmask, j, k, log2n)] + x[cidx(i, (j - 1) & m, k, log2n)] +
                         x[cidx(i, j, (k - 1) & m, log2n)] - 6.0f * x[t] + x[cidx(i, j, (k + 1) & m, log2n)] +
-                        x[cidx(i, (j + 1) & m, k, log2n)] + x[cidx((i + 1) & m, j, k, log2n)];
+                        x[cidx(i, (j + 1) & m, k, log2n)] + x[cidx((i + 1) & xr.xmask, j, k, log2n)];
         out[t] = mode ? (-(s)*invh2 + b[t]) : s * invh2;
     }
+}
+
+static int lap_operator_launch(pm_ctx *c, const float *d_x, const float *d_b, int n, int mode, float *d_out, XRange xr) {
+    const int64_t total = (int64_t)xr.ni * n * n;
+    hipLaunchKernelGGL(lap_operator_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_x, d_b,
+                       ilog2(n), mode, (float)((double)n * n), d_out, xr);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
 }
 
 extern "C" int pm_lap_operator(pm_ctx *c, const float *d_x, const float *d_b, int n, int mode, float *d_out) {
     PM_REQUIRE(c && d_x && d_out && (mode == 0 || d_b), "NULL argument");
     PM_CHECK_GRID(n);
-    const int64_t total = (int64_t)n * n * n;
-    hipLaunchKernelGGL(lap_operator_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_x, d_b,
-                       ilog2(n), mode, (float)((double)n * n), d_out);
-    PM_LAUNCH_CHECK();
-    return PM_OK;
+    return lap_operator_launch(c, d_x, d_b, n, mode, d_out, xr_cube(n));
+}
+
+extern "C" int pm_lap_operator_slab(pm_ctx *c, const float *d_x, const float *d_b, int n, int nx, int mode,
+                                    float *d_out) {
+    PM_REQUIRE(c && d_x && d_out && (mode == 0 || d_b) && nx >= 1, "bad argument");
+    PM_CHECK_GRID(n);
+    return lap_operator_launch(c, d_x, d_b, n, mode, d_out, xr_slab(nx));
 }
 
 // laplacian.py:125-226 restrict_residual: fused residual + 1/8 restriction, reference summation order
 __global__ __launch_bounds__(BLK) void lap_restrict_residual_kernel(const float *__restrict__ x,
                                                                     const float *__restrict__ b, int log2n,
-                                                                    float invh2, float *__restrict__ out) {
+                                                                    float invh2, float *__restrict__ out, XRange xf,
+                                                                    XRange xc) {
     const int n = 1 << log2n, m = n - 1, log2nc = log2n - 1, nc = n >> 1;
-    const int64_t total = (int64_t)nc * nc * nc;
-#define X(a, bb, cc) x[cidx((a)&m, (bb)&m, (cc)&m, log2n)]
+    const int64_t total = (int64_t)xc.ni << (2 * log2nc);
+#define X(a, bb, cc) x[cidx((a)&xf.xmask, (bb)&m, (cc)&m, log2n)]
 #define B(a, bb, cc) b[cidx(a, bb, cc, log2n)]
     for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
         const int k = (int)(t & (nc - 1)), j = (int)((t >> log2nc) & (nc - 1)), i = (int)(t >> (2 * log2nc));
-        const int ii = 2 * i, jj = 2 * j, kk = 2 * k;
+        const int ii = xf.i0 + 2 * i, jj = 2 * j, kk = 2 * k;
         const int m1 = ii - 1, p1 = ii + 1, p2 = ii + 2, jm1 = jj - 1, jp1 = jj + 1, jp2 = jj + 2, km1 = kk - 1,
                   kp1 = kk + 1, kp2 = kk + 2;
         const float s = +X(m1, jj, kk) + X(m1, jj, kp1) + X(m1, jp1, kk) + X(m1, jp1, kp1) + X(ii, jm1, kk) +
@@ -123,21 +166,34 @@ __global__ __launch_bounds__(BLK) void lap_restrict_residual_kernel(const float 
                         X(p2, jj, kk) + X(p2, jj, kp1) + X(p2, jp1, kk) + X(p2, jp1, kp1) -
                         3.0f * (X(ii, jj, kk) + X(ii, jj, kp1) + X(ii, jp1, kk) + X(ii, jp1, kp1) + X(p1, jj, kk) +
                                 X(p1, jj, kp1) + X(p1, jp1, kk) + X(p1, jp1, kp1));
-        out[t] = 0.125f * (-(s)*invh2 + B(ii, jj, kk) + B(ii, jj, kp1) + B(ii, jp1, kk) + B(ii, jp1, kp1) +
-                           B(p1, jj, kk) + B(p1, jj, kp1) + B(p1, jp1, kk) + B(p1, jp1, kp1));
+        out[cidx(xc.i0 + i, j, k, log2nc)] =
+            0.125f * (-(s)*invh2 + B(ii, jj, kk) + B(ii, jj, kp1) + B(ii, jp1, kk) + B(ii, jp1, kp1) + B(p1, jj, kk) +
+                      B(p1, jj, kp1) + B(p1, jp1, kk) + B(p1, jp1, kp1));
     }
 #undef X
 #undef B
 }
 
+static int lap_restrict_residual_launch(pm_ctx *c, const float *d_x, const float *d_b, int n, float *d_out, XRange xf,
+                                        XRange xc) {
+    const int64_t total = (int64_t)xc.ni * (n / 2) * (n / 2);
+    hipLaunchKernelGGL(lap_restrict_residual_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_x,
+                       d_b, ilog2(n), (float)((double)n * n), d_out, xf, xc);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
 extern "C" int pm_lap_restrict_residual(pm_ctx *c, const float *d_x, const float *d_b, int n, float *d_out) {
     PM_REQUIRE(c && d_x && d_b && d_out, "NULL argument");
     PM_CHECK_GRID(n);
-    const int64_t total = (int64_t)(n / 2) * (n / 2) * (n / 2);
-    hipLaunchKernelGGL(lap_restrict_residual_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_x,
-                       d_b, ilog2(n), (float)((double)n * n), d_out);
-    PM_LAUNCH_CHECK();
-    return PM_OK;
+    return lap_restrict_residual_launch(c, d_x, d_b, n, d_out, xr_cube(n), xr_cube(n / 2));
+}
+
+extern "C" int pm_lap_restrict_residual_slab(pm_ctx *c, const float *d_x, const float *d_b, int n, int nx,
+                                             float *d_out) {
+    PM_REQUIRE(c && d_x && d_b && d_out && nx >= 2 && (nx % 2) == 0, "bad argument (even number of owned planes)");
+    PM_CHECK_GRID(n);
+    return lap_restrict_residual_launch(c, d_x, d_b, n, d_out, xr_slab(nx), xr_slab(nx / 2));
 }
 
 // block-level fp64 sum -> one atomicAdd(double) per workgroup
@@ -163,31 +219,48 @@ static int read_norm(pm_ctx *c, float *h_out) {
 // laplacian.py:327-381 residual_error = sqrt(sum (b - Ax)^2)
 __global__ __launch_bounds__(BLK) void lap_residual_error_kernel(const float *__restrict__ x,
                                                                  const float *__restrict__ b, int log2n, float invh2,
-                                                                 double *__restrict__ result) {
+                                                                 double *__restrict__ result, XRange xr) {
     const int n = 1 << log2n, m = n - 1;
-    const int64_t total = (int64_t)n * n * n;
+    const int64_t total = (int64_t)xr.ni << (2 * log2n);
     double acc = 0;
-    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
-        const int k = (int)(t & m), j = (int)((t >> log2n) & m), i = (int)(t >> (2 * log2n));
-        const float s = +x[cidx((i - 1) & m, j, k, log2n)] + x[cidx(i, j, (k - 1) & m, log2n)] +
+    for (int64_t t0 = (int64_t)blockIdx.x * BLK + threadIdx.x; t0 < total; t0 += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t0 & m), j = (int)((t0 >> log2n) & m), i = xr.i0 + (int)(t0 >> (2 * log2n));
+        const int64_t t = cidx(i, j, k, log2n);
+        const float s = +x[cidx((i - 1) & xr.xmask, j, k, log2n)] + x[cidx(i, j, (k - 1) & m, log2n)] +
                         x[cidx(i, j, (k + 1) & m, log2n)] + x[cidx(i, (j - 1) & m, k, log2n)] - 6.0f * x[t] +
-                        x[cidx(i, (j + 1) & m, k, log2n)] + x[cidx((i + 1) & m, j, k, log2n)];
+                        x[cidx(i, (j + 1) & m, k, log2n)] + x[cidx((i + 1) & xr.xmask, j, k, log2n)];
         const float r = -(s)*invh2 + b[t];
         acc += (double)(r * r);
     }
     block_sum_to(acc, result);
 }
 
+static int lap_residual_sumsq(pm_ctx *c, const float *d_x, const float *d_b, int n, XRange xr, double *h_sum) {
+    PM_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(double), c->stream));
+    const int64_t total = (int64_t)xr.ni * n * n;
+    int blocks = pm_stream_blocks(total, BLK * 4);
+    hipLaunchKernelGGL(lap_residual_error_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n),
+                       (float)((double)n * n), c->d_hist, xr);
+    PM_LAUNCH_CHECK();
+    PM_HIP(hipMemcpyAsync(h_sum, c->d_hist, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
 extern "C" int pm_lap_residual_error(pm_ctx *c, const float *d_x, const float *d_b, int n, float *h_out) {
     PM_REQUIRE(c && d_x && d_b && h_out, "NULL argument");
     PM_CHECK_GRID(n);
-    PM_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(double), c->stream));
-    const int64_t total = (int64_t)n * n * n;
-    int blocks = pm_stream_blocks(total, BLK * 4);
-    hipLaunchKernelGGL(lap_residual_error_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n),
-                       (float)((double)n * n), c->d_hist);
-    PM_LAUNCH_CHECK();
-    return read_norm(c, h_out);
+    double s = 0;
+    int rc = lap_residual_sumsq(c, d_x, d_b, n, xr_cube(n), &s);
+    *h_out = (float)sqrt(s);
+    return rc;
+}
+
+// slab: the local sum of squares (fp64); the caller adds the ranks' sums and takes the root
+extern "C" int pm_lap_residual_sumsq_slab(pm_ctx *c, const float *d_x, const float *d_b, int n, int nx, double *h_sum) {
+    PM_REQUIRE(c && d_x && d_b && h_sum && nx >= 1, "bad argument");
+    PM_CHECK_GRID(n);
+    return lap_residual_sumsq(c, d_x, d_b, n, xr_slab(nx), h_sum);
 }
 
 // sqrt(sum (f*a - b)^2): tail of laplacian.truncation_error :529-532 (f=1), cubic.truncation_error :1057-1061 (f=4)
@@ -208,6 +281,18 @@ extern "C" int pm_diff_norm(pm_ctx *c, const float *d_a, const float *d_b, float
                        count, c->d_hist);
     PM_LAUNCH_CHECK();
     return read_norm(c, h_out);
+}
+
+// the same without the root, in fp64 (slab ranks add their sums)
+extern "C" int pm_diff_sumsq(pm_ctx *c, const float *d_a, const float *d_b, float f, int64_t count, double *h_sum) {
+    PM_REQUIRE(c && d_a && d_b && h_sum && count > 0, "bad argument");
+    PM_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(double), c->stream));
+    hipLaunchKernelGGL(diff_norm_kernel, dim3(pm_stream_blocks(count, BLK * 4)), dim3(BLK), 0, c->stream, d_a, d_b, f,
+                       count, c->d_hist);
+    PM_LAUNCH_CHECK();
+    PM_HIP(hipMemcpyAsync(h_sum, c->d_hist, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
+    return PM_OK;
 }
 
 // laplacian.py:844-1022 gauss_seidel.  One launch per colour (the reference warns that its two
@@ -267,14 +352,19 @@ __device__ __forceinline__ float gs_update(float xm, float xp, float ym, float y
 
 template <int COLOUR>
 __global__ __launch_bounds__(BLK) void lap_gauss_seidel_rows_kernel(float *__restrict__ x, const float *__restrict__ b,
-                                                                    int log2n, float h2, float invsix, float f_relax) {
+                                                                    int log2n, float h2, float invsix, float f_relax,
+                                                                    XRange xr, int gpar) {
+    // gpar: parity of (global plane index - local plane index), 0 on a single GPU
     const int n = 1 << log2n, m = n - 1, lseg = log2n - 3;
-    const int64_t total = (int64_t)n * n << lseg;
+    const int64_t total = ((int64_t)xr.ni << log2n) << lseg;
     for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
         const int k0 = (int)(t & ((1 << lseg) - 1)) << 3;
-        const int64_t row = t >> lseg;
-        const int j = (int)(row & m), i = (int)(row >> log2n);
-        auto rowp = [&](int ii, int jj) -> const float * { return x + ((((int64_t)(ii & m) << log2n) + (jj & m)) << log2n); };
+        const int64_t row0 = t >> lseg;
+        const int j = (int)(row0 & m), il = xr.i0 + (int)(row0 >> log2n), i = il + gpar;  // i: parity of the global plane
+        const int64_t row = ((int64_t)il << log2n) + j;
+        auto rowp = [&](int ii, int jj) -> const float * {
+            return x + ((((int64_t)(ii & xr.xmask) << log2n) + (jj & m)) << log2n);
+        };
         float *mine = x + (row << log2n);
         float v[10], xm[8], xp[8], ym[8], yp[8], bb[8];
         auto ld8 = [&](const float *p, float *d) {
@@ -283,7 +373,7 @@ __global__ __launch_bounds__(BLK) void lap_gauss_seidel_rows_kernel(float *__res
         };
         ld8(mine, v + 1);
         v[0] = mine[(k0 - 1) & m], v[9] = mine[(k0 + 8) & m];
-        ld8(rowp(i - 1, j), xm), ld8(rowp(i + 1, j), xp), ld8(rowp(i, j - 1), ym), ld8(rowp(i, j + 1), yp);
+        ld8(rowp(il - 1, j), xm), ld8(rowp(il + 1, j), xp), ld8(rowp(il, j - 1), ym), ld8(rowp(il, j + 1), yp);
         ld8(b + (row << log2n), bb);
         const int o = (COLOUR + i + j) & 1;  // k parity of this row's cells of the launch's colour
         const int cls = ((i & 1) << 2) | ((j & 1) << 1) | o;
@@ -318,9 +408,9 @@ extern "C" int pm_lap_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, int 
         const int64_t threads = (int64_t)n * n * (n / 8);
         const int blocks = pm_stream_blocks(threads, BLK);
         hipLaunchKernelGGL((lap_gauss_seidel_rows_kernel<1>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), h2,
-                           invsix, f_relax);
+                           invsix, f_relax, xr_cube(n), 0);
         hipLaunchKernelGGL((lap_gauss_seidel_rows_kernel<0>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), h2,
-                           invsix, f_relax);
+                           invsix, f_relax, xr_cube(n), 0);
         PM_LAUNCH_CHECK();
         return PM_OK;
     }
@@ -330,6 +420,28 @@ extern "C" int pm_lap_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, int 
                        invsix, f_relax);
     hipLaunchKernelGGL((lap_gauss_seidel_kernel<0>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), h2,
                        invsix, f_relax);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// One colour half-sweep on a slab [nx + 2, n, n] (owned planes 1..nx, ghosts filled by the caller, who
+// exchanges them again between the red (colour 1) and the black (colour 0) half).  x_lo = global index of
+// the first owned plane.  Same arithmetic per cell as the single-GPU sweep.
+extern "C" int pm_lap_gauss_seidel_slab(pm_ctx *c, float *d_x, const float *d_b, int n, int nx, int x_lo, int colour,
+                                        float f_relax) {
+    PM_REQUIRE(c && d_x && d_b && nx >= 1 && (colour == 0 || colour == 1), "bad argument");
+    PM_CHECK_GRID(n);
+    PM_REQUIRE(n >= 16 && pm_aligned16(d_x) && pm_aligned16(d_b), "slab smoother needs n >= 16 and 16-byte aligned arrays");
+    const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
+    const int64_t threads = (int64_t)nx * n * (n / 8);
+    const int blocks = pm_stream_blocks(threads, BLK);
+    const int gpar = (x_lo - 1) & 1;  // global = local - 1 + x_lo
+    if (colour == 1)
+        hipLaunchKernelGGL((lap_gauss_seidel_rows_kernel<1>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), h2,
+                           invsix, f_relax, xr_slab(nx), gpar);
+    else
+        hipLaunchKernelGGL((lap_gauss_seidel_rows_kernel<0>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), h2,
+                           invsix, f_relax, xr_slab(nx), gpar);
     PM_LAUNCH_CHECK();
     return PM_OK;
 }
@@ -605,13 +717,14 @@ __device__ __forceinline__ float mond_nu(float y, float alpha) {
 // mond.py:171-316 rhs_simple and its four siblings
 template <int KIND>
 __global__ __launch_bounds__(BLK) void mond_rhs_kernel(const float *__restrict__ pot, float *__restrict__ out,
-                                                       int log2n, float inv_g0, float alpha) {
+                                                       int log2n, float inv_g0, float alpha, XRange xr) {
     const int n = 1 << log2n, m = n - 1;
     const float invh = (float)n, inv4h = (float)(0.25 * n);
-    const int64_t total = (int64_t)n * n * n;
-#define P(a, b, c) pot[cidx((a)&m, (b)&m, (c)&m, log2n)]
-    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
-        const int k = (int)(t & m), j = (int)((t >> log2n) & m), i = (int)(t >> (2 * log2n));
+    const int64_t total = (int64_t)xr.ni << (2 * log2n);
+#define P(a, b, c) pot[cidx((a)&xr.xmask, (b)&m, (c)&m, log2n)]
+    for (int64_t t0 = (int64_t)blockIdx.x * BLK + threadIdx.x; t0 < total; t0 += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t0 & m), j = (int)((t0 >> log2n) & m), i = xr.i0 + (int)(t0 >> (2 * log2n));
+        const int64_t t = cidx(i, j, k, log2n);
         const int im1 = i - 1, ip1 = i + 1, jm1 = j - 1, jp1 = j + 1, km1 = k - 1, kp1 = k + 1;
         const float p000 = P(i, j, k);
         const float Axx = invh * (p000 - P(im1, j, k));
@@ -646,23 +759,36 @@ __global__ __launch_bounds__(BLK) void mond_rhs_kernel(const float *__restrict__
 #undef P
 }
 
-extern "C" int pm_mond_rhs(pm_ctx *c, const float *d_pot, float *d_out, int n, float g0, int kind, float alpha) {
-    PM_REQUIRE(c && d_pot && d_out && d_pot != d_out, "bad argument");
-    PM_CHECK_GRID(n);
-    const int64_t total = (int64_t)n * n * n;
+static int mond_rhs_launch(pm_ctx *c, const float *d_pot, float *d_out, int n, float g0, int kind, float alpha,
+                           XRange xr) {
+    const int64_t total = (int64_t)xr.ni * n * n;
     const int blocks = pm_stream_blocks(total, BLK);
     const float inv_g0 = (float)(1.0 / (double)g0);
     const int l2 = ilog2(n);
     switch (kind) {
-        case 0: hipLaunchKernelGGL((mond_rhs_kernel<0>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha); break;
-        case 1: hipLaunchKernelGGL((mond_rhs_kernel<1>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha); break;
-        case 2: hipLaunchKernelGGL((mond_rhs_kernel<2>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha); break;
-        case 3: hipLaunchKernelGGL((mond_rhs_kernel<3>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha); break;
-        case 4: hipLaunchKernelGGL((mond_rhs_kernel<4>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha); break;
+        case 0: hipLaunchKernelGGL((mond_rhs_kernel<0>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha, xr); break;
+        case 1: hipLaunchKernelGGL((mond_rhs_kernel<1>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha, xr); break;
+        case 2: hipLaunchKernelGGL((mond_rhs_kernel<2>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha, xr); break;
+        case 3: hipLaunchKernelGGL((mond_rhs_kernel<3>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha, xr); break;
+        case 4: hipLaunchKernelGGL((mond_rhs_kernel<4>), dim3(blocks), dim3(BLK), 0, c->stream, d_pot, d_out, l2, inv_g0, alpha, xr); break;
         default:
             pm_set_error("MOND function %d, should be 0..4 (simple, n, beta, gamma, delta)", kind);
             return PM_EINVAL;
     }
     PM_LAUNCH_CHECK();
     return PM_OK;
+}
+
+extern "C" int pm_mond_rhs(pm_ctx *c, const float *d_pot, float *d_out, int n, float g0, int kind, float alpha) {
+    PM_REQUIRE(c && d_pot && d_out && d_pot != d_out, "bad argument");
+    PM_CHECK_GRID(n);
+    return mond_rhs_launch(c, d_pot, d_out, n, g0, kind, alpha, xr_cube(n));
+}
+
+// slab form: d_pot / d_out are [nx + 2, n, n] with the ghosts of d_pot filled by the caller
+extern "C" int pm_mond_rhs_slab(pm_ctx *c, const float *d_pot, float *d_out, int n, int nx, float g0, int kind,
+                                float alpha) {
+    PM_REQUIRE(c && d_pot && d_out && d_pot != d_out && nx >= 1, "bad argument");
+    PM_CHECK_GRID(n);
+    return mond_rhs_launch(c, d_pot, d_out, n, g0, kind, alpha, xr_slab(nx));
 }

@@ -236,6 +236,9 @@ def all_reduce_max(values: List[float], device) -> List[float]:
 # ------------------------------------------------------------------------------------------------
 
 
+_SLAB_MULTIGRID = True  # False: multigrid / MOND under slabs all-gather the density and solve replicated
+
+
 class Slab:
     """Geometry of this rank's slab and the distributed PM step."""
 
@@ -397,10 +400,25 @@ class Slab:
         scheme = _SCHEME[MASS_SCHEME]
         nx = self.nx
         decomposed = THEORY == "newton" and LINEAR_NEWTON_SOLVER in ("fft", "fft_7pt") and not save_pk
-        if not decomposed:
+        # Newton + multigrid and QUMOND: halo-exchange multigrid / slab FFT (HIP provider, >= 4 planes per rank)
+        grid_solvers = (not decomposed and not save_pk and _SLAB_MULTIGRID and isinstance(ops, HipOps)
+                        and n >= 32 and nx >= 4 and nx % 2 == 0
+                        and ((THEORY == "newton" and LINEAR_NEWTON_SOLVER == "multigrid")
+                             or (THEORY == "mond" and LINEAR_NEWTON_SOLVER in ("multigrid", "fft_7pt"))))
+        if not decomposed and not grid_solvers:
             return self._pm_replicated_grid(position, param, potential, additional_field, tables, kick, scheme)
         param["save_pk"] = False
         param["parametrized_mu_z"] = np.float32(1)
+        if grid_solvers:
+            lists = getattr(ops, "tile_lists", None)
+            if lists is not None:
+                lists(position)
+            try:
+                return self._pm_decomposed_grid_solvers(position, param, potential, additional_field, tables, kick,
+                                                        scheme)
+            finally:
+                if lists is not None:
+                    lists(None)
 
         lists = getattr(ops, "tile_lists", None)
         if lists is not None:
@@ -411,11 +429,10 @@ class Slab:
             if lists is not None:
                 lists(None)
 
-    def _pm_decomposed(self, position, param, scheme, kick):
-        import torch
-
+    def _deposit_owned(self, position, param, scheme):
+        """Density on the owned planes [nx, n, n] (a view into the deposit's [nx + 2] array): deposit with one
+        ghost plane each side, ghosts folded into the neighbours, normalised to unit mean (solver.py:113)."""
         n, nx, ops = self.n, self.nx, self.ops
-        # deposit into the slab + one ghost plane each side, then fold the ghosts into the neighbours
         rho_ext = ops.deposit(scheme, position, nx + 2, self.x_lo - 1)
         from_left, from_right = exchange_planes(rho_ext[0], rho_ext[nx + 1])
         rho_ext[1] += from_left       # left neighbour's right ghost is my first plane
@@ -423,12 +440,13 @@ class Slab:
         rho = rho_ext[1:nx + 1]       # contiguous view of the owned planes
         if n**3 != param["npart"]:
             ops.scale_inplace(rho, np.float32(n**3 / param["npart"]))
-        param["compute_additional_field"] = False
-        # solver.rhs_poisson's f1*(rho - 1) is folded into the Green's function (k = 0 is discarded)
-        f1 = np.float32(1.5 * param["aexp"] * param["Om_m"] * param["parametrized_mu_z"])
-        phi = self.poisson_fft(rho, param, f1)
-        del rho_ext, rho
+        return rho
 
+    def _gather(self, phi, position, param, scheme, kick):
+        """Acceleration at the particles from the owned planes of the potential (+ second kick, maxima)."""
+        import torch
+
+        n, nx, ops = self.n, self.nx, self.ops
         # phi ghosts: gradient reach + 1 plane for the TSC/CIC gather of the force
         order = param["gradient_stencil_order"]
         if order not in _REACH:
@@ -445,8 +463,94 @@ class Slab:
             del force
         del phi_ext
         self.local_max = (ma, mv)
+        return acc
+
+    def _pm_decomposed(self, position, param, scheme, kick):
+        import torch
+
+        rho = self._deposit_owned(position, param, scheme)
+        param["compute_additional_field"] = False
+        # solver.rhs_poisson's f1*(rho - 1) is folded into the Green's function (k = 0 is discarded)
+        f1 = np.float32(1.5 * param["aexp"] * param["Om_m"] * param["parametrized_mu_z"])
+        phi = self.poisson_fft(rho, param, f1)
+        del rho
+        acc = self._gather(phi, position, param, scheme, kick)
         empty = torch.empty(0, dtype=torch.float32, device=position.device)
         return acc, phi, empty
+
+    def _pm_decomposed_grid_solvers(self, position, param, potential, additional_field, tables, kick, scheme):
+        """Newton with the multigrid solver and QUMOND (multigrid or fft_7pt) on slabs: solver.py:113-215 with
+        every grid operation decomposed -- halo-exchange multigrid (slab_multigrid.py), the slab FFT, the MOND
+        source stencil on a slab.  Potential and extra field are returned (and expected back for the warm
+        start, solver.py:273-280) as the rank's owned planes [nx, n, n]."""
+        import torch
+
+        from .slab_multigrid import SlabMultigrid
+
+        n, nx, ops = self.n, self.nx, self.ops
+        mg = getattr(self, "_mg", None) or SlabMultigrid(self)
+        self._mg = mg
+        THEORY = param["theory"].casefold()
+        SOLVER = param["linear_newton_solver"].casefold()
+        dev = position.device
+
+        def owned(t):  # [nx, n, n] planes of a field handed back by the caller, or None
+            if t is None or t.numel() == 0:
+                return None
+            if tuple(t.shape) == (n, n, n):  # a full grid from an earlier replicated solve
+                return t[self.x_lo:self.x_lo + nx]
+            if tuple(t.shape) != (nx, n, n):
+                raise ValueError(f"slab solve expects [nx, n, n] = {(nx, n, n)} fields, got {tuple(t.shape)}")
+            return t
+
+        def solve(x0, rhs_lvl, warm_scale):
+            """One Poisson solve on a level array rhs_lvl ([nx+2, n, n]); returns the solution level array."""
+            if SOLVER == "multigrid":
+                if x0 is None:
+                    x = mg.initialise_potential(rhs_lvl)
+                else:
+                    x = mg.extend(x0)
+                    if warm_scale is not None:
+                        ops.scale_inplace(x, warm_scale)
+                return mg.linear(x, rhs_lvl, param)
+            sol = self.poisson_fft(rhs_lvl[1:nx + 1], param)  # fft / fft_7pt
+            return mg.extend(sol)
+
+        rho = self._deposit_owned(position, param, scheme)
+        dens = mg.extend(rho)
+        del rho
+        f1 = np.float32(1.5 * param["aexp"] * param["Om_m"] * param["parametrized_mu_z"])
+        param["compute_additional_field"] = True
+        af = None
+        if THEORY == "mond":  # solver.py:360-374: Newtonian potential first
+            if SOLVER not in ("multigrid", "fft_7pt"):
+                raise NotImplementedError(f"{param['linear_newton_solver']=}, should be 'multigrid' or 'fft_7pt'")
+            ops.linear_operator_inplace(dens, f1, -f1)
+            af = solve(owned(additional_field), dens, None)
+        param["compute_additional_field"] = False
+        if THEORY == "mond":  # solver.py:381-443: density <- div[nu(|grad phi_N| / g0) grad phi_N]
+            g0 = (param["mond_g0"] * 1e-3 * 1e-10 * param["unit_t"] ** 2 / param["unit_l"]
+                  * param["aexp"] ** (1 + param["mond_scale_factor_exponent"]))
+            kinds = {"simple": 0, "n": 1, "beta": 2, "gamma": 3, "delta": 4}
+            fn = param["mond_function"].casefold()
+            if fn not in kinds:
+                raise NotImplementedError(f"MOND_FUNCTION={fn!r}, should be 'simple', 'n', 'beta', 'gamma' or 'delta'")
+            rhs = dens  # reused as the output buffer
+            mg.mond_rhs(af, rhs, g0, kinds[fn], param["mond_alpha"])
+        else:
+            rhs = dens
+            ops.linear_operator_inplace(rhs, f1, -f1)
+        pot0 = owned(potential)
+        warm = None
+        if pot0 is not None:  # solver.py:273-280
+            warm = np.float32(param["aexp"] * tables[3](np.log(param["aexp"]))
+                              / (param["aexp_old"] * tables[3](np.log(param["aexp_old"]))))
+        phi_lvl = solve(pot0, rhs, warm)
+        del rhs, dens
+        phi = phi_lvl[1:nx + 1]
+        acc = self._gather(phi, position, param, scheme, kick)
+        extra = af[1:nx + 1] if af is not None else torch.empty(0, dtype=torch.float32, device=dev)
+        return acc, phi, extra
 
     def _pm_replicated_grid(self, position, param, potential, additional_field, tables, kick, scheme):
         """Multigrid / f(R) / MOND / P(k) under slabs, first cut: the particles (deposit, gather, kick) stay

@@ -1,0 +1,202 @@
+"""Linear multigrid on x-slabs with halo exchange (multi-GPU; no reference counterpart: PySCo is
+single-process).  Mirrors pysco_amd/multigrid.py:linear / V_cycle (reference multigrid.py:23-83, 474-517)
+level by level; every level array is [nx_l + 2, n_l, n_l] -- the rank's planes of that level plus one
+ghost plane per side, refreshed from the ring neighbours before each kernel that reads x-neighbours
+(twice per Gauss-Seidel sweep: the black half needs the neighbours' fresh red values).  Arithmetic per
+cell is the single-GPU kernels' (same code, pmstep.h "slab" entry points); only the norms are summed in
+a different order (per rank, then all-reduce).
+
+Below the level where a rank would own fewer than two planes (or the grid is smaller than 16^3) the
+coarse problem is a few thousand cells: it is all-gathered and every rank runs the single-GPU V-cycle
+on it (deterministic, identical on all ranks), then takes its planes of the correction.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+
+import numpy as np
+
+from . import _lib as L
+from . import laplacian, multigrid
+
+
+class SlabMultigrid:
+    def __init__(self, slab):
+        self.slab = slab
+        self.torch = L.require_gpu()
+        self.world, self.rank = slab.world, slab.rank
+
+    # ---- level geometry / communication ---------------------------------------------------------
+    def _ctx(self, n):
+        return L.context(n)
+
+    def nx_of(self, n_l: int) -> int:
+        return n_l // self.world
+
+    def distributed(self, n_l: int) -> bool:
+        """This level is kept on slabs (every rank owns an even number >= 2 of planes, rows kernel applies)."""
+        nx = n_l // self.world
+        return n_l >= 16 and n_l % self.world == 0 and nx >= 2 and nx % 2 == 0
+
+    def new(self, n_l: int):
+        return self.torch.empty((self.nx_of(n_l) + 2, n_l, n_l), dtype=self.torch.float32, device="cuda")
+
+    def extend(self, owned):
+        """[nx, n, n] owned planes -> level array with (unfilled) ghosts."""
+        x = self.new(owned.shape[1])
+        x[1:-1].copy_(owned)
+        return x
+
+    def exchange(self, x) -> None:
+        """Fill the two ghost planes of a level array from the ring neighbours."""
+        from .slab import exchange_planes
+
+        nx = x.shape[0] - 2
+        from_left, from_right = exchange_planes(x[1], x[nx])
+        x[0].copy_(from_left)
+        x[nx + 1].copy_(from_right)
+
+    def all_sum(self, v: float) -> float:
+        from .slab import _dist
+
+        dist = _dist()
+        t = self.torch.tensor([v], dtype=self.torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def gather_full(self, x):
+        """Level array -> the full periodic [n, n, n] grid on every rank."""
+        from .slab import _dist, _stage, _unstage
+
+        dist = _dist()
+        mine = _stage(x[1:-1].contiguous())
+        parts = [self.torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        return _unstage(self.torch.cat(parts, dim=0), x)
+
+    # ---- level operations (pmstep.h slab entry points) ---------------------------------------------------
+    def smoothing(self, x, b, nsweeps: int) -> None:
+        n, nx = x.shape[1], x.shape[0] - 2
+        ctx = self._ctx(n)
+        x_lo = self.rank * nx
+        for _ in range(int(nsweeps)):
+            for colour in (1, 0):  # red, then black (laplacian.py:870-1022)
+                self.exchange(x)
+                ctx.call("pm_lap_gauss_seidel_slab", L.ptr(x), L.ptr(b), n, nx, x_lo, colour, 1.25)
+
+    def restrict_residual(self, x, b):
+        n, nx = x.shape[1], x.shape[0] - 2
+        out = self.new(n // 2)
+        self.exchange(x)
+        self._ctx(n).call("pm_lap_restrict_residual_slab", L.ptr(x), L.ptr(b), n, nx, L.ptr(out))
+        return out
+
+    def add_prolongation(self, x, x_c) -> None:
+        nc, nxc = x_c.shape[1], x_c.shape[0] - 2
+        self.exchange(x_c)
+        self._ctx(2 * nc).call("pm_prolongation_slab", L.ptr(x), L.ptr(x_c), nc, nxc, 1)
+
+    def initialise_potential(self, b):
+        """-h^2/6 * b (laplacian.py:765) on the whole level array."""
+        n = b.shape[1]
+        out = self.torch.empty_like(b)
+        h = np.float32(1.0 / n)
+        self._ctx(n).call("pm_linear_operator", L.ptr(out), L.ptr(b), float(np.float32(-float(h * h) / 6.0)), 0.0,
+                          b.numel())
+        return out
+
+    def residual_error(self, x, b) -> np.float32:
+        n, nx = x.shape[1], x.shape[0] - 2
+        self.exchange(x)
+        s = C.c_double(0)
+        self._ctx(n).call("pm_lap_residual_sumsq_slab", L.ptr(x), L.ptr(b), n, nx, C.byref(s))
+        return np.float32(np.sqrt(self.all_sum(s.value)))
+
+    def truncation_error(self, x) -> np.float32:
+        """|| R(L x) - L(R x) || (laplacian.py:502) on slabs."""
+        n, nx = x.shape[1], x.shape[0] - 2
+        ctx = self._ctx(n)
+        self.exchange(x)
+        Lx = self.torch.empty_like(x)
+        ctx.call("pm_lap_operator_slab", L.ptr(x), None, n, nx, 0, L.ptr(Lx))
+        RLx = self.new(n // 2)
+        ctx.call("pm_restriction_slab", L.ptr(Lx), n, nx, 0.125, L.ptr(RLx))
+        Rx = self.new(n // 2)
+        ctx.call("pm_restriction_slab", L.ptr(x), n, nx, 0.125, L.ptr(Rx))
+        self.exchange(Rx)
+        LRx = self.torch.empty_like(Rx)
+        self._ctx(n // 2).call("pm_lap_operator_slab", L.ptr(Rx), None, n // 2, nx // 2, 0, L.ptr(LRx))
+        s = C.c_double(0)
+        a, bb = RLx[1:-1], LRx[1:-1]  # owned planes: contiguous
+        ctx.call("pm_diff_sumsq", L.ptr(a), L.ptr(bb), 1.0, a.numel(), C.byref(s))
+        return np.float32(np.sqrt(self.all_sum(s.value)))
+
+    # ---- the cycle (multigrid.py:474-517) -----------------------------------------------------------------------
+    def V_cycle(self, x, b, param, nlevel: int = 0) -> None:
+        n = x.shape[1]
+        self.smoothing(x, b, param["Npre"])
+        res_c = self.restrict_residual(x, b)
+        n_c = n // 2
+        if self.distributed(n_c):
+            x_corr_c = self.initialise_potential(res_c)
+            if nlevel >= (param["ncoarse"] - 3):
+                self.smoothing(x_corr_c, res_c, param["Npre"])
+            else:
+                self.V_cycle(x_corr_c, res_c, param, nlevel + 1)
+        else:  # small coarse problem: every rank solves all of it
+            res_full = self.gather_full(res_c)
+            x_full = laplacian.initialise_potential(res_full)
+            if nlevel >= (param["ncoarse"] - 3):
+                laplacian.smoothing(x_full, res_full, param["Npre"])
+            else:
+                multigrid.V_cycle(x_full, res_full, param, nlevel + 1)
+            nxc = n_c // self.world if n_c % self.world == 0 else None
+            x_corr_c = self._take_planes(x_full, n_c, nxc)
+            del res_full, x_full
+        del res_c
+        if x_corr_c.shape[0] - 2 == (x.shape[0] - 2) // 2:
+            if self.distributed(n_c):
+                self.add_prolongation(x, x_corr_c)
+            else:  # ghosts already taken from the full grid
+                self._ctx(n).call("pm_prolongation_slab", L.ptr(x), L.ptr(x_corr_c), n_c, x_corr_c.shape[0] - 2, 1)
+        else:
+            raise RuntimeError("inconsistent slab multigrid geometry")
+        del x_corr_c
+        self.smoothing(x, b, param["Npost"])
+
+    def _take_planes(self, full, n_c: int, nxc):
+        """My planes (+ one periodic ghost each side) of a full coarse grid, as a level array."""
+        if nxc is None or nxc < 1:
+            raise ValueError(f"slab multigrid: {n_c} planes cannot be split over {self.world} ranks")
+        lo = self.rank * nxc
+        idx = self.torch.arange(lo - 1, lo + nxc + 1, device=full.device) % n_c
+        return full.index_select(0, idx).contiguous()
+
+    def linear(self, x, b, param):
+        """multigrid.linear (multigrid.py:23) on level arrays x, b ([nx+2, n, n]); in place on x."""
+        THEORY = param["theory"].casefold()
+        mond_pot = (not param["compute_additional_field"]) and "mond" == THEORY
+        if ("tolerance" not in param) or (param["nsteps"] % 3) == 0:
+            logging.info("Compute Truncation error")
+            tolerance = param["epsrel"] * self.truncation_error(x)
+            if mond_pot:
+                param["tolerance_mond"] = tolerance
+            else:
+                param["tolerance"] = tolerance
+        tolerance = param["tolerance_mond"] if mond_pot else param["tolerance"]
+        residual_err = 1e30
+        while residual_err > tolerance:
+            self.V_cycle(x, b, param)
+            residual_error_tmp = self.residual_error(x, b)
+            logging.info(f"{residual_error_tmp=} {tolerance=}")
+            if residual_error_tmp < tolerance or residual_err / residual_error_tmp < 2:
+                break
+            residual_err = residual_error_tmp
+        return x
+
+    def mond_rhs(self, pot, out, g0, kind: int, alpha) -> None:
+        n, nx = pot.shape[1], pot.shape[0] - 2
+        self.exchange(pot)
+        self._ctx(n).call("pm_mond_rhs_slab", L.ptr(pot), L.ptr(out), n, nx, float(np.float32(g0)), int(kind),
+                          float(np.float32(alpha)))

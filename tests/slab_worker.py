@@ -33,9 +33,16 @@ def main():
              "nsteps": 0}
     if len(sys.argv) > 8:
         param["integrator"] = sys.argv[8]
-    if len(sys.argv) > 10:  # e.g. "mond" / "fr" / "newton_mg": theories whose grid solve is replicated under slabs
+    if len(sys.argv) > 10:  # "mond" / "fr" / "newton_mg" [+ "_replicated": all-gathered density, replicated grid solve]
         kind = sys.argv[10]
-        param.update({"Npre": 2, "Npost": 1, "epsrel": 1e-2, "linear_newton_solver": "multigrid"})
+        if kind.endswith("_replicated"):
+            kind = kind[: -len("_replicated")]
+            slab._SLAB_MULTIGRID = False
+        if kind == "mond_fft7pt":
+            kind, solver_name = "mond", "fft_7pt"
+        else:
+            solver_name = "multigrid"
+        param.update({"Npre": 2, "Npost": 1, "epsrel": 1e-2, "linear_newton_solver": solver_name})
         if kind == "mond":
             param.update({"theory": "mond", "mond_function": "simple", "mond_g0": 1.2, "mond_alpha": 1,
                           "mond_scale_factor_exponent": 0})

@@ -47,9 +47,11 @@ def reference_run(n, steps, integrator="leapfrog", flow="sym", theory=None):
     param["integrator"] = integrator
     if theory:
         param.update({"Npre": 2, "Npost": 1, "epsrel": 1e-2, "linear_newton_solver": "multigrid"})
-        if theory == "mond":
+        if theory in ("mond", "mond_fft7pt"):
             param.update({"theory": "mond", "mond_function": "simple", "mond_g0": 1.2, "mond_alpha": 1,
                           "mond_scale_factor_exponent": 0})
+            if theory == "mond_fft7pt":
+                param["linear_newton_solver"] = "fft_7pt"
         elif theory == "fr":
             param.update({"theory": "fr", "fR_n": 1, "fR_logfR0": 5, "boxlen": 1000.0})
     param["t"] = float(tables[1](np.log(param["aexp"])))
@@ -129,20 +131,30 @@ def test_two_ranks_on_one_gpu_hip(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("theory", ["newton_mg", "mond", "fr"])
-def test_two_ranks_replicated_grid_solve_hip(tmp_path, theory):
-    """Multigrid / MOND / f(R) under slabs: decomposed particles + replicated grid solve (HIP kernels,
-    2 ranks sharing cuda:0 over gloo) against the single-process oracle, at the solvers' own accuracy."""
+@pytest.mark.parametrize("theory", ["newton_mg", "mond", "mond_fft7pt", "newton_mg_replicated", "mond_replicated", "fr"])
+def test_two_ranks_grid_solvers_hip(tmp_path, theory):
+    """Multigrid / MOND / f(R) under slabs (HIP kernels, 2 ranks sharing cuda:0 over gloo) against the
+    single-process oracle, at the solvers' own accuracy.  Newton-multigrid and QUMOND run decomposed: halo-exchange
+    V-cycles (slab_multigrid.py), the MOND source stencil on slabs, the slab FFT for fft_7pt; the `_replicated`
+    variants and f(R) all-gather the density and solve the grid on every rank."""
     n, steps, world = 32, 1, 2
     ranks = run_ranks(world, tmp_path, "hip", n, steps, theory=theory)
-    ref = reference_run(n, steps, theory=theory)
+    base = theory.replace("_replicated", "")
+    ref = reference_run(n, steps, theory=base)
     ids0 = np.concatenate([r["id0"] for r in ranks])
     acc0 = np.concatenate([r["acc0"] for r in ranks])
     sa = np.abs(ref["acc0"]).max()
     np.testing.assert_allclose(acc0, ref["acc0"][ids0], rtol=0, atol=2e-3 * sa)
-    for r in ranks:  # every rank holds the full potential (warm start of the next solve)
-        assert r["phi0"].shape == (n, n, n)
-        np.testing.assert_allclose(r["phi0"], ref["phi0"], rtol=0, atol=5e-4 * np.abs(ref["phi0"]).max())
+    decomposed = theory in ("newton_mg", "mond", "mond_fft7pt")
+    sp = np.abs(ref["phi0"]).max()
+    if decomposed:  # every rank holds its planes of the potential
+        phi0 = np.concatenate([r["phi0"] for r in ranks], axis=0)
+        assert phi0.shape == (n, n, n)
+        np.testing.assert_allclose(phi0, ref["phi0"], rtol=0, atol=5e-4 * sp)
+    else:           # every rank holds the full potential (warm start of the next solve)
+        for r in ranks:
+            assert r["phi0"].shape == (n, n, n)
+            np.testing.assert_allclose(r["phi0"], ref["phi0"], rtol=0, atol=5e-4 * sp)
     ids = np.concatenate([r["id"] for r in ranks])
     assert sorted(ids.tolist()) == list(range(n**3))
     pos = np.concatenate([r["pos"] for r in ranks])
