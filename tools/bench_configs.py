@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Secondary BASELINE configs on one GPU (development / reporting tool, not the driver's bench):
+"""Secondary BASELINE configs (development / reporting tool, not the driver's bench):
     python tools/bench_configs.py --ncells 512 --config fr|mond|newton_mg|newton_fft [--steps 3]
+Under torch.distributed.run (one rank per GPU; PMSTEP_DIST_BACKEND=gloo rehearses several ranks on one GPU) the
+run is slab-decomposed exactly as bench.py's.
 One leapfrog step = integration.integrate (dt selection, kick/drift/deposit, solve, gather/kick).
 Prints ms per step, multigrid cycle counts where the solver records them, and the per-stage table."""
 import argparse
@@ -26,6 +28,13 @@ def main():
     args = ap.parse_args()
     import torch
 
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(os.environ.get("PMSTEP_DIST_BACKEND", "nccl"))
     from bench import make_param, zeldovich_device
     from pysco_amd import _lib as L
     from pysco_amd import integration, solver, utils
@@ -48,6 +57,12 @@ def main():
     utils.set_units(param)
     pos, vel = zeldovich_device(n)
     utils.periodic_wrap(pos)
+    if world > 1:
+        from pysco_amd import slab
+
+        sl = slab.get(n)
+        lo, hi = sl.x_lo * n * n, (sl.x_lo + sl.nx) * n * n
+        pos, vel = sl.migrate(pos[lo:hi].clone(), vel[lo:hi].clone())
     pos, vel = utils.reorder_particles(pos, vel)
     if args.scan_boxlen:
         for b in [float(x) for x in args.scan_boxlen.split(",")]:
@@ -74,12 +89,20 @@ def main():
     wall = time.perf_counter() - t0
     stages = L.profile_stop()
     assert bool(torch.isfinite(pos).all()) and bool(torch.isfinite(acc).all())
-    print(json.dumps({"config": args.config, "ncells": n, "ms_per_step": 1e3 * wall / args.steps,
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    print(json.dumps({"config": args.config, "ncells": n, "ranks": world, "ms_per_step": 1e3 * wall / args.steps,
                       "particles_per_s": n**3 * args.steps / wall}))
     tot = sum(ms for _, ms in stages.values())
     for name, (calls, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1])[:18]:
         print(f"  {name:34s} calls/step {calls / args.steps:8.1f}  ms/step {ms / args.steps:9.3f}  avg {ms / calls:8.4f} ms")
     print(f"  (sum of stage events {tot / args.steps:.1f} ms/step)")
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
