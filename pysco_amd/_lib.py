@@ -110,6 +110,9 @@ def load_library():
                 f"{LIB_PATH} not found: build the HIP extension first (python -m pysco_amd.build). "
                 "pysco_amd has no CPU fallback."
             )
+        # torch first: it ships its own HIP runtime, and libpmstep must bind to that one (loaded the other way
+        # round the process ends up with two runtimes and ours sees no device)
+        _torch()
         lib = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
