@@ -112,6 +112,15 @@ int pm_poisson_fft_fused(pm_ctx *ctx, int kind, int p, const float *d_rhs, float
  *                     x-slabs delivers -- x forward, G(kx, ky0+ky, kz)/n^3, x inverse
  *   pm_fftp_inverse : d_C [n, n/2+1, nx]            -> d_phi [nx,n,n] real              (y inverse + z c2r) */
 int pm_fftp_forward(pm_ctx *ctx, const float *d_rhs, int nx, void *d_C);
+/* The same stage by stage, so that a slab driver can pipeline the passes against its all-to-alls: the y passes
+ * and the x pass take a kz range [kz0, kz0 + nkz) and work on a spectrum chunk [n (ky), nkz, nx] (after the
+ * all-to-all: [nseg][nky][nkz][nx]); the z passes go through the context's internal B buffer (all kz). */
+int pm_fftp_z_forward(pm_ctx *ctx, const float *d_rhs, int nx);
+int pm_fftp_y_forward(pm_ctx *ctx, int nx, int kz0, int nkz, void *d_C);
+int pm_fftp_xgreen_kz(pm_ctx *ctx, int kind, int p, void *d_C, int nx, int nky, int ky0, int kz0, int nkz,
+                      const float *h_k2, const float *h_s, float c0);
+int pm_fftp_y_inverse(pm_ctx *ctx, const void *d_C, int nx, int kz0, int nkz);
+int pm_fftp_z_inverse(pm_ctx *ctx, int nx, float *d_phi);
 int pm_fftp_xgreen(pm_ctx *ctx, int kind, int p, void *d_C, int nx, int nky, int ky0, const float *h_k2,
                    const float *h_s, float c0);
 int pm_fftp_inverse(pm_ctx *ctx, const void *d_C, int nx, float *d_phi);

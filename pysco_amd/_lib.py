@@ -53,6 +53,11 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_fftp_forward": (_vp, _vp, _i, _vp),
     "pm_fftp_xgreen": (_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _f),
     "pm_fftp_inverse": (_vp, _vp, _i, _vp),
+    "pm_fftp_z_forward": (_vp, _vp, _i),
+    "pm_fftp_y_forward": (_vp, _i, _i, _i, _vp),
+    "pm_fftp_xgreen_kz": (_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f),
+    "pm_fftp_y_inverse": (_vp, _vp, _i, _i, _i),
+    "pm_fftp_z_inverse": (_vp, _i, _vp),
     "pm_kick_drift_wrap": (_vp, _vp, _vp, _vp, _f, _f, _i64),
     "pm_interp_kick": (_vp, _i, _vp, _vp, _i64, _vp, _vp, _f),
     "pm_tile_lists": (_vp, _vp, _i64),

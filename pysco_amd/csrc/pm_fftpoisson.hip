@@ -286,7 +286,9 @@ __device__ __forceinline__ int64_t c_index(int ky, int kz, int x, int n, int nh,
 template <bool FORWARD>
 __global__ __launch_bounds__(FBLK) void fftp_y(float2 *__restrict__ B, float2 *__restrict__ C,
                                                const float2 *__restrict__ g_tw, int n, int log2n, int nx,
-                                               int kzmajor) {
+                                               int kzmajor, int kz0, int nkz) {
+    // C holds the kz range [kz0, kz0 + nkz) only (slab layout: [ky][nkz][nx]; the whole spectrum is kz0 = 0,
+    // nkz = n/2 + 1); B always holds all of it
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *buf = lds, *tw = lds + 8 * NP(n);
     const int nh = (n >> 1) + 1;
@@ -296,8 +298,8 @@ __global__ __launch_bounds__(FBLK) void fftp_y(float2 *__restrict__ B, float2 *_
     // and HBM sees whole lines (PMC before: the inverse pass fetched 2x its bytes).
     unsigned grp = blockIdx.x;
     if (grp < (gridDim.x & ~15u)) grp = (grp & ~15u) + ((grp & 7u) << 1) + ((grp >> 3) & 1u);
-    const int64_t line0 = (int64_t)grp * 8;  // flat (kz*nx + x), nx = local x planes (multiple of 8)
-    const int kz = (int)(line0 / nx), x0 = (int)(line0 - (int64_t)kz * nx);
+    const int64_t line0 = (int64_t)grp * 8;  // flat (kz_local*nx + x), nx = local x planes (multiple of 8)
+    const int kzl = (int)(line0 / nx), x0 = (int)(line0 - (int64_t)kzl * nx), kz = kz0 + kzl;
     load_twiddles(tw, g_tw, n, log2n);
     // transposed side: thread = (ky, pair of x) -> one 16-byte access; 4 lanes cover the 64-byte piece
     const int lx = (threadIdx.x & 3) << 1;
@@ -307,11 +309,11 @@ __global__ __launch_bounds__(FBLK) void fftp_y(float2 *__restrict__ B, float2 *_
         fft_forward_lds(buf, tw, n, log2n, 8);
         for (int ky = threadIdx.x >> 2; ky < n; ky += FBLK / 4) {
             const float2 a = buf[lx * NP(n) + PADI(ky)], b = buf[(lx + 1) * NP(n) + PADI(ky)];
-            *reinterpret_cast<float4 *>(C + c_index(ky, kz, x0 + lx, n, nh, nx, kzmajor)) = make_float4(a.x, a.y, b.x, b.y);
+            *reinterpret_cast<float4 *>(C + c_index(ky, kzl, x0 + lx, n, nkz, nx, kzmajor)) = make_float4(a.x, a.y, b.x, b.y);
         }
     } else {
         for (int ky = threadIdx.x >> 2; ky < n; ky += FBLK / 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(C + c_index(ky, kz, x0 + lx, n, nh, nx, kzmajor));
+            const float4 v = *reinterpret_cast<const float4 *>(C + c_index(ky, kzl, x0 + lx, n, nkz, nx, kzmajor));
             buf[lx * NP(n) + PADI(ky)] = make_float2(v.x, v.y);
             buf[(lx + 1) * NP(n) + PADI(ky)] = make_float2(v.z, v.w);
         }
@@ -332,22 +334,23 @@ template <int KIND>
 __global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, const float2 *__restrict__ g_tw, int n,
                                                      int log2n, int p, const float *__restrict__ k2,
                                                      const float *__restrict__ s, float c0, float norm, int nx,
-                                                     int nky, int ky0, int kzmajor) {
+                                                     int nky, int ky0, int kzmajor, int kz0, int nkz) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *buf = lds, *tw = lds + 8 * NP(n);
     const int nh = (n >> 1) + 1;
     const int64_t line0 = (int64_t)blockIdx.x * 8;
     load_twiddles(tw, g_tw, n, log2n);
-    const int64_t nlines_total = (int64_t)nky * nh;
+    const int64_t nlines_total = (int64_t)nky * nkz;
     __syncthreads();  // twiddle table; from here on every wave works on its own line, no workgroup barrier
     const int l = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t line = line0 + l;
     float2 *ln = buf + l * NP(n);
-    // line index: ky_local * nh + kz, or kz * n + ky on a single GPU (kzmajor, where nseg = 1)
-    const int kyl = kzmajor ? (int)(line & (n - 1)) : (int)(line / nh);
-    const int kz = kzmajor ? (int)(line >> log2n) : (int)(line - (int64_t)kyl * nh), ky = ky0 + kyl;
+    // line index: ky_local * nkz + kz_local, or kz_local * n + ky on a single GPU (kzmajor, where nseg = 1)
+    const int kyl = kzmajor ? (int)(line & (n - 1)) : (int)(line / nkz);
+    const int kzl = kzmajor ? (int)(line >> log2n) : (int)(line - (int64_t)kyl * nkz);
+    const int kz = kz0 + kzl, ky = ky0 + kyl;
     auto xaddr = [&](int e) -> int64_t {
-        if (kzmajor) return c_index(kyl, kz, e, n, nh, nx, 1);
+        if (kzmajor) return c_index(kyl, kzl, e, n, nkz, nx, 1);
         const int seg = e / nx, xl = e - seg * nx;
         return ((int64_t)seg * nlines_total + line) * nx + xl;
     };
@@ -469,60 +472,101 @@ static inline size_t fftp_lds_bytes(int n) {
 #define FFTP_CHECK_N(c)                                                                                        \
     PM_REQUIRE((c)->n >= 32 && (c)->n <= 1024, "LDS-FFT passes support 32 <= n <= 1024 (use the rocFFT entry points otherwise)")
 
-// P1 + P2 on nx local x-planes: d_rhs [nx, n, n] real -> d_C [n (ky), n/2+1 (kz), nx] complex
-static int fftp_forward_impl(pm_ctx *c, const float *d_rhs, int nx, void *d_C, int kzmajor) {
-    PM_REQUIRE(c && d_rhs && d_C, "NULL argument");
+// ---- stages (each a C-ABI entry point so that a slab driver can pipeline them against its all-to-alls) ----
+// P1: d_rhs [nx, n, n] real -> the context's B (all kz)
+static int fftp_z_forward(pm_ctx *c, const float *d_rhs, int nx) {
+    PM_REQUIRE(c && d_rhs, "NULL argument");
     FFTP_CHECK_N(c);
     const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
     PM_REQUIRE(nx >= 8 && nx <= n && (nx % 8) == 0, "nx must be a multiple of 8 in [8, n]");
-    PM_REQUIRE(pm_aligned16(d_rhs) && pm_aligned16(d_C), "buffers must be 16-byte aligned");
+    PM_REQUIRE(pm_aligned16(d_rhs), "buffers must be 16-byte aligned");
     int rc = ensure_fused_buffers(c, (size_t)nh * nx * n * sizeof(float2), 0);
     if (rc) return rc;
-    const float2 *tw = (const float2 *)c->fp_tw;
-    const size_t lds = fftp_lds_bytes(n);
-    hipLaunchKernelGGL(fftp_z_r2c, dim3((unsigned)((int64_t)nx * n / 16)), dim3(FBLK), lds, c->stream, d_rhs,
-                       (float2 *)c->fp_B, tw, n, log2n, nx);
-    hipLaunchKernelGGL((fftp_y<true>), dim3((unsigned)((int64_t)nh * nx / 8)), dim3(FBLK), lds, c->stream,
-                       (float2 *)c->fp_B, (float2 *)d_C, tw, n, log2n, nx, kzmajor);
+    hipLaunchKernelGGL(fftp_z_r2c, dim3((unsigned)((int64_t)nx * n / 16)), dim3(FBLK), fftp_lds_bytes(n), c->stream,
+                       d_rhs, (float2 *)c->fp_B, (const float2 *)c->fp_tw, n, log2n, nx);
     PM_LAUNCH_CHECK();
     return PM_OK;
 }
 
+// P2 / P4 for the kz range [kz0, kz0 + nkz): B <-> d_C [n (ky), nkz, nx] (slab layout) or kz-major
+static int fftp_y_pass(pm_ctx *c, bool forward, void *d_C, int nx, int kz0, int nkz, int kzmajor) {
+    PM_REQUIRE(c && d_C, "NULL argument");
+    FFTP_CHECK_N(c);
+    const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
+    PM_REQUIRE(nx >= 8 && nx <= n && (nx % 8) == 0, "nx must be a multiple of 8 in [8, n]");
+    PM_REQUIRE(kz0 >= 0 && nkz >= 1 && kz0 + nkz <= nh, "bad kz range");
+    PM_REQUIRE(pm_aligned16(d_C), "buffers must be 16-byte aligned");
+    int rc = ensure_fused_buffers(c, (size_t)nh * nx * n * sizeof(float2), 0);
+    if (rc) return rc;
+    const float2 *tw = (const float2 *)c->fp_tw;
+    const unsigned grid = (unsigned)((int64_t)nkz * nx / 8);
+    if (forward)
+        hipLaunchKernelGGL((fftp_y<true>), dim3(grid), dim3(FBLK), fftp_lds_bytes(n), c->stream, (float2 *)c->fp_B,
+                           (float2 *)d_C, tw, n, log2n, nx, kzmajor, kz0, nkz);
+    else
+        hipLaunchKernelGGL((fftp_y<false>), dim3(grid), dim3(FBLK), fftp_lds_bytes(n), c->stream, (float2 *)c->fp_B,
+                           (float2 *)d_C, tw, n, log2n, nx, kzmajor, kz0, nkz);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// P5: the context's B -> d_phi [nx, n, n] real
+static int fftp_z_inverse(pm_ctx *c, int nx, float *d_phi) {
+    PM_REQUIRE(c && d_phi, "NULL argument");
+    FFTP_CHECK_N(c);
+    const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
+    PM_REQUIRE(nx >= 8 && nx <= n && (nx % 8) == 0, "nx must be a multiple of 8 in [8, n]");
+    PM_REQUIRE(pm_aligned16(d_phi), "buffers must be 16-byte aligned");
+    int rc = ensure_fused_buffers(c, (size_t)nh * nx * n * sizeof(float2), 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fftp_z_c2r, dim3((unsigned)((int64_t)nx * n / 16)), dim3(FBLK), fftp_lds_bytes(n), c->stream,
+                       (const float2 *)c->fp_B, d_phi, (const float2 *)c->fp_tw, n, log2n, nx);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+extern "C" int pm_fftp_z_forward(pm_ctx *c, const float *d_rhs, int nx) { return fftp_z_forward(c, d_rhs, nx); }
+extern "C" int pm_fftp_y_forward(pm_ctx *c, int nx, int kz0, int nkz, void *d_C) {
+    return fftp_y_pass(c, true, d_C, nx, kz0, nkz, 0);
+}
+extern "C" int pm_fftp_y_inverse(pm_ctx *c, const void *d_C, int nx, int kz0, int nkz) {
+    return fftp_y_pass(c, false, const_cast<void *>(d_C), nx, kz0, nkz, 0);
+}
+extern "C" int pm_fftp_z_inverse(pm_ctx *c, int nx, float *d_phi) { return fftp_z_inverse(c, nx, d_phi); }
+
+// P1 + P2 on nx local x-planes: d_rhs [nx, n, n] real -> d_C [n (ky), n/2+1 (kz), nx] complex
+static int fftp_forward_impl(pm_ctx *c, const float *d_rhs, int nx, void *d_C, int kzmajor) {
+    int rc = fftp_z_forward(c, d_rhs, nx);
+    if (rc) return rc;
+    return fftp_y_pass(c, true, d_C, nx, 0, c->n / 2 + 1, kzmajor);
+}
+
 extern "C" int pm_fftp_forward(pm_ctx *c, const float *d_rhs, int nx, void *d_C) {
+    PM_REQUIRE(d_C, "NULL argument");
     return fftp_forward_impl(c, d_rhs, nx, d_C, 0);
 }
 
 // P4 + P5: d_C [n, n/2+1, nx] -> d_phi [nx, n, n] real (d_C is read only)
 static int fftp_inverse_impl(pm_ctx *c, const void *d_C, int nx, float *d_phi, int kzmajor) {
-    PM_REQUIRE(c && d_phi && d_C, "NULL argument");
-    FFTP_CHECK_N(c);
-    const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
-    PM_REQUIRE(nx >= 8 && nx <= n && (nx % 8) == 0, "nx must be a multiple of 8 in [8, n]");
-    PM_REQUIRE(pm_aligned16(d_phi) && pm_aligned16(d_C), "buffers must be 16-byte aligned");
-    int rc = ensure_fused_buffers(c, (size_t)nh * nx * n * sizeof(float2), 0);
+    PM_REQUIRE(c, "NULL argument");
+    int rc = fftp_y_pass(c, false, const_cast<void *>(d_C), nx, 0, c->n / 2 + 1, kzmajor);
     if (rc) return rc;
-    const float2 *tw = (const float2 *)c->fp_tw;
-    const size_t lds = fftp_lds_bytes(n);
-    hipLaunchKernelGGL((fftp_y<false>), dim3((unsigned)((int64_t)nh * nx / 8)), dim3(FBLK), lds, c->stream,
-                       (float2 *)c->fp_B, (float2 *)const_cast<void *>(d_C), tw, n, log2n, nx, kzmajor);
-    hipLaunchKernelGGL(fftp_z_c2r, dim3((unsigned)((int64_t)nx * n / 16)), dim3(FBLK), lds, c->stream,
-                       (const float2 *)c->fp_B, d_phi, tw, n, log2n, nx);
-    PM_LAUNCH_CHECK();
-    return PM_OK;
+    return fftp_z_inverse(c, nx, d_phi);
 }
 
 extern "C" int pm_fftp_inverse(pm_ctx *c, const void *d_C, int nx, float *d_phi) {
     return fftp_inverse_impl(c, d_C, nx, d_phi, 0);
 }
 
-// P3 in place on d_C laid out [nseg = n/nx][nky][n/2+1][nx]: the lines (ky0 + ky_local, kz) along x
+// P3 in place on d_C laid out [nseg = n/nx][nky][nkz][nx]: the lines (ky0 + ky_local, kz0 + kz_local) along x
 static int fftp_xgreen_impl(pm_ctx *c, int kind, int p, void *d_C, int nx, int nky, int ky0, const float *h_k2,
-                            const float *h_s, float c0, int kzmajor) {
+                            const float *h_s, float c0, int kzmajor, int kz0, int nkz) {
     PM_REQUIRE(c && d_C && h_k2 && h_s, "NULL argument");
     FFTP_CHECK_N(c);
     const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
     PM_REQUIRE(nx >= 8 && nx <= n && (n % nx) == 0 && (nx % 2) == 0, "nx must divide n");
     PM_REQUIRE(nky >= 8 && (nky % 8) == 0 && ky0 >= 0 && ky0 + nky <= n, "bad ky range (multiple of 8 lines)");
+    PM_REQUIRE(kz0 >= 0 && nkz >= 1 && kz0 + nkz <= nh, "bad kz range");
     PM_REQUIRE(kind == PM_GREEN_PLAIN || kind == PM_GREEN_COMPENSATED || kind == PM_GREEN_7PT,
                "unknown Green's function kind");
     PM_REQUIRE(pm_aligned16(d_C), "buffers must be 16-byte aligned");
@@ -541,20 +585,20 @@ static int fftp_xgreen_impl(pm_ctx *c, int kind, int p, void *d_C, int nx, int n
     const float2 *tw = (const float2 *)c->fp_tw;
     const size_t lds = fftp_lds_bytes(n);
     const float norm = (float)(1.0 / ((double)n * n * n));
-    const unsigned g3 = (unsigned)((int64_t)nky * nh / 8);
+    const unsigned g3 = (unsigned)((int64_t)nky * nkz / 8);
     float2 *C = (float2 *)d_C;
     switch (kind) {
         case PM_GREEN_PLAIN:
             hipLaunchKernelGGL((fftp_x_green<PM_GREEN_PLAIN>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n, log2n, p,
-                               c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0, kzmajor);
+                               c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0, kzmajor, kz0, nkz);
             break;
         case PM_GREEN_COMPENSATED:
             hipLaunchKernelGGL((fftp_x_green<PM_GREEN_COMPENSATED>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n,
-                               log2n, p, c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0, kzmajor);
+                               log2n, p, c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0, kzmajor, kz0, nkz);
             break;
         default:
             hipLaunchKernelGGL((fftp_x_green<PM_GREEN_7PT>), dim3(g3), dim3(FBLK), lds, c->stream, C, tw, n, log2n, p,
-                               c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0, kzmajor);
+                               c->d_tab, c->d_tab + n, c0, norm, nx, nky, ky0, kzmajor, kz0, nkz);
             break;
     }
     PM_LAUNCH_CHECK();
@@ -563,7 +607,14 @@ static int fftp_xgreen_impl(pm_ctx *c, int kind, int p, void *d_C, int nx, int n
 
 extern "C" int pm_fftp_xgreen(pm_ctx *c, int kind, int p, void *d_C, int nx, int nky, int ky0, const float *h_k2,
                               const float *h_s, float c0) {
-    return fftp_xgreen_impl(c, kind, p, d_C, nx, nky, ky0, h_k2, h_s, c0, 0);
+    PM_REQUIRE(c, "NULL argument");
+    return fftp_xgreen_impl(c, kind, p, d_C, nx, nky, ky0, h_k2, h_s, c0, 0, 0, c->n / 2 + 1);
+}
+
+// the same for a spectrum holding the kz range [kz0, kz0 + nkz) only: [nseg][nky][nkz][nx]
+extern "C" int pm_fftp_xgreen_kz(pm_ctx *c, int kind, int p, void *d_C, int nx, int nky, int ky0, int kz0, int nkz,
+                                 const float *h_k2, const float *h_s, float c0) {
+    return fftp_xgreen_impl(c, kind, p, d_C, nx, nky, ky0, h_k2, h_s, c0, 0, kz0, nkz);
 }
 
 extern "C" int pm_poisson_fft_fused(pm_ctx *c, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
@@ -575,7 +626,7 @@ extern "C" int pm_poisson_fft_fused(pm_ctx *c, int kind, int p, const float *d_r
     if (rc) return rc;
     rc = fftp_forward_impl(c, d_rhs, n, c->fp_C, 1);  // single GPU: C is kz-major (see the header)
     if (rc) return rc;
-    rc = fftp_xgreen_impl(c, kind, p, c->fp_C, n, n, 0, h_k2, h_s, c0, 1);
+    rc = fftp_xgreen_impl(c, kind, p, c->fp_C, n, n, 0, h_k2, h_s, c0, 1, 0, n / 2 + 1);
     if (rc) return rc;
     return fftp_inverse_impl(c, c->fp_C, n, d_phi, 1);
 }

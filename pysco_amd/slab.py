@@ -163,6 +163,30 @@ class HipOps:
             c0 = float(np.float32(c0) * np.float32(scale))
         self.ctx.call("pm_fftp_xgreen", kind, int(p), L.ptr(seg), nx, nky, ky0, L.hptr(k2), L.hptr(s), c0)
 
+    # stage-wise forms (pipelined against the all-to-alls)
+    def fftp_z_forward(self, rhs):
+        self.ctx.call("pm_fftp_z_forward", L.ptr(rhs), rhs.shape[0])
+
+    def fftp_y_forward(self, nx, kz0, nkz):
+        out = self.torch.empty((self.n, nkz, nx), dtype=self.torch.complex64, device="cuda")
+        self.ctx.call("pm_fftp_y_forward", nx, kz0, nkz, L.ptr(out))
+        return out
+
+    def fftp_xgreen_kz(self, seg, kind, p, nx, nky, ky0, kz0, nkz, scale=None):
+        k2, s, c0 = fourier.green_tables(self.n, kind)
+        if scale is not None:
+            c0 = float(np.float32(c0) * np.float32(scale))
+        self.ctx.call("pm_fftp_xgreen_kz", kind, int(p), L.ptr(seg), nx, nky, ky0, kz0, nkz, L.hptr(k2), L.hptr(s), c0)
+
+    def fftp_y_inverse(self, c, nx, kz0, nkz):
+        self.ctx.call("pm_fftp_y_inverse", L.ptr(c), nx, kz0, nkz)
+
+    def fftp_z_inverse(self, nx):
+        n = self.n
+        out = self.torch.empty((nx, n, n), dtype=self.torch.float32, device="cuda")
+        self.ctx.call("pm_fftp_z_inverse", nx, L.ptr(out))
+        return out
+
     def fftp_inverse(self, c, nx):
         n = self.n
         out = self.torch.empty((nx, n, n), dtype=self.torch.float32, device=c.device)
@@ -206,6 +230,25 @@ def all_to_all(send, out_splits: Optional[List[int]] = None, in_splits: Optional
     return _unstage(out, send)
 
 
+class _AllToAllHandle:
+    """An all_to_all in flight (equal splits along dim 0): wait() gives the received tensor."""
+
+    def __init__(self, send):
+        import torch
+
+        dist = _dist()
+        self.like = send
+        self.src = _stage(send.contiguous())  # kept alive until wait()
+        self.out = torch.empty_like(self.src)
+        a, b = (torch.view_as_real(self.out), torch.view_as_real(self.src)) if self.src.is_complex() else (self.out, self.src)
+        self.work = dist.all_to_all_single(a, b, async_op=True)
+
+    def wait(self):
+        self.work.wait()  # nccl: the current stream waits, not the host
+        out, self.src = _unstage(self.out, self.like), None
+        return out
+
+
 def exchange_planes(to_left, to_right):
     """Send `to_left` to rank-1 and `to_right` to rank+1 (periodic); returns (from_left, from_right)."""
     import torch
@@ -236,6 +279,7 @@ def all_reduce_max(values: List[float], device) -> List[float]:
 # ------------------------------------------------------------------------------------------------
 
 
+_PIPELINE_FFT = True    # False: the slab FFT exchanges the whole spectrum in one all-to-all each way
 _SLAB_MULTIGRID = True  # False: multigrid / MOND under slabs all-gather the density and solve replicated
 
 
@@ -602,6 +646,28 @@ class Slab:
             kind, p = (L.GREEN_PLAIN, 0) if MAS_index == 0 else (L.GREEN_COMPENSATED, int(MAS_index))
         else:
             kind, p = L.GREEN_7PT, 0
+        if getattr(ops, "has_fftp", None) and ops.has_fftp(nx, ny) and hasattr(ops, "fftp_y_forward") and _PIPELINE_FFT:
+            # The same in chunks of kz so that the all-to-alls (xGMI) run under the FFT passes (HBM) of the
+            # neighbouring chunks: y forward of chunk c+1 while chunk c is in flight, x pass of chunk c while
+            # c+1 arrives and c-1 returns, y inverse likewise.
+            nchunk = 4 if nh >= 16 else 1
+            base, rem = divmod(nh, nchunk)
+            ranges, k0 = [], 0
+            for i in range(nchunk):
+                ranges.append((k0, base + (1 if i < rem else 0)))
+                k0 += ranges[-1][1]
+            ops.fftp_z_forward(rhs)
+            fwd = [_AllToAllHandle(ops.fftp_y_forward(nx, kz0, nkz)) for kz0, nkz in ranges]   # [n (ky), nkz, nx] each
+            bwd = []
+            for (kz0, nkz), h in zip(ranges, fwd):
+                seg = h.wait()                                                 # [G (src), ny, nkz, nx]
+                ops.fftp_xgreen_kz(seg, kind, p, nx, ny, self.rank * ny, kz0, nkz, scale)
+                bwd.append(_AllToAllHandle(seg))
+            del fwd
+            for (kz0, nkz), h in zip(ranges, bwd):
+                ops.fftp_y_inverse(h.wait(), nx, kz0, nkz)
+            del bwd
+            return ops.fftp_z_inverse(nx)
         if getattr(ops, "has_fftp", None) and ops.has_fftp(nx, ny):
             # LDS-FFT passes: the forward stage already writes [ky][kz][x_local], so both all-to-alls
             # exchange contiguous blocks and the x pass reads its lines as G segments of nx elements

@@ -572,3 +572,48 @@ def test_fftp_stages_on_slabs_match_fused(amd, nseg):
         ctx.call("pm_fftp_inverse", L.ptr(back), nx, L.ptr(out))
         phi[r * nx:(r + 1) * nx] = out
     assert torch.equal(phi, ref)
+
+
+@pytest.mark.parametrize("nseg", [2, 4])
+def test_fftp_kz_chunked_stages_match_fused(amd, nseg):
+    """The stage-wise entry points a slab driver pipelines against its all-to-alls (z forward; y forward, x pass
+    and y inverse per kz chunk; z inverse), with uneven kz chunks and the all-to-all emulated on one GPU:
+    bit-identical to pm_poisson_fft_fused.  One context per emulated rank (each owns its B buffer)."""
+    import pysco_amd._lib as L
+    from pysco_amd import fourier
+
+    torch = amd.torch
+    n = 64
+    nx = ny = n // nseg
+    nh = n // 2 + 1
+    rhs = torch.randn((n, n, n), dtype=torch.float32, device="cuda")
+    ctx = L.context(n)
+    k2, s, c0 = fourier.green_tables(n, L.GREEN_7PT)
+    ref = torch.empty_like(rhs)
+    ctx.call("pm_poisson_fft_fused", L.GREEN_7PT, 0, L.ptr(rhs), L.ptr(ref), L.hptr(k2), L.hptr(s), c0)
+    ranges = [(0, 9), (9, 8), (17, 8), (25, 8)]
+    assert sum(r[1] for r in ranges) == nh
+    phi = torch.empty_like(rhs)
+    # the context's B holds one rank's spectrum at a time: keep every rank's chunks, then finish rank by rank
+    chunks = {}
+    for r in range(nseg):
+        ctx.call("pm_fftp_z_forward", L.ptr(rhs[r * nx:(r + 1) * nx].contiguous()), nx)
+        for kz0, nkz in ranges:
+            c = torch.empty((n, nkz, nx), dtype=torch.complex64, device="cuda")
+            ctx.call("pm_fftp_y_forward", nx, kz0, nkz, L.ptr(c))
+            chunks[(r, kz0)] = c
+    segs = {}
+    for kz0, nkz in ranges:
+        for q in range(nseg):  # "all-to-all" + x pass on rank q
+            seg = torch.stack([chunks[(r, kz0)][q * ny:(q + 1) * ny] for r in range(nseg)], dim=0).contiguous()
+            ctx.call("pm_fftp_xgreen_kz", L.GREEN_7PT, 0, L.ptr(seg), nx, ny, q * ny, kz0, nkz, L.hptr(k2), L.hptr(s), c0)
+            segs[(q, kz0)] = seg
+    for r in range(nseg):
+        for kz0, nkz in ranges:
+            back = torch.cat([segs[(q, kz0)][r] for q in range(nseg)], dim=0).contiguous()  # [n (ky), nkz, nx]
+            ctx.call("pm_fftp_y_inverse", L.ptr(back), nx, kz0, nkz)
+        out = torch.empty((nx, n, n), dtype=torch.float32, device="cuda")
+        ctx.call("pm_fftp_z_inverse", nx, L.ptr(out))
+        phi[r * nx:(r + 1) * nx] = out
+    assert torch.equal(phi, ref)
+
