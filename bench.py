@@ -239,6 +239,10 @@ def main():
                    "pm_fft2d_r2c": 16.0 * cells, "pm_fft2d_c2r": 16.0 * cells, "pm_fft1d_x": 2.0 * spec,
                    "pm_greens_slab": 2.0 * spec, "pm_gradient_slab": 16.0 * cells,
                    "pm_fftp_forward": 16.0 * cells, "pm_fftp_inverse": 16.0 * cells, "pm_fftp_xgreen": 2.0 * spec,
+                   # pipelined form: z passes whole, y / x passes per kz chunk (4 chunks)
+                   "pm_fftp_z_forward": 8.0 * cells, "pm_fftp_z_inverse": 8.0 * cells,
+                   "pm_fftp_y_forward": 2.0 * spec / 4, "pm_fftp_y_inverse": 2.0 * spec / 4,
+                   "pm_fftp_xgreen_kz": 2.0 * spec / 4,
                    "pm_kick_drift_wrap_slab": 60.0 * npart / world})
     table = []
     for name, (calls, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):

@@ -211,6 +211,10 @@ int pm_mond_rhs(pm_ctx *ctx, const float *d_pot, float *d_out, int n, float g0, 
  * pm_interp_kick) that local plane 0 is global plane x0 (periodic) and that there are nx planes.
  * Default (single GPU): nx = n, x0 = 0. */
 int pm_set_slab(pm_ctx *ctx, int nx, int x0);
+/* Planes [x_lo, x_lo + nx) that ALL particles handed to the tile-range kernels live in (a rank's owned planes
+ * after migration): only the tiles of that window get a workgroup instead of the whole mesh's.  x_lo and nx
+ * multiples of 8, nx/8 a power of two; anything else (and the default 0, n) enumerates every tile. */
+int pm_set_tile_window(pm_ctx *ctx, int x_lo, int nx);
 /* gradient on a slab: d_phi holds nx_phi planes from global plane x0_phi, d_force receives nx_force
  * planes from x0_force; needs phi on [x0_force - R, x0_force + nx_force + R), R = 1, 1, 2, 3 for order 2, 3, 5, 7 */
 int pm_gradient_slab(pm_ctx *ctx, int order, const float *d_phi, int nx_phi, int x0_phi, float *d_force,

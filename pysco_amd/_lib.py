@@ -82,6 +82,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_quartic_gauss_seidel": (_vp, _vp, _vp, _f, _vp, _i, _f),
     "pm_mond_rhs": (_vp, _vp, _vp, _i, _f, _i, _f),
     "pm_set_slab": (_vp, _i, _i),
+    "pm_set_tile_window": (_vp, _i, _i),
     "pm_lap_gauss_seidel_slab": (_vp, _vp, _vp, _i, _i, _i, _i, _f),
     "pm_lap_restrict_residual_slab": (_vp, _vp, _vp, _i, _i, _vp),
     "pm_restriction_slab": (_vp, _vp, _i, _i, _f, _vp),

@@ -140,6 +140,7 @@ struct pm_ctx {
     void *tile_tmp;
     size_t tile_tmp_bytes;
     int gather_mode;  // 1: tile-range gather (default), 2: chunk/anchor gather
+    int tile_x_lo, tile_nx;  // planes the particles live in (pm_set_tile_window); 0, n on a single GPU
     // prepared tile ranges + straggler lists (pm_tile_lists): valid for exactly these positions
     const float *lists_pos;
     int64_t lists_np;

@@ -655,7 +655,9 @@ __global__ __launch_bounds__(BLK) void tile_extra_kernel(const int64_t *__restri
 struct TileWork {
     const int64_t *start;   // [ntiles + 1] monotone particle offsets
     const int64_t *xstart;  // [ntiles + 1] exclusive prefix of the extra chunks per tile
-    unsigned ntiles;
+    unsigned ntiles;        // tiles of the whole mesh (size of the tables)
+    unsigned nlaunch;       // first-chunk workgroups = tiles inside the particle window (== ntiles on a single GPU)
+    int ti0, lnti, lT;      // window: first tile in x, log2 of its tiles in x, log2 of the tiles per side in y / z
 };
 
 // Incoming stragglers per tile (pm_tile_lists): particles that the sorted order files under another
@@ -669,24 +671,38 @@ struct TileLists {
 };
 
 // work item of this workgroup: tile key and particle range [s, e); false if it has none
-// tile of workgroup b < ntiles (no memory access).  Workgroups go round-robin to the 8 XCDs (each with
-// its own L2): deal every XCD runs of 64 consecutive tiles (a 32x64x64-cell Morton block) so the tile
-// halos it re-reads are its own L2 hits.
-__device__ __forceinline__ unsigned tile_key_of_block(unsigned b, unsigned ntiles) {
+// tile of first-chunk workgroup b < nlaunch (no memory access).  Workgroups go round-robin to the 8 XCDs
+// (each with its own L2): deal every XCD runs of 64 consecutive tiles (a 32x64x64-cell Morton block) so the
+// tile halos it re-reads are its own L2 hits.  On an x-slab (multi-GPU) only the tiles of the rank's planes
+// are enumerated: x fastest inside the window, then a 2-D Morton walk over (y, z).
+__device__ __forceinline__ unsigned compact2_16(unsigned v) {  // every second bit -> 16 bits
+    v &= 0x55555555u;
+    v = (v | (v >> 1)) & 0x33333333u;
+    v = (v | (v >> 2)) & 0x0f0f0f0fu;
+    v = (v | (v >> 4)) & 0x00ff00ffu;
+    v = (v | (v >> 8)) & 0x0000ffffu;
+    return v;
+}
+
+__device__ __forceinline__ unsigned tile_key_of_block(unsigned b, const TileWork &w) {
     constexpr unsigned G = 512;
-    if (b >= (ntiles / G) * G) return b;
-    const unsigned r = b % G;
-    return b - r + (r % 8) * (G / 8) + r / 8;
+    if (b < (w.nlaunch / G) * G) {
+        const unsigned r = b % G;
+        b = b - r + (r % 8) * (G / 8) + r / 8;
+    }
+    if (w.nlaunch == w.ntiles) return b;
+    const unsigned til = b & ((1u << w.lnti) - 1u), yz = b >> w.lnti;
+    return tile_key(w.ti0 + (int)til, (int)compact2_16(yz >> 1), (int)compact2_16(yz));
 }
 
 __device__ __forceinline__ bool tile_work_item(const TileWork &w, unsigned &key, int64_t &s, int64_t &e) {
     const unsigned b = blockIdx.x;
-    if (b < w.ntiles) {
-        key = tile_key_of_block(b, w.ntiles);
+    if (b < w.nlaunch) {
+        key = tile_key_of_block(b, w);
         s = w.start[key];
         e = min(w.start[key + 1], s + PM_RANGE_CHUNK);
     } else {
-        const int64_t x = (int64_t)(b - w.ntiles);
+        const int64_t x = (int64_t)(b - w.nlaunch);
         if (x >= w.xstart[w.ntiles]) return false;
         unsigned lo = 0, hi = w.ntiles;  // largest key with xstart[key] <= x
         while (hi - lo > 1) {
@@ -701,6 +717,27 @@ __device__ __forceinline__ bool tile_work_item(const TileWork &w, unsigned &key,
         e = min(w.start[lo + 1], s + PM_RANGE_CHUNK);
     }
     return s < e;
+}
+
+// window of first-chunk workgroups: the tiles of the planes the particles live in (pm_set_tile_window)
+static void tile_window(const pm_ctx *c, TileWork *w) {
+    const int n = c->n;
+    w->ntiles = (unsigned)(((int64_t)n * n * n) >> (PM_LI + PM_LJ + PM_LK));
+    w->nlaunch = w->ntiles, w->ti0 = 0, w->lnti = 0, w->lT = 0;
+    const int nti = c->tile_nx >> PM_LI, T = n >> PM_LJ;
+    if (c->tile_nx < n && nti >= 1 && (nti & (nti - 1)) == 0 && (c->tile_x_lo % PM_TI) == 0 && (c->tile_nx % PM_TI) == 0) {
+        w->ti0 = c->tile_x_lo >> PM_LI;
+        w->lnti = __builtin_ctz((unsigned)nti);
+        w->lT = __builtin_ctz((unsigned)T);
+        w->nlaunch = (unsigned)nti * (unsigned)T * (unsigned)T;
+    }
+}
+
+extern "C" int pm_set_tile_window(pm_ctx *c, int x_lo, int nx) {
+    PM_REQUIRE(c && nx >= 1 && nx <= c->n && x_lo >= 0 && x_lo + nx <= c->n, "bad plane window");
+    if (c->tile_x_lo != x_lo || c->tile_nx != nx) c->lists_pos = nullptr;  // prepared ranges belong to the old window
+    c->tile_x_lo = x_lo, c->tile_nx = nx;
+    return PM_OK;
 }
 
 static int tile_ranges(pm_ctx *c, const float *pos, int64_t np, TileWork *out, unsigned *out_blocks) {
@@ -735,9 +772,10 @@ static int tile_ranges(pm_ctx *c, const float *pos, int64_t np, TileWork *out, u
     PM_LAUNCH_CHECK();
     PM_HIP(rocprim::exclusive_scan(scan_tmp, tmp_bytes, extra, xstart, (int64_t)0, (size_t)ntiles + 1,
                                    rocprim::plus<int64_t>(), c->stream));
-    out->start = start, out->xstart = xstart, out->ntiles = ntiles;
-    // sum over tiles of ceil(len/CHUNK) <= ntiles + np/CHUNK: surplus workgroups exit at once
-    const int64_t blocks = (int64_t)ntiles + np / PM_RANGE_CHUNK + 1;
+    tile_window(c, out);
+    out->start = start, out->xstart = xstart;
+    // sum over tiles of ceil(len/CHUNK) <= nlaunch + np/CHUNK: surplus workgroups exit at once
+    const int64_t blocks = (int64_t)out->nlaunch + np / PM_RANGE_CHUNK + 1;
     if (blocks > 2147483647LL) {
         pm_set_error("too many particles for one launch");
         return PM_EINVAL;
@@ -926,7 +964,7 @@ extern "C" int pm_tile_lists(pm_ctx *c, const float *d_pos, int64_t np) {
 static int tile_work_for(pm_ctx *c, const float *pos, int64_t np, TileWork *work, TileLists *lists, unsigned *blocks) {
     if (c->lists_pos == pos && c->lists_np == np && pos) {
         work->start = (const int64_t *)c->lists_ptr[0], work->xstart = (const int64_t *)c->lists_ptr[1];
-        work->ntiles = (unsigned)(((int64_t)c->n * c->n * c->n) >> (PM_LI + PM_LJ + PM_LK));
+        tile_window(c, work);
         lists->idx = (const unsigned *)c->lists_ptr[2], lists->lstart = (const unsigned *)c->lists_ptr[3];
         lists->use = c->lists_use;
         *blocks = c->lists_blocks;
@@ -990,7 +1028,7 @@ __global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__rest
     int64_t s, e;
     const bool has_range = tile_work_item(work, key, s, e);
     unsigned ls = 0, le = 0;  // incoming stragglers (first workgroup of the tile only)
-    if (lists.use && blockIdx.x < work.ntiles) ls = lists.lstart[key], le = lists.lstart[key + 1];
+    if (lists.use && blockIdx.x < work.nlaunch) ls = lists.lstart[key], le = lists.lstart[key + 1];
     if (!has_range && ls == le) return;
     __shared__ pm_acc_t tile[PM_TILE];  // 25.9 KB
     const int tid = threadIdx.x;
@@ -1306,9 +1344,9 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     unsigned key = 0;
     int64_t s = 0, e = 0;
     bool has_range = false;
-    const bool first_chunk = blockIdx.x < work.ntiles;
+    const bool first_chunk = blockIdx.x < work.nlaunch;
     if (first_chunk)
-        key = tile_key_of_block(blockIdx.x, work.ntiles);
+        key = tile_key_of_block(blockIdx.x, work);
     else if (!tile_work_item(work, key, s, e))
         return;
     else

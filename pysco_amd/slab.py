@@ -55,6 +55,17 @@ class HipOps:
         self.n = n
         self.ctx = L.context(n)
 
+    def _window(self, on: bool) -> None:
+        """Restrict the tile-range kernels to the tiles of the rank's planes (set by Slab) around a particle call;
+        it stays on while prepared tile lists are held (they belong to the window they were made for)."""
+        w = getattr(self, "window", None)
+        if w is None:
+            return
+        if on:
+            self.ctx.call("pm_set_tile_window", w[0], w[1])
+        elif not getattr(self, "_lists_held", False):
+            self.ctx.call("pm_set_tile_window", 0, self.n)
+
     # particles
     def kick_drift_wrap(self, pos, vel, acc, half_dt, dt, x_lo, x_hi):
         """Fused kick + drift + wrap; returns the (sorted) indices of the particles that left [x_lo, x_hi)."""
@@ -74,20 +85,24 @@ class HipOps:
         n = self.n
         rho = self.torch.empty((nx, n, n), dtype=self.torch.float32, device=pos.device)
         self.ctx.call("pm_set_slab", nx, x0)
+        self._window(True)
         try:
             self.ctx.call("pm_deposit", scheme, L.ptr(pos), pos.shape[0], L.ptr(rho), 1)
         finally:
             self.ctx.call("pm_set_slab", n, 0)
+            self._window(False)
         return rho
 
     def interp_kick(self, scheme, force, nx, x0, pos, vel, half_dt):
         out = self.torch.empty_like(pos)
         self.ctx.call("pm_set_slab", nx, x0)
+        self._window(True)
         try:
             self.ctx.call("pm_interp_kick", scheme, L.ptr(force), L.ptr(pos), pos.shape[0], L.ptr(out),
                           L.ptr(vel) if vel is not None else None, float(half_dt))
         finally:
             self.ctx.call("pm_set_slab", self.n, 0)
+            self._window(False)
         a, v = C.c_float(0), C.c_float(0)
         self.ctx.call("pm_last_maxabs", C.byref(a), C.byref(v))
         return out, float(a.value), float(v.value)
@@ -95,8 +110,13 @@ class HipOps:
     def gradient_interp_kick(self, order, scheme, phi_ext, x0_phi, pos, vel, half_dt):
         """Gradient + gather + kick from the potential slab (with ghosts) without a force array."""
         out = self.torch.empty_like(pos)
-        self.ctx.call("pm_gradient_interp_kick", int(order), scheme, L.ptr(phi_ext), phi_ext.shape[0], int(x0_phi),
-                      L.ptr(pos), pos.shape[0], L.ptr(out), L.ptr(vel) if vel is not None else None, float(half_dt))
+        self._window(True)
+        try:
+            self.ctx.call("pm_gradient_interp_kick", int(order), scheme, L.ptr(phi_ext), phi_ext.shape[0], int(x0_phi),
+                          L.ptr(pos), pos.shape[0], L.ptr(out), L.ptr(vel) if vel is not None else None,
+                          float(half_dt))
+        finally:
+            self._window(False)
         a, v = C.c_float(0), C.c_float(0)
         self.ctx.call("pm_last_maxabs", C.byref(a), C.byref(v))
         return out, float(a.value), float(v.value)
@@ -105,8 +125,12 @@ class HipOps:
         """Tile ranges + straggler lists for these positions (pmstep.h: pm_tile_lists); None drops them."""
         if pos is None:
             self.ctx.call("pm_tile_lists", None, 0)
+            self._lists_held = False
+            self._window(False)
         else:
+            self._window(True)
             self.ctx.call("pm_tile_lists", L.ptr(pos), pos.shape[0])
+            self._lists_held = True
 
     def max_abs(self, x) -> float:
         if x.numel() == 0:
@@ -295,6 +319,8 @@ class Slab:
         self.nx = n // self.world
         self.x_lo = self.rank * self.nx
         self.ops = ops if ops is not None else HipOps(n)
+        if isinstance(self.ops, HipOps) and self.nx % 8 == 0:
+            self.ops.window = (self.x_lo, self.nx)  # all particles of this rank live in these planes (after migrate)
         self.carry = ()  # extra per-particle arrays ([Np, ...]) that migrate with the particles (e.g. IDs)
 
     # ---- particles ------------------------------------------------------------------------------
