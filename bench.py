@@ -243,7 +243,8 @@ def main():
                    "pm_fftp_z_forward": 8.0 * cells, "pm_fftp_z_inverse": 8.0 * cells,
                    "pm_fftp_y_forward": 2.0 * spec / 4, "pm_fftp_y_inverse": 2.0 * spec / 4,
                    "pm_fftp_xgreen_kz": 2.0 * spec / 4,
-                   "pm_kick_drift_wrap_slab": 60.0 * npart / world})
+                   "pm_kick_drift_wrap_slab": 60.0 * npart / world,
+                   "pm_kick_drift_wrap_deposit_slab": 60.0 * npart / world + 4.0 * cells})
     table = []
     for name, (calls, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):
         avg = ms / calls

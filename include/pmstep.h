@@ -153,6 +153,14 @@ int pm_tile_lists(pm_ctx *ctx, const float *d_pos, int64_t np);
  * keeps them, so the gather of the same step reuses them.  Single-GPU layout, n >= 16, np < 2^32. */
 int pm_kick_drift_wrap_deposit(pm_ctx *ctx, int scheme, float *d_pos, float *d_vel, const float *d_acc,
                                float half_dt, float dt, int64_t np, float *d_rho);
+/* The same on a slab (pm_set_slab, pm_set_tile_window in force): d_rho is the rank's [nx_slab, n, n] density
+ * array, which must be wide enough (ghost planes) for the footprint of every particle AFTER the drift -- the
+ * caller bounds the drift (it knows dt, max|v|, max|a|) and chooses the ghost width; the particles whose new x
+ * left [x_lo, x_hi) are deposited here, by their old owner, and listed as by pm_kick_drift_wrap_slab.  The tile
+ * lists are dropped: the migration that follows renumbers the particles. */
+int pm_kick_drift_wrap_deposit_slab(pm_ctx *ctx, int scheme, float *d_pos, float *d_vel, const float *d_acc,
+                                    float half_dt, float dt, int64_t np, float *d_rho, float x_lo, float x_hi,
+                                    int64_t *d_leave_idx, int cap, int *h_count);
 /* mesh.derivative (mesh.py:2072, orders 2/3/5/7) + pm_interp_kick in one kernel: every workgroup stages the
  * potential of its tile in LDS, differentiates it there with the reference's stencil and gathers from the
  * result, so the [n,n,n,3] force grid is never written or read.  Same bits as pm_gradient followed by

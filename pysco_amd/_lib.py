@@ -62,6 +62,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_interp_kick": (_vp, _i, _vp, _vp, _i64, _vp, _vp, _f),
     "pm_tile_lists": (_vp, _vp, _i64),
     "pm_kick_drift_wrap_deposit": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp),
+    "pm_kick_drift_wrap_deposit_slab": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _f, _f, _vp, _i, C.POINTER(_i)),
     "pm_gradient_interp_kick": (_vp, _i, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _f),
     "pm_last_maxabs": (_vp, C.POINTER(_f), C.POINTER(_f)),
     "pm_set_gather_mode": (_vp, _i),

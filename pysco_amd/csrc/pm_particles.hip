@@ -1082,12 +1082,20 @@ __global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__rest
 
 constexpr int PM_SCAP = 1024;  // stragglers staged in LDS per workgroup before the global append
 
+// slab decomposition: particles whose new x leaves [x_lo, x_hi) are listed for the migration (idx == NULL: off)
+struct Leavers {
+    float x_lo, x_hi;
+    int64_t *idx;
+    int cap;
+    int *count;
+};
+
 template <int SCHEME>
 __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ pos, float *__restrict__ vel,
                                                           const float *__restrict__ acc, float mhalf_dt, float dt,
                                                           TileWork work, pm_geom geo, float *__restrict__ rho,
                                                           unsigned *__restrict__ lkeys, unsigned *__restrict__ lidx,
-                                                          unsigned subcap, unsigned *__restrict__ counts) {
+                                                          unsigned subcap, unsigned *__restrict__ counts, Leavers lv) {
     unsigned key;
     int64_t s, e;
     if (!tile_work_item(work, key, s, e)) return;
@@ -1127,6 +1135,10 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
                     pm_kick_drift_wrap_one(x[u][m], v[u][m], a[u][m], mhalf_dt, dt);
                     vel[3 * p + m] = v[u][m];
                     pos[3 * p + m] = x[u][m];
+                }
+                if (lv.idx && (x[u][0] < lv.x_lo || x[u][0] >= lv.x_hi)) {  // slab: leaves this rank's planes
+                    const int slot = atomicAdd(lv.count, 1);
+                    if (slot < lv.cap) lv.idx[slot] = p;
                 }
                 const float xp = x[u][0] * nf, yp = x[u][1] * nf, zp = x[u][2] * nf;
                 const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
@@ -1190,7 +1202,7 @@ __global__ __launch_bounds__(BLK) void deposit_list_kernel(const float *__restri
 
 template <int SCHEME>
 static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *acc, float half_dt, float dt, int64_t np,
-                              float *rho) {
+                              float *rho, Leavers lv) {
     TileWork work;
     unsigned blocks = 0;
     tile_lists_drop(c);
@@ -1204,7 +1216,7 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));
     PM_HIP(hipMemsetAsync(b.counts, 0, PM_NSUB * PM_SUB_STRIDE * sizeof(unsigned), c->stream));
     hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, vel, acc, -half_dt, dt, work,
-                       pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts);
+                       pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv);
     PM_LAUNCH_CHECK();
     const unsigned *idx = nullptr;
     unsigned listed = 0;
@@ -1234,18 +1246,44 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     return PM_OK;
 }
 
+static int kdw_deposit_scheme(pm_ctx *c, int scheme, float *d_pos, float *d_vel, const float *d_acc, float half_dt,
+                              float dt, int64_t np, float *d_rho, Leavers lv) {
+    switch (scheme) {
+        case PM_NGP: return kdw_deposit_launch<PM_NGP>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, lv);
+        case PM_CIC: return kdw_deposit_launch<PM_CIC>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, lv);
+        case PM_TSC: return kdw_deposit_launch<PM_TSC>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, lv);
+    }
+    pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme);
+    return PM_EINVAL;
+}
+
 extern "C" int pm_kick_drift_wrap_deposit(pm_ctx *c, int scheme, float *d_pos, float *d_vel, const float *d_acc,
                                           float half_dt, float dt, int64_t np, float *d_rho) {
     PM_REQUIRE(c && d_pos && d_vel && d_acc && d_rho && np > 0, "bad argument");
     PM_REQUIRE(c->n >= 16 && np < 4294967296LL, "pm_kick_drift_wrap_deposit needs n >= 16 and np < 2^32");
     PM_REQUIRE(c->slab_nx == c->n, "pm_kick_drift_wrap_deposit is the single-GPU form (no slab set)");
-    switch (scheme) {
-        case PM_NGP: return kdw_deposit_launch<PM_NGP>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho);
-        case PM_CIC: return kdw_deposit_launch<PM_CIC>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho);
-        case PM_TSC: return kdw_deposit_launch<PM_TSC>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho);
-    }
-    pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme);
-    return PM_EINVAL;
+    return kdw_deposit_scheme(c, scheme, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, Leavers{0.f, 1.f, nullptr, 0, nullptr});
+}
+
+// The same on a slab (pm_set_slab: d_rho is [nx_slab, n, n] starting at global plane x0, wide enough for
+// the footprint of every particle AFTER the drift -- the caller bounds the drift and chooses the ghost
+// width) plus the list of the particles whose new x left [x_lo, x_hi), as pm_kick_drift_wrap_slab returns it.
+// The deposit of the leavers is done here, by their old owner; the prepared tile lists are dropped (the
+// migration that follows renumbers the particles).
+extern "C" int pm_kick_drift_wrap_deposit_slab(pm_ctx *c, int scheme, float *d_pos, float *d_vel, const float *d_acc,
+                                               float half_dt, float dt, int64_t np, float *d_rho, float x_lo,
+                                               float x_hi, int64_t *d_leave_idx, int cap, int *h_count) {
+    PM_REQUIRE(c && d_pos && d_vel && d_acc && d_rho && np > 0 && d_leave_idx && h_count && cap > 0, "bad argument");
+    PM_REQUIRE(c->n >= 16 && np < 4294967296LL, "pm_kick_drift_wrap_deposit_slab needs n >= 16 and np < 2^32");
+    int *d_count = reinterpret_cast<int *>(c->d_scratch + 16);
+    PM_HIP(hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
+    int rc = kdw_deposit_scheme(c, scheme, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho,
+                                Leavers{x_lo, x_hi, d_leave_idx, cap, d_count});
+    tile_lists_drop(c);
+    if (rc) return rc;
+    PM_HIP(hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
+    return PM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -81,6 +81,31 @@ class HipOps:
             return torch.nonzero((x < x_lo) | (x >= x_hi), as_tuple=False).squeeze(1)
         return torch.sort(self._leave_buf[:count.value]).values
 
+    def kick_drift_wrap_deposit(self, scheme, pos, vel, acc, half_dt, dt, x_lo, x_hi, nx, x0):
+        """Fused first kick + drift + wrap + deposit into [nx, n, n] planes starting at x0 (ghosts included);
+        returns (density, sorted leaver indices)."""
+        torch, n, npart = self.torch, self.n, pos.shape[0]
+        cap = max(4096, npart // 16)
+        if getattr(self, "_leave_buf", None) is None or self._leave_buf.numel() < cap:
+            self._leave_buf = torch.empty(cap, dtype=torch.int64, device=pos.device)
+        rho = torch.empty((nx, n, n), dtype=torch.float32, device=pos.device)
+        count = C.c_int(0)
+        self.ctx.call("pm_set_slab", nx, x0)
+        self._window(True)
+        try:
+            self.ctx.call("pm_kick_drift_wrap_deposit_slab", scheme, L.ptr(pos), L.ptr(vel), L.ptr(acc), float(half_dt),
+                          float(dt), npart, L.ptr(rho), float(x_lo), float(x_hi), L.ptr(self._leave_buf), cap,
+                          C.byref(count))
+        finally:
+            self.ctx.call("pm_set_slab", n, 0)
+            self._window(False)
+        if count.value > cap:
+            x = pos[:, 0]
+            leave = torch.nonzero((x < x_lo) | (x >= x_hi), as_tuple=False).squeeze(1)
+        else:
+            leave = torch.sort(self._leave_buf[:count.value]).values
+        return rho, leave
+
     def deposit(self, scheme, pos, nx, x0):
         n = self.n
         rho = self.torch.empty((nx, n, n), dtype=self.torch.float32, device=pos.device)
@@ -303,6 +328,7 @@ def all_reduce_max(values: List[float], device) -> List[float]:
 # ------------------------------------------------------------------------------------------------
 
 
+_FUSE_SLAB_DEPOSIT = True  # False: kick_drift_wrap, migration, then a separate deposit
 _PIPELINE_FFT = True    # False: the slab FFT exchanges the whole spectrum in one all-to-all each way
 _SLAB_MULTIGRID = True  # False: multigrid / MOND under slabs all-gather the density and solve replicated
 
@@ -499,15 +525,26 @@ class Slab:
             if lists is not None:
                 lists(None)
 
+    def _deposit_folded(self, position, scheme):
+        """Density on the owned planes [nx, n, n] (a view into the deposit's [nx + 2W] array): deposit with W
+        ghost planes each side (1, or what the fused kick + deposit of integrate() used), ghosts folded into
+        the neighbours.  Not normalised."""
+        nx, ops = self.nx, self.ops
+        pre = getattr(self, "_predeposited", None)
+        self._predeposited = None
+        if pre is not None:
+            rho_ext, W = pre
+        else:
+            rho_ext, W = ops.deposit(scheme, position, nx + 2, self.x_lo - 1), 1
+        from_left, from_right = exchange_planes(rho_ext[:W], rho_ext[nx + W:])
+        rho_ext[W:2 * W] += from_left             # left neighbour's right ghosts are my first planes
+        rho_ext[nx:nx + W] += from_right          # right neighbour's left ghosts are my last planes
+        return rho_ext[W:nx + W]                  # contiguous view of the owned planes
+
     def _deposit_owned(self, position, param, scheme):
-        """Density on the owned planes [nx, n, n] (a view into the deposit's [nx + 2] array): deposit with one
-        ghost plane each side, ghosts folded into the neighbours, normalised to unit mean (solver.py:113)."""
-        n, nx, ops = self.n, self.nx, self.ops
-        rho_ext = ops.deposit(scheme, position, nx + 2, self.x_lo - 1)
-        from_left, from_right = exchange_planes(rho_ext[0], rho_ext[nx + 1])
-        rho_ext[1] += from_left       # left neighbour's right ghost is my first plane
-        rho_ext[nx] += from_right     # right neighbour's left ghost is my last plane
-        rho = rho_ext[1:nx + 1]       # contiguous view of the owned planes
+        """The same, normalised to unit mean (solver.py:113)."""
+        n, ops = self.n, self.ops
+        rho = self._deposit_folded(position, scheme)
         if n**3 != param["npart"]:
             ops.scale_inplace(rho, np.float32(n**3 / param["npart"]))
         return rho
@@ -633,15 +670,11 @@ class Slab:
 
         n, nx, ops = self.n, self.nx, self.ops
         dist = _dist()
-        rho_ext = ops.deposit(scheme, position, nx + 2, self.x_lo - 1)
-        from_left, from_right = exchange_planes(rho_ext[0], rho_ext[nx + 1])
-        rho_ext[1] += from_left
-        rho_ext[nx] += from_right
-        mine = _stage(rho_ext[1:nx + 1].contiguous())
+        mine = _stage(self._deposit_folded(position, scheme).contiguous())
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine)
         density = _unstage(torch.cat(parts, dim=0), position)
-        del rho_ext, mine, parts
+        del mine, parts
         if potential is None:
             potential = torch.empty(0, dtype=torch.float32, device=position.device)
         if additional_field is None:
@@ -757,7 +790,23 @@ class Slab:
         x_lo, x_hi = self.rank / self.world, (self.rank + 1) / self.world  # exact in fp32 (G is a power of two)
         if INTEGRATOR == "leapfrog":
             half_dt = np.float32(0.5 * dt)
-            leave = ops.kick_drift_wrap(position, velocity, acceleration, half_dt, np.float32(dt), x_lo, x_hi)
+            # Fused first kick + drift + deposit (pmstep.h): the deposit is done before the migration, by the old
+            # owner, into ghost planes wide enough for the farthest a particle can get in this step:
+            # |dx| <= dt max|v| + dt^2/2 max|a| cells (+ 1.5 for the TSC cloud).
+            W = 0
+            MASS_SCHEME = param["mass_scheme"].casefold()
+            if (_FUSE_SLAB_DEPOSIT and hasattr(ops, "kick_drift_wrap_deposit") and MASS_SCHEME in _SCHEME
+                    and self.n >= 16 and 0 < position.shape[0] < 2**32 and np.isfinite(ma) and np.isfinite(mv)):
+                reach = (float(dt) * float(mv) + 0.5 * float(dt) ** 2 * float(ma)) * self.n + 1.5
+                if reach < 4.0:
+                    W = int(np.ceil(reach))
+            if W > 0:
+                rho_ext, leave = ops.kick_drift_wrap_deposit(_SCHEME[MASS_SCHEME], position, velocity, acceleration,
+                                                             half_dt, np.float32(dt), x_lo, x_hi, self.nx + 2 * W,
+                                                             self.x_lo - W)
+                self._predeposited = (rho_ext, W)
+            else:
+                leave = ops.kick_drift_wrap(position, velocity, acceleration, half_dt, np.float32(dt), x_lo, x_hi)
             advance_clock()
             self._migrate_leavers(leave)
             position, velocity = self._views()
