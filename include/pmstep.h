@@ -144,6 +144,11 @@ int pm_interp_kick(pm_ctx *ctx, int scheme, const float *d_force, const float *d
  * that writes positions, and must be dropped by the caller before d_pos is modified otherwise.  Results
  * are identical with and without (gather: same bits; deposit: same sums up to atomic ordering). */
 int pm_tile_lists(pm_ctx *ctx, const float *d_pos, int64_t np);
+/* Outcome of the most recent straggler scan on this context (pm_tile_lists, pm_kick_drift_wrap_deposit[_slab]):
+ * number of particles outside the tile they are filed under, the np it was counted over, and whether the lists
+ * hold them all (they have room for every particle; a sub-list can overflow).  *stragglers = -1 before any scan.  Lets the caller re-sort
+ * (pm_reorder_particles) when the sort has aged instead of on a fixed cadence only. */
+int pm_tile_lists_info(pm_ctx *ctx, int64_t *stragglers, int64_t *np, int *complete);
 /* pm_kick_drift_wrap (integration.py:250-258) + pm_deposit (mesh.py:2240/2284/2468) in one kernel, for a
  * stream that is (approximately) Morton-sorted: the update streams through HBM while the LDS does the
  * deposit, and the positions are read once.  d_pos / d_vel are updated in place exactly as by

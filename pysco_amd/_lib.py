@@ -61,6 +61,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_kick_drift_wrap": (_vp, _vp, _vp, _vp, _f, _f, _i64),
     "pm_interp_kick": (_vp, _i, _vp, _vp, _i64, _vp, _vp, _f),
     "pm_tile_lists": (_vp, _vp, _i64),
+    "pm_tile_lists_info": (_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)),
     "pm_kick_drift_wrap_deposit": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp),
     "pm_kick_drift_wrap_deposit_slab": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _f, _f, _vp, _i, C.POINTER(_i)),
     "pm_gradient_interp_kick": (_vp, _i, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _f),

@@ -146,6 +146,8 @@ struct pm_ctx {
     int64_t lists_np;
     unsigned lists_blocks;
     int lists_use;       // 1: every straggler is in the per-tile incoming lists
+    int64_t last_stragglers, last_np;  // of the most recent straggler scan (pm_tile_lists_info); -1 before any
+    int last_complete;
     int lists_sticky;    // prepared by pm_kick_drift_wrap_deposit: the next pm_tile_lists on them keeps them
     const void *lists_ptr[4];  // start, xstart (tile_tmp); idx, lstart (list_buf)
     void *list_buf;      // keys/indices (in, out), per-tile list offsets, sort scratch

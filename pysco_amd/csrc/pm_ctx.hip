@@ -58,6 +58,7 @@ extern "C" int pm_ctx_create(pm_ctx **out, int n, void *stream) {
     c->slab_x0 = 0;
     c->gather_mode = 1;
     c->tile_x_lo = 0, c->tile_nx = n;
+    c->last_stragglers = -1, c->last_np = 0, c->last_complete = 1;
     c->stream = (hipStream_t)stream;
     PM_HIP(hipMalloc((void **)&c->d_scratch, 64 * sizeof(unsigned)));
     PM_HIP(hipMemset(c->d_scratch, 0, 64 * sizeof(unsigned)));

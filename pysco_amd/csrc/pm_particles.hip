@@ -864,8 +864,11 @@ struct ListBufs {
 };
 
 static int list_bufs(pm_ctx *c, int64_t np, unsigned ntiles, ListBufs *b) {
-    // room for one straggler in eight particles; beyond that the stream is not worth calling sorted
-    b->subcap = (size_t)(np / (8 * PM_NSUB) + 64);
+    c->last_np = np;
+    // room for every particle (16 bytes each: 17 GB at 1024^3 of 288): the sort and the list pass only cost what
+    // the actual number of stragglers makes them cost, and there is no cliff when a sort has aged badly; a
+    // sub-list can still overflow when the stragglers bunch up in few workgroups (then: order-independent kernels)
+    b->subcap = (size_t)(np / PM_NSUB + 64);
     b->cap = b->subcap * PM_NSUB;
     const size_t off_l = ((b->cap * 4 * sizeof(unsigned)) + 255) & ~(size_t)255;
     const size_t off_c = off_l + ((((size_t)ntiles + 1) * sizeof(unsigned) + 255) & ~(size_t)255);
@@ -898,8 +901,10 @@ static int list_group(pm_ctx *c, const ListBufs &b, unsigned ntiles, const unsig
     SubLists sub;
     unsigned cnt = 0, biggest = 0;
     *complete = 1;
+    c->last_stragglers = 0;
     for (int k = 0; k < PM_NSUB; ++k) {
         unsigned ck = h_counts[k * PM_SUB_STRIDE];
+        c->last_stragglers += ck;
         if (ck > b.subcap) ck = (unsigned)b.subcap, *complete = 0;
         sub.count[k] = ck, sub.offset[k] = cnt;
         cnt += ck;
@@ -923,6 +928,17 @@ static int list_group(pm_ctx *c, const ListBufs &b, unsigned ntiles, const unsig
                        b.lstart);
     PM_LAUNCH_CHECK();
     *listed = cnt;
+    c->last_complete = *complete;
+    return PM_OK;
+}
+
+// Outcome of the most recent straggler scan on this context (pm_tile_lists, pm_kick_drift_wrap_deposit[_slab]):
+// how many of the np particles were outside the tile they are filed under, and whether the lists hold them
+// all (beyond one in four the kernels serve stragglers themselves, slowly).  *stragglers = -1 before any scan.
+// A caller uses it to decide when to re-sort (utils.reorder_particles).
+extern "C" int pm_tile_lists_info(pm_ctx *c, int64_t *stragglers, int64_t *np, int *complete) {
+    PM_REQUIRE(c && stragglers && np && complete, "NULL argument");
+    *stragglers = c->last_stragglers, *np = c->last_np, *complete = c->last_complete;
     return PM_OK;
 }
 
@@ -1226,7 +1242,7 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     c->lists_ptr[0] = work.start, c->lists_ptr[1] = work.xstart, c->lists_ptr[2] = idx, c->lists_ptr[3] = b.lstart;
     c->lists_blocks = blocks;
     if (!complete) {
-        // more than one particle in eight has left its tile: not a sorted stream.  The positions are
+        // a sub-list overflowed (stragglers bunched up in few workgroups): no complete lists.  The positions are
         // updated; deposit them again from scratch with the kernels that serve stragglers themselves.
         c->lists_pos = nullptr;
         PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));

@@ -14,7 +14,12 @@ from typing import Callable, List, Optional, Sequence
 
 import numpy as np
 
+from . import _lib as L
 from . import integration, solver, utils
+
+
+def L_is_device(x) -> bool:
+    return L.is_device_array(x)
 
 
 def run_nbody(position, velocity, param, tables: List, z_out: Sequence[float],
@@ -39,8 +44,15 @@ def run_nbody(position, velocity, param, tables: List, z_out: Sequence[float],
         position, velocity, acceleration, potential, additional_field = integration.integrate(
             position, velocity, acceleration, potential, additional_field, tables, param,
             t_out[param["i_snap"] - 1])
-        if (param["nsteps"] % param["n_reorder"]) == 0:
-            logging.info("Reordering particles")
+        # besides the reference's fixed cadence: re-sort when more than `reorder_straggler_fraction` of the
+        # particles (default 10 %) have left the tile the last sort filed them under -- the cost of serving them
+        # has then grown to about that of the sort (one step's worth); particle order is not an observable
+        frac, complete = (None, True)
+        if L_is_device(position):
+            frac, complete = utils.straggler_fraction(2 ** int(param["ncoarse"]))
+        aged = (not complete) or (frac is not None and frac > float(param.get("reorder_straggler_fraction", 0.10)))
+        if (param["nsteps"] % param["n_reorder"]) == 0 or aged:
+            logging.info(f"Reordering particles ({frac=})")
             position, velocity, acceleration = utils.reorder_particles(position, velocity, acceleration)
         if param["write_snapshot"]:
             if on_snapshot is not None:

@@ -122,12 +122,17 @@ class HipOps:
         out = self.torch.empty_like(pos)
         self.ctx.call("pm_set_slab", nx, x0)
         self._window(True)
+        complete = self.lists_complete()
+        if not complete:
+            self.ctx.call("pm_set_gather_mode", 2)  # chunk / anchor kernel: any particle order through LDS
         try:
             self.ctx.call("pm_interp_kick", scheme, L.ptr(force), L.ptr(pos), pos.shape[0], L.ptr(out),
                           L.ptr(vel) if vel is not None else None, float(half_dt))
         finally:
             self.ctx.call("pm_set_slab", self.n, 0)
             self._window(False)
+            if not complete:
+                self.ctx.call("pm_set_gather_mode", 1)
         a, v = C.c_float(0), C.c_float(0)
         self.ctx.call("pm_last_maxabs", C.byref(a), C.byref(v))
         return out, float(a.value), float(v.value)
@@ -156,6 +161,11 @@ class HipOps:
             self._window(True)
             self.ctx.call("pm_tile_lists", L.ptr(pos), pos.shape[0])
             self._lists_held = True
+
+    def lists_complete(self) -> bool:
+        from . import utils
+
+        return utils.straggler_fraction(self.n)[1]
 
     def max_abs(self, x) -> float:
         if x.numel() == 0:
@@ -562,7 +572,10 @@ class Slab:
         from_left, from_right = exchange_planes(phi[:H], phi[nx - H:])
         phi_ext = torch.cat([from_left, phi, from_right], dim=0)
         vel, half_dt = (kick if kick is not None else (None, 0.0))
-        if hasattr(ops, "gradient_interp_kick") and n >= 16:  # the gather differentiates its own LDS tile
+        fused = hasattr(ops, "gradient_interp_kick") and n >= 16
+        if fused and hasattr(ops, "lists_complete") and not ops.lists_complete():
+            fused = False  # more stragglers than the lists hold: force grid + order-independent gather
+        if fused:  # the gather differentiates its own LDS tile
             acc, ma, mv = ops.gradient_interp_kick(order, scheme, phi_ext, self.x_lo - H, position, vel, half_dt)
         else:
             force = ops.gradient(order, phi_ext, self.x_lo - H, nx + 2, self.x_lo - 1)

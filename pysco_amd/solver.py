@@ -70,6 +70,10 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
         # the potential and differentiates its own LDS tile (mesh.derivative_interp_vec_kick), and the
         # [n,n,n,3] array is never built.
         fuse_gradient = _FUSE_GRADIENT and ncells_1d >= 16 and THEORY != "fr"
+        # More stragglers than the lists hold (an unsorted or long-unsorted stream): the gather from the
+        # potential would serve each of them with 324 loads; the force grid + order-independent gather it is.
+        frac, lists_complete = utils.straggler_fraction(ncells_1d)
+        fuse_gradient = fuse_gradient and lists_complete
         potential_d, additional_field_d, force = _solve_grid(density, param, _dev(potential),
                                                              _dev(additional_field), tables,
                                                              want_force=not fuse_gradient)
@@ -80,7 +84,12 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
             acceleration = mesh.derivative_interp_vec_kick(MASS_SCHEME, potential_d,
                                                            param["gradient_stencil_order"], pos_d, vel, half_dt)
         elif _kick is not None and ncells_1d >= 16:
-            acceleration = mesh.interp_vec_kick(MASS_SCHEME, force, pos_d, _kick[0], _kick[1])
+            if not lists_complete:
+                ctx.call("pm_set_gather_mode", 2)  # chunk / anchor kernel: any particle order through LDS
+            try:
+                acceleration = mesh.interp_vec_kick(MASS_SCHEME, force, pos_d, _kick[0], _kick[1])
+            finally:
+                ctx.call("pm_set_gather_mode", 1)
         else:
             acceleration = mesh.invCIC_vec(force, pos_d) if MASS_SCHEME == "cic" else mesh.invTSC_vec(force, pos_d)
             if _kick is not None:

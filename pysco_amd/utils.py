@@ -142,6 +142,19 @@ def periodic_wrap(position) -> None:
     _inplace(position, lambda t: ctx.call("pm_periodic_wrap", L.ptr(t), t.numel()))
 
 
+def straggler_fraction(ncells_1d: int):
+    """(fraction, complete) of the most recent straggler scan on the n-cell context: the share of particles that
+    were outside the tile the sorted order files them under, and whether the per-tile lists held them all.
+    (None, True) before any scan.  No reference counterpart; main.run_nbody uses it to re-sort on demand."""
+    import ctypes as C
+
+    s, npart, complete = C.c_int64(-1), C.c_int64(0), C.c_int(1)
+    L.context(ncells_1d).call("pm_tile_lists_info", C.byref(s), C.byref(npart), C.byref(complete))
+    if s.value < 0 or npart.value <= 0:
+        return None, True
+    return s.value / npart.value, bool(complete.value)
+
+
 def reorder_particles(position, velocity=None, acceleration=None):
     """Sort particles by Morton key (utils.py:1019).  Unlike the reference's per-thread partial
     argsort (utils.py:1080-1116) this is always a full, stable sort."""

@@ -226,8 +226,7 @@ def test_drifted_sorted_stream_stragglers(amd, drift_cells):
                                            ("cic", amd.mesh.CIC, orc.CIC, orc.invCIC_vec, False),
                                            ("tsc", amd.mesh.TSC, orc.TSC, orc.invTSC_vec, True),
                                            ("cic", amd.mesh.CIC, orc.CIC, orc.invCIC_vec, True)):
-        # lists=True: stragglers pre-grouped by pm_tile_lists (what solver.pm does), every particle via LDS;
-        # at 3 cells of drift the list overflows its np/8 capacity and the kernels fall back by themselves
+        # lists=True: stragglers pre-grouped by pm_tile_lists (what solver.pm does), every particle via LDS
         ctx.call("pm_tile_lists", L.ptr(pd) if lists else None, pd.shape[0] if lists else 0)
         ref = odep(pos, n)
         rho = dep(pd, n).cpu().numpy()
@@ -630,7 +629,7 @@ def test_run_nbody_loop_vs_oracle(amd):
             "Om_lambda": 0.742589237, "H0": 72.0, "boxlen": 100.0, "aexp": 0.5, "aexp_old": 0.49,
             "linear_newton_solver": "fft", "gradient_stencil_order": 5, "save_power_spectrum": "no", "nthreads": 1,
             "Courant_factor": 1.0, "max_aexp_stepping": 10, "integrator": "leapfrog", "write_snapshot": False,
-            "n_reorder": 2}
+            "n_reorder": 2, "reorder_straggler_fraction": 1.0}  # fixed cadence only, as in the oracle loop below
     base["t"] = float(tables[1](np.log(base["aexp"])))
     z_out = [0.45, 0.6]
 
