@@ -865,10 +865,10 @@ struct ListBufs {
 
 static int list_bufs(pm_ctx *c, int64_t np, unsigned ntiles, ListBufs *b) {
     c->last_np = np;
-    // room for every particle (16 bytes each: 17 GB at 1024^3 of 288): the sort and the list pass only cost what
+    // room for every particle and some imbalance (20 bytes each: 21 GB at 1024^3 of 288): the sort and the list pass only cost what
     // the actual number of stragglers makes them cost, and there is no cliff when a sort has aged badly; a
     // sub-list can still overflow when the stragglers bunch up in few workgroups (then: order-independent kernels)
-    b->subcap = (size_t)(np / PM_NSUB + 64);
+    b->subcap = (size_t)(np / PM_NSUB + np / (4 * PM_NSUB) + 2 * PM_RANGE_CHUNK);
     b->cap = b->subcap * PM_NSUB;
     const size_t off_l = ((b->cap * 4 * sizeof(unsigned)) + 255) & ~(size_t)255;
     const size_t off_c = off_l + ((((size_t)ntiles + 1) * sizeof(unsigned) + 255) & ~(size_t)255);

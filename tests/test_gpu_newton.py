@@ -228,6 +228,9 @@ def test_drifted_sorted_stream_stragglers(amd, drift_cells):
                                            ("cic", amd.mesh.CIC, orc.CIC, orc.invCIC_vec, True)):
         # lists=True: stragglers pre-grouped by pm_tile_lists (what solver.pm does), every particle via LDS
         ctx.call("pm_tile_lists", L.ptr(pd) if lists else None, pd.shape[0] if lists else 0)
+        if lists:  # the scan's statistics: what main.run_nbody re-sorts on
+            frac, complete = amd.utils.straggler_fraction(n)
+            assert complete and (0.01 < frac < 0.5 if drift_cells < 1 else frac > 0.5), (frac, complete)
         ref = odep(pos, n)
         rho = dep(pd, n).cpu().numpy()
         np.testing.assert_allclose(rho, ref, rtol=0, atol=4e-6 * _scale(ref))
