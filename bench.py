@@ -136,6 +136,21 @@ def cpu_baseline(cpu_n, budget_s=15.0):
             if dt > budget_s or steps >= 200 or (steps >= 2 and dt + dt / steps > 1.3 * budget_s):
                 return steps, dt
 
+    # P(k) of the same particle set on both sides (the second half of BASELINE.json's metric): TSC deposit ->
+    # r2c -> binned, window-deconvolved spectrum (fourier.py:22-100) by the HIP path and by the oracle
+    import torch
+
+    from pysco_amd import fourier, mesh
+
+    rho_k = orc.fft_3D_real(orc.TSC(pos0, cpu_n))
+    _, pk_cpu, nm = orc.fourier_grid_to_Pk(rho_k, 3)
+    del rho_k
+    rho_d = mesh.TSC(torch.from_numpy(pos0).cuda(), cpu_n)
+    _, pk_gpu, _ = fourier.fourier_grid_to_Pk(fourier.fft_3D_real(rho_d), 3)
+    del rho_d
+    ok = nm > 0
+    pk_rel_err = float(np.max(np.abs(pk_gpu[ok] - pk_cpu[ok]) / np.abs(pk_cpu[ok])))
+
     s1, t1 = leg(False)
     try:
         sn, tn = leg(True)
@@ -144,6 +159,8 @@ def cpu_baseline(cpu_n, budget_s=15.0):
         orc.use_openmp(False)
     return {"value": cpu_n**3 * sn / tn, "unit": "particles/s", "cores": threads, "kind": "port",
             "value_1core": cpu_n**3 * s1 / t1,
+            "pk_rel_err": {"value": pk_rel_err, "bins": int(ok.sum()), "what": f"max over bins of |P_hip - P_cpu| / P_cpu, "
+                           f"TSC density of the {cpu_n}^3 sample, deconvolved (p = 3)"},
             "sample": f"leapfrog steps at {cpu_n}^3 particles / {cpu_n}^3 mesh (TSC, FFT, order 5) with the CPU "
                       f"restatement of PySCo's Numba path (oracle/pm_oracle.c): {sn} steps in {tn:.1f} s on {threads} "
                       f"threads (OpenMP, atomic deposit, scipy.fft workers), {s1} steps in {t1:.1f} s on 1 core "
