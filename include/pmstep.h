@@ -256,6 +256,21 @@ int pm_lap_operator_slab(pm_ctx *ctx, const float *d_x, const float *d_b, int n,
 int pm_lap_residual_sumsq_slab(pm_ctx *ctx, const float *d_x, const float *d_b, int n, int nx, double *h_sum);
 int pm_diff_sumsq(pm_ctx *ctx, const float *d_a, const float *d_b, float f, int64_t count, double *h_sum);
 int pm_mond_rhs_slab(pm_ctx *ctx, const float *d_pot, float *d_out, int n, int nx, float g0, int kind, float alpha);
+/* f(R) scalaron operator on a slab (cubic.py / quartic.py; fr_n = 1 / 2), same conventions: pm_fr_operator_slab
+ * is operator (d_rhs NULL) or residual_with_rhs, pm_fr_gauss_seidel_slab ONE colour half-sweep (with or without
+ * rhs), pm_fr_residual_sumsq_slab the local sum of squares of the operator; pm_gradient_fr_slab the f(R) force
+ * (mesh.derivative_fR) from potential and scalaron slabs with ghosts. */
+int pm_fr_operator_slab(pm_ctx *ctx, int fr_n, const float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                        int nx, float *d_out);
+int pm_fr_residual_sumsq_slab(pm_ctx *ctx, int fr_n, const float *d_x, const float *d_b, float q, int n, int nx,
+                              double *h_sum);
+int pm_fr_gauss_seidel_slab(pm_ctx *ctx, int fr_n, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                            int nx, int x_lo, int colour, float f_relax);
+int pm_gradient_fr_slab(pm_ctx *ctx, int order, int fr_n, float f, const float *d_phi, const float *d_u, int nx_phi,
+                        int x0_phi, float *d_force, int nx_force, int x0_force);
+/* cubic / quartic initialise_potential on `count` cells of a level with n cells per side (slab level arrays) */
+int pm_cubic_initialise_potential_flat(pm_ctx *ctx, const float *d_b, float q, int n, int64_t count, float *d_out);
+int pm_quartic_initialise_potential_flat(pm_ctx *ctx, const float *d_b, float q, int n, int64_t count, float *d_out);
 
 /* slab FFT pieces: batched 2-D r2c / c2r over (y,z) on nplanes x-planes ([np,n,n] <-> [np,n,n/2+1]; the
  * c2r carries 1/n^3), and the in-place strided 1-D c2c along x of an [n, ncolumns] complex array

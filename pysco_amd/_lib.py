@@ -93,6 +93,12 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_lap_residual_sumsq_slab": (_vp, _vp, _vp, _i, _i, C.POINTER(C.c_double)),
     "pm_diff_sumsq": (_vp, _vp, _vp, _f, _i64, C.POINTER(C.c_double)),
     "pm_mond_rhs_slab": (_vp, _vp, _vp, _i, _i, _f, _i, _f),
+    "pm_fr_operator_slab": (_vp, _i, _vp, _vp, _f, _vp, _i, _i, _vp),
+    "pm_fr_residual_sumsq_slab": (_vp, _i, _vp, _vp, _f, _i, _i, C.POINTER(C.c_double)),
+    "pm_fr_gauss_seidel_slab": (_vp, _i, _vp, _vp, _f, _vp, _i, _i, _i, _i, _f),
+    "pm_gradient_fr_slab": (_vp, _i, _i, _f, _vp, _vp, _i, _i, _vp, _i, _i),
+    "pm_cubic_initialise_potential_flat": (_vp, _vp, _f, _i, _i64, _vp),
+    "pm_quartic_initialise_potential_flat": (_vp, _vp, _f, _i, _i64, _vp),
     "pm_kick_drift_wrap_slab": (_vp, _vp, _vp, _vp, _f, _f, _i64, _f, _f, _vp, _i, C.POINTER(_i)),
     "pm_gradient_slab": (_vp, _i, _vp, _i, _i, _vp, _i, _i),
     "pm_fft2d_r2c": (_vp, _vp, _vp, _i),

@@ -429,6 +429,19 @@ extern "C" int pm_gradient_slab(pm_ctx *c, int order, const float *d_phi, int nx
                                 ((x0_force % n) + n) % n);
 }
 
+// f(R) force on a slab: d_phi and d_u both hold nx_phi planes from global plane x0_phi (reach + 1 ghosts)
+extern "C" int pm_gradient_fr_slab(pm_ctx *c, int order, int fr_n, float f, const float *d_phi, const float *d_u,
+                                   int nx_phi, int x0_phi, float *d_force, int nx_force, int x0_force) {
+    PM_REQUIRE(c && d_phi && d_u && d_force, "NULL argument");
+    PM_REQUIRE(pm_aligned16(d_phi) && pm_aligned16(d_u) && pm_aligned16(d_force), "grids must be 16-byte aligned");
+    PM_REQUIRE(c->n >= 8 && nx_phi >= 1 && nx_force >= 1, "bad slab geometry");
+    const int n = c->n, x0p = ((x0_phi % n) + n) % n, x0f = ((x0_force % n) + n) % n;
+    if (fr_n == 1) return gradient_dispatch<1>(c, order, f, d_phi, d_u, d_force, nx_phi, x0p, nx_force, x0f);
+    if (fr_n == 2) return gradient_dispatch<2>(c, order, f, d_phi, d_u, d_force, nx_phi, x0p, nx_force, x0f);
+    pm_set_error("Only f(R) with n = 1 and 2, currently fR_n=%d", fr_n);
+    return PM_ENOSUP;
+}
+
 extern "C" int pm_gradient_fr(pm_ctx *c, int order, int fr_n, float f, const float *d_phi, const float *d_u,
                               float *d_force) {
     PM_REQUIRE(c && d_phi && d_u && d_force, "NULL argument");

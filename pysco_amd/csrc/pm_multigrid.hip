@@ -501,10 +501,10 @@ __device__ __forceinline__ double cubic_root(float pf, float d1f) {
 
 template <int FRN>
 __device__ __forceinline__ float cubic_p(const float *__restrict__ x, const float *__restrict__ b, int i, int j, int k,
-                                         int m, int log2n, float h2, float invsix) {
-    const float a0 = x[cidx((i - 1) & m, j, k, log2n)], a1 = x[cidx(i, (j - 1) & m, k, log2n)],
+                                         int m, int log2n, float h2, float invsix, int xmask) {
+    const float a0 = x[cidx((i - 1) & xmask, j, k, log2n)], a1 = x[cidx(i, (j - 1) & m, k, log2n)],
                 a2 = x[cidx(i, j, (k - 1) & m, log2n)], a3 = x[cidx(i, j, (k + 1) & m, log2n)],
-                a4 = x[cidx(i, (j + 1) & m, k, log2n)], a5 = x[cidx((i + 1) & m, j, k, log2n)];
+                a4 = x[cidx(i, (j + 1) & m, k, log2n)], a5 = x[cidx((i + 1) & xmask, j, k, log2n)];
     return h2 * b[cidx(i, j, k, log2n)] - invsix * (fr_pw<FRN>(a0) + fr_pw<FRN>(a1) + fr_pw<FRN>(a2) + fr_pw<FRN>(a3) +
                                                     fr_pw<FRN>(a4) + fr_pw<FRN>(a5));
 }
@@ -514,13 +514,14 @@ template <int MODE, int FRN>
 __global__ __launch_bounds__(BLK) void cubic_operator_kernel(const float *__restrict__ x, const float *__restrict__ b,
                                                              float qh2, const float *__restrict__ rhs, int log2n,
                                                              float h2, float invsix, float *__restrict__ out,
-                                                             double *__restrict__ result) {
+                                                             double *__restrict__ result, XRange xr) {
     const int n = 1 << log2n, m = n - 1;
-    const int64_t total = (int64_t)n * n * n;
+    const int64_t total = (int64_t)xr.ni << (2 * log2n);
     double acc = 0;
-    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
-        const int k = (int)(t & m), j = (int)((t >> log2n) & m), i = (int)(t >> (2 * log2n));
-        const float p = cubic_p<FRN>(x, b, i, j, k, m, log2n, h2, invsix);
+    for (int64_t t0 = (int64_t)blockIdx.x * BLK + threadIdx.x; t0 < total; t0 += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t0 & m), j = (int)((t0 >> log2n) & m), i = xr.i0 + (int)(t0 >> (2 * log2n));
+        const int64_t t = cidx(i, j, k, log2n);
+        const float p = cubic_p<FRN>(x, b, i, j, k, m, log2n, h2, invsix, xr.xmask);
         const float xt = x[t];
         if (MODE == 0) out[t] = fr_lead<FRN>(xt) + p * xt + qh2;
         if (MODE == 1) out[t] = -(fr_lead<FRN>(xt)) - p * xt - qh2 + rhs[t];
@@ -533,48 +534,74 @@ __global__ __launch_bounds__(BLK) void cubic_operator_kernel(const float *__rest
 }
 
 template <int FRN>
-static int fr_operator(pm_ctx *c, const float *d_x, const float *d_b, float q, const float *d_rhs, int n, float *d_out) {
+static int fr_operator(pm_ctx *c, const float *d_x, const float *d_b, float q, const float *d_rhs, int n, float *d_out,
+                       XRange xr) {
     PM_REQUIRE(c && d_x && d_b && d_out, "NULL argument");
     PM_CHECK_GRID(n);
-    const int64_t total = (int64_t)n * n * n;
+    const int64_t total = (int64_t)xr.ni * n * n;
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
     const int blocks = pm_stream_blocks(total, BLK);
     if (d_rhs)
         hipLaunchKernelGGL((cubic_operator_kernel<1, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, q * h2,
-                           d_rhs, ilog2(n), h2, invsix, d_out, (double *)nullptr);
+                           d_rhs, ilog2(n), h2, invsix, d_out, (double *)nullptr, xr);
     else
         hipLaunchKernelGGL((cubic_operator_kernel<0, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, q * h2,
-                           d_rhs, ilog2(n), h2, invsix, d_out, (double *)nullptr);
+                           d_rhs, ilog2(n), h2, invsix, d_out, (double *)nullptr, xr);
     PM_LAUNCH_CHECK();
     return PM_OK;
 }
 
 template <int FRN>
-static int fr_residual_error(pm_ctx *c, const float *d_x, const float *d_b, float q, int n, float *h_out) {
-    PM_REQUIRE(c && d_x && d_b && h_out, "NULL argument");
+static int fr_residual_sumsq(pm_ctx *c, const float *d_x, const float *d_b, float q, int n, XRange xr, double *h_sum) {
+    PM_REQUIRE(c && d_x && d_b && h_sum, "NULL argument");
     PM_CHECK_GRID(n);
     PM_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(double), c->stream));
-    const int64_t total = (int64_t)n * n * n;
+    const int64_t total = (int64_t)xr.ni * n * n;
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
     hipLaunchKernelGGL((cubic_operator_kernel<2, FRN>), dim3(pm_stream_blocks(total, BLK * 4)), dim3(BLK), 0, c->stream,
-                       d_x, d_b, q * h2, (const float *)nullptr, ilog2(n), h2, invsix, (float *)nullptr, c->d_hist);
+                       d_x, d_b, q * h2, (const float *)nullptr, ilog2(n), h2, invsix, (float *)nullptr, c->d_hist, xr);
     PM_LAUNCH_CHECK();
-    return read_norm(c, h_out);
+    PM_HIP(hipMemcpyAsync(h_sum, c->d_hist, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+template <int FRN>
+static int fr_residual_error(pm_ctx *c, const float *d_x, const float *d_b, float q, int n, float *h_out) {
+    PM_REQUIRE(h_out, "NULL argument");
+    double s = 0;
+    int rc = fr_residual_sumsq<FRN>(c, d_x, d_b, q, n, xr_cube(n), &s);
+    *h_out = (float)sqrt(s);
+    return rc;
 }
 
 extern "C" int pm_cubic_operator(pm_ctx *c, const float *d_x, const float *d_b, float q, const float *d_rhs, int n,
                                  float *d_out) {
-    return fr_operator<1>(c, d_x, d_b, q, d_rhs, n, d_out);
+    return fr_operator<1>(c, d_x, d_b, q, d_rhs, n, d_out, xr_cube(n));
 }
 extern "C" int pm_quartic_operator(pm_ctx *c, const float *d_x, const float *d_b, float q, const float *d_rhs, int n,
                                    float *d_out) {
-    return fr_operator<2>(c, d_x, d_b, q, d_rhs, n, d_out);
+    return fr_operator<2>(c, d_x, d_b, q, d_rhs, n, d_out, xr_cube(n));
 }
 extern "C" int pm_cubic_residual_error(pm_ctx *c, const float *d_x, const float *d_b, float q, int n, float *h_out) {
     return fr_residual_error<1>(c, d_x, d_b, q, n, h_out);
 }
 extern "C" int pm_quartic_residual_error(pm_ctx *c, const float *d_x, const float *d_b, float q, int n, float *h_out) {
     return fr_residual_error<2>(c, d_x, d_b, q, n, h_out);
+}
+
+// slab forms (level arrays [nx + 2, n, n], ghosts of d_x filled by the caller); fr_n = 1 cubic, 2 quartic
+extern "C" int pm_fr_operator_slab(pm_ctx *c, int fr_n, const float *d_x, const float *d_b, float q, const float *d_rhs,
+                                   int n, int nx, float *d_out) {
+    PM_REQUIRE(nx >= 1 && (fr_n == 1 || fr_n == 2), "bad argument");
+    return fr_n == 1 ? fr_operator<1>(c, d_x, d_b, q, d_rhs, n, d_out, xr_slab(nx))
+                     : fr_operator<2>(c, d_x, d_b, q, d_rhs, n, d_out, xr_slab(nx));
+}
+extern "C" int pm_fr_residual_sumsq_slab(pm_ctx *c, int fr_n, const float *d_x, const float *d_b, float q, int n, int nx,
+                                         double *h_sum) {
+    PM_REQUIRE(nx >= 1 && (fr_n == 1 || fr_n == 2), "bad argument");
+    return fr_n == 1 ? fr_residual_sumsq<1>(c, d_x, d_b, q, n, xr_slab(nx), h_sum)
+                     : fr_residual_sumsq<2>(c, d_x, d_b, q, n, xr_slab(nx), h_sum);
 }
 
 // cubic.py:217-265 initialise_potential (fp64 per cell under Numba's typing)
@@ -595,6 +622,18 @@ extern "C" int pm_cubic_initialise_potential(pm_ctx *c, const float *d_b, float 
     const float h2 = (float)(1.0 / ((double)n * n));
     hipLaunchKernelGGL(cubic_init_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_b,
                        3.0 * (double)h2, 27.0 * (double)h2 * (double)q, total, d_out);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// the same on `count` cells of a level with n cells per side (slab level arrays)
+extern "C" int pm_cubic_initialise_potential_flat(pm_ctx *c, const float *d_b, float q, int n, int64_t count,
+                                                  float *d_out) {
+    PM_REQUIRE(c && d_b && d_out && count > 0, "bad argument");
+    PM_CHECK_GRID(n);
+    const float h2 = (float)(1.0 / ((double)n * n));
+    hipLaunchKernelGGL(cubic_init_kernel, dim3(pm_stream_blocks(count, BLK)), dim3(BLK), 0, c->stream, d_b,
+                       3.0 * (double)h2, 27.0 * (double)h2 * (double)q, count, d_out);
     PM_LAUNCH_CHECK();
     return PM_OK;
 }
@@ -622,20 +661,32 @@ extern "C" int pm_quartic_initialise_potential(pm_ctx *c, const float *d_b, floa
     return PM_OK;
 }
 
+extern "C" int pm_quartic_initialise_potential_flat(pm_ctx *c, const float *d_b, float q, int n, int64_t count,
+                                                    float *d_out) {
+    PM_REQUIRE(c && d_b && d_out && count > 0, "bad argument");
+    PM_CHECK_GRID(n);
+    const double h2 = 1.0 / ((double)n * n);
+    hipLaunchKernelGGL(quartic_init_kernel, dim3(pm_stream_blocks(count, BLK)), dim3(BLK), 0, c->stream, d_b, h2,
+                       12.0 * h2 * (double)q, count, d_out);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
 // cubic.py:269-442 / quartic.py:270-444 gauss_seidel and cubic.py:446-668 / quartic.py:448-632
 // gauss_seidel_with_rhs: one launch per colour, one thread per cell of that colour.  `c_q` is 27 h^2 q
 // for the cubic (d1 = c_q - 27 rhs) and q h^2 for the quartic (qq = c_q - rhs).
 template <int COLOUR, bool WITH_RHS, int FRN>
 __global__ __launch_bounds__(BLK) void cubic_gauss_seidel_kernel(float *__restrict__ x, const float *__restrict__ b,
                                                                  float d1_q, const float *__restrict__ rhs, int log2n,
-                                                                 float h2, float invsix, float f_relax) {
+                                                                 float h2, float invsix, float f_relax, XRange xr,
+                                                                 int gpar) {
     const int n = 1 << log2n, m = n - 1, nh = n >> 1, log2nh = log2n - 1;
-    const int64_t total = (int64_t)n * n * nh;
+    const int64_t total = ((int64_t)xr.ni << log2n) << log2nh;
     for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
-        const int kh = (int)(t & (nh - 1)), j = (int)((t >> log2nh) & m), i = (int)(t >> (log2nh + log2n));
-        const int k = 2 * kh + ((i + j + COLOUR) & 1);
+        const int kh = (int)(t & (nh - 1)), j = (int)((t >> log2nh) & m), i = xr.i0 + (int)(t >> (log2nh + log2n));
+        const int k = 2 * kh + ((i + gpar + j + COLOUR) & 1);  // gpar: parity of (global - local) plane index
         const int64_t c = cidx(i, j, k, log2n);
-        const float p = cubic_p<FRN>(x, b, i, j, k, m, log2n, h2, invsix);
+        const float p = cubic_p<FRN>(x, b, i, j, k, m, log2n, h2, invsix, xr.xmask);
         float sol;
         if (FRN == 1) {
             const float d1 = WITH_RHS ? d1_q - 27.0f * rhs[c] : d1_q;
@@ -649,12 +700,13 @@ __global__ __launch_bounds__(BLK) void cubic_gauss_seidel_kernel(float *__restri
     }
 }
 
+// colours: 3 = red then black (the whole sweep), 1 = red only, 0 = black only (slabs: ghosts refreshed between)
 template <int FRN>
-static int fr_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
-                           float f_relax) {
+static int fr_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, const float *d_rhs, int n, float f_relax,
+                           XRange xr, int gpar, int colours) {
     PM_REQUIRE(c && d_x && d_b, "NULL argument");
     PM_CHECK_GRID(n);
-    const int64_t total = (int64_t)n * n * (n / 2);
+    const int64_t total = (int64_t)xr.ni * n * (n / 2);
     const int blocks = pm_stream_blocks(total, BLK);
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
     const int l2 = ilog2(n);
@@ -665,28 +717,41 @@ static int fr_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, con
         c_q = 27.0f * h2 * q;  // cubic.py:487 (all fp32)
     else
         c_q = (float)(27.0 * (double)h2 * (double)q);  // cubic.py:305 (int * f4 -> f8, then f4)
+    const bool red = colours == 3 || colours == 1, black = colours == 3 || colours == 0;
     if (d_rhs) {
-        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, true, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
-                           c_q, d_rhs, l2, h2, invsix, f_relax);
-        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, true, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
-                           c_q, d_rhs, l2, h2, invsix, f_relax);
+        if (red)
+            hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, true, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
+                               c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
+        if (black)
+            hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, true, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
+                               c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
     } else {
-        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, false, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
-                           c_q, d_rhs, l2, h2, invsix, f_relax);
-        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, false, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
-                           c_q, d_rhs, l2, h2, invsix, f_relax);
+        if (red)
+            hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, false, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
+                               c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
+        if (black)
+            hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, false, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
+                               c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
     }
     PM_LAUNCH_CHECK();
     return PM_OK;
 }
 
+extern "C" int pm_fr_gauss_seidel_slab(pm_ctx *c, int fr_n, float *d_x, const float *d_b, float q, const float *d_rhs,
+                                       int n, int nx, int x_lo, int colour, float f_relax) {
+    PM_REQUIRE(nx >= 1 && (fr_n == 1 || fr_n == 2) && (colour == 0 || colour == 1), "bad argument");
+    const int gpar = (x_lo - 1) & 1;
+    return fr_n == 1 ? fr_gauss_seidel<1>(c, d_x, d_b, q, d_rhs, n, f_relax, xr_slab(nx), gpar, colour)
+                     : fr_gauss_seidel<2>(c, d_x, d_b, q, d_rhs, n, f_relax, xr_slab(nx), gpar, colour);
+}
+
 extern "C" int pm_cubic_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
                                      float f_relax) {
-    return fr_gauss_seidel<1>(c, d_x, d_b, q, d_rhs, n, f_relax);
+    return fr_gauss_seidel<1>(c, d_x, d_b, q, d_rhs, n, f_relax, xr_cube(n), 0, 3);
 }
 extern "C" int pm_quartic_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
                                        float f_relax) {
-    return fr_gauss_seidel<2>(c, d_x, d_b, q, d_rhs, n, f_relax);
+    return fr_gauss_seidel<2>(c, d_x, d_b, q, d_rhs, n, f_relax, xr_cube(n), 0, 3);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -510,7 +510,8 @@ class Slab:
         grid_solvers = (not decomposed and not save_pk and _SLAB_MULTIGRID and isinstance(ops, HipOps)
                         and n >= 32 and nx >= 4 and nx % 2 == 0
                         and ((THEORY == "newton" and LINEAR_NEWTON_SOLVER == "multigrid")
-                             or (THEORY == "mond" and LINEAR_NEWTON_SOLVER in ("multigrid", "fft_7pt"))))
+                             or (THEORY == "mond" and LINEAR_NEWTON_SOLVER in ("multigrid", "fft_7pt"))
+                             or (THEORY == "fr" and LINEAR_NEWTON_SOLVER in ("multigrid", "fft", "fft_7pt"))))
         if not decomposed and not grid_solvers:
             return self._pm_replicated_grid(position, param, potential, additional_field, tables, kick, scheme)
         param["save_pk"] = False
@@ -647,6 +648,22 @@ class Slab:
                 raise NotImplementedError(f"{param['linear_newton_solver']=}, should be 'multigrid' or 'fft_7pt'")
             ops.linear_operator_inplace(dens, f1, -f1)
             af = solve(owned(additional_field), dens, None)
+        if THEORY == "fr":  # solver.py:326-359: scalaron u by FAS on slabs
+            from . import solver as _solver
+
+            Rbar = 3 * param["Om_m"] * param["aexp"] ** (-3) + 12 * param["Om_lambda"]
+            Rbar0 = 3 * param["Om_m"] + 12 * param["Om_lambda"]
+            fR_a = -param["aexp"] ** 2 * ((Rbar0 / Rbar) ** (param["fR_n"] + 1)) * 10.0 ** (-param["fR_logfR0"])
+            c2 = (_solver._C_LIGHT * 1e-3 * param["unit_t"] / (param["unit_l"] * param["aexp"])) ** 2
+            g1 = np.float32(param["aexp"] * param["Om_m"] / (c2 * 6)) / (-fR_a)
+            g2 = np.float32(Rbar / 3 * param["aexp"] ** 4 - param["Om_m"] * param["aexp"]) / (6 * c2) / (-fR_a)
+            dens_term = torch.empty_like(dens)
+            self.ops.ctx.call("pm_linear_operator", L.ptr(dens_term), L.ptr(dens), float(g1), float(g2), dens.numel())
+            param["fR_q"] = np.float32(-param["aexp"] ** 4 * Rbar / (18 * c2)) / (-fR_a)
+            u0 = owned(additional_field)
+            af = mg.fr_initialise_potential(dens_term, param) if u0 is None else mg.extend(u0)
+            af = mg.FAS(af, dens_term, param)
+            del dens_term
         param["compute_additional_field"] = False
         if THEORY == "mond":  # solver.py:381-443: density <- div[nu(|grad phi_N| / g0) grad phi_N]
             g0 = (param["mond_g0"] * 1e-3 * 1e-10 * param["unit_t"] ** 2 / param["unit_l"]
@@ -657,7 +674,7 @@ class Slab:
                 raise NotImplementedError(f"MOND_FUNCTION={fn!r}, should be 'simple', 'n', 'beta', 'gamma' or 'delta'")
             rhs = dens  # reused as the output buffer
             mg.mond_rhs(af, rhs, g0, kinds[fn], param["mond_alpha"])
-        else:
+        else:  # newton / fr: f1 (rho - 1)
             rhs = dens
             ops.linear_operator_inplace(rhs, f1, -f1)
         pot0 = owned(potential)
@@ -668,9 +685,36 @@ class Slab:
         phi_lvl = solve(pot0, rhs, warm)
         del rhs, dens
         phi = phi_lvl[1:nx + 1]
-        acc = self._gather(phi, position, param, scheme, kick)
+        if THEORY == "fr":  # force = grad(phi) + half_c2 grad(u^(n+1)) (solver.py:167-203): force grid + gather
+            acc = self._gather_fr(phi, af[1:nx + 1], position, param, scheme, kick)
+        else:
+            acc = self._gather(phi, position, param, scheme, kick)
         extra = af[1:nx + 1] if af is not None else torch.empty(0, dtype=torch.float32, device=dev)
         return acc, phi, extra
+
+    def _gather_fr(self, phi, u, position, param, scheme, kick):
+        """f(R) force from the owned planes of potential and scalaron (mesh.derivative_fR) and the gather."""
+        import torch
+
+        from . import solver as _solver
+
+        n, nx, ops = self.n, self.nx, self.ops
+        order = param["gradient_stencil_order"]
+        if order not in _REACH:
+            raise ValueError(f"gradient_order={order}, should be 2, 3, 5 or 7")
+        H = _REACH[order] + 1
+        ext = []
+        for f in (phi, u):
+            from_left, from_right = exchange_planes(f[:H], f[nx - H:])
+            ext.append(torch.cat([from_left, f, from_right], dim=0))
+        force = torch.empty((nx + 2, n, n, 3), dtype=torch.float32, device=phi.device)
+        ops.ctx.call("pm_gradient_fr_slab", int(order), int(param["fR_n"]), float(_solver.fr_half_c2(param)),
+                     L.ptr(ext[0]), L.ptr(ext[1]), nx + 2 * H, self.x_lo - H, L.ptr(force), nx + 2, self.x_lo - 1)
+        del ext
+        vel, half_dt = (kick if kick is not None else (None, 0.0))
+        acc, ma, mv = ops.interp_kick(scheme, force, nx + 2, self.x_lo - 1, position, vel, half_dt)
+        self.local_max = (ma, mv)
+        return acc
 
     def _pm_replicated_grid(self, position, param, potential, additional_field, tables, kick, scheme):
         """Multigrid / f(R) / MOND / P(k) under slabs, first cut: the particles (deposit, gather, kick) stay

@@ -200,3 +200,121 @@ class SlabMultigrid:
         self.exchange(pot)
         self._ctx(n).call("pm_mond_rhs_slab", L.ptr(pot), L.ptr(out), n, nx, float(np.float32(g0)), int(kind),
                           float(np.float32(alpha)))
+
+    # ---- f(R): Full Approximation Scheme on slabs (multigrid.py:88-138, 521-579; cubic.py / quartic.py) ----------
+    def _fr(self, param):
+        n_fr = int(param["fR_n"])
+        if n_fr not in (1, 2):
+            raise NotImplementedError(f"Only f(R) with n = 1 and 2, currently {param['fR_n']=}")
+        return n_fr, float(np.float32(param["fR_q"]))
+
+    def fr_operator(self, x, b, param, rhs=None):
+        """operator(x, b, q) or, with rhs, residual_with_rhs = rhs - operator (cubic.py:23, 90)."""
+        n, nx = x.shape[1], x.shape[0] - 2
+        n_fr, q = self._fr(param)
+        self.exchange(x)
+        out = self.torch.empty_like(x)
+        self._ctx(n).call("pm_fr_operator_slab", n_fr, L.ptr(x), L.ptr(b), q, None if rhs is None else L.ptr(rhs), n, nx,
+                          L.ptr(out))
+        return out
+
+    def fr_smoothing(self, x, b, nsweeps: int, param, rhs=None) -> None:
+        n, nx = x.shape[1], x.shape[0] - 2
+        n_fr, q = self._fr(param)
+        ctx, x_lo = self._ctx(n), self.rank * nx
+        for _ in range(int(nsweeps)):
+            for colour in (1, 0):
+                self.exchange(x)
+                ctx.call("pm_fr_gauss_seidel_slab", n_fr, L.ptr(x), L.ptr(b), q, None if rhs is None else L.ptr(rhs), n,
+                         nx, x_lo, colour, 1.25)
+
+    def restriction(self, x, scale=0.125):
+        n, nx = x.shape[1], x.shape[0] - 2
+        out = self.new(n // 2)
+        self._ctx(n).call("pm_restriction_slab", L.ptr(x), n, nx, float(scale), L.ptr(out))
+        return out
+
+    def fr_residual_error(self, x, b, param) -> np.float32:
+        n, nx = x.shape[1], x.shape[0] - 2
+        n_fr, q = self._fr(param)
+        self.exchange(x)
+        s = C.c_double(0)
+        self._ctx(n).call("pm_fr_residual_sumsq_slab", n_fr, L.ptr(x), L.ptr(b), q, n, nx, C.byref(s))
+        return np.float32(np.sqrt(self.all_sum(s.value)))
+
+    def fr_truncation_error(self, x, b, param) -> np.float32:
+        """|| 4 R(L x) - L(R x, R b) || (cubic.py:1021)."""
+        n = x.shape[1]
+        RLx = self.restriction(self.fr_operator(x, b, param))
+        LRx = self.fr_operator(self.restriction(x), self.restriction(b), param)
+        s = C.c_double(0)
+        a, bb = RLx[1:-1], LRx[1:-1]
+        self._ctx(n).call("pm_diff_sumsq", L.ptr(a), L.ptr(bb), 4.0, a.numel(), C.byref(s))
+        return np.float32(np.sqrt(self.all_sum(s.value)))
+
+    def V_cycle_FAS(self, x, b, param, nlevel: int = 0, rhs=None) -> None:
+        from . import utils
+
+        n = x.shape[1]
+        n_c = n // 2
+        self.fr_smoothing(x, b, param["Npre"], param, rhs)
+        if rhs is None:   # multigrid.py:282: minus_restriction(operator) or restriction(residual_with_rhs)
+            res_c = self.restriction(self.fr_operator(x, b, param), -0.125)
+        else:
+            res_c = self.restriction(self.fr_operator(x, b, param, rhs))
+        x_c = self.restriction(x)
+        b_c = self.restriction(b)
+        if self.distributed(n_c):
+            x_corr_c = x_c.clone()
+            L_c = self.fr_operator(x_c, b_c, param)
+            utils.linear_operator_vectors_inplace(res_c, multigrid.normalisation_residual(param), L_c, np.float32(1))
+            del L_c
+            if nlevel >= (param["ncoarse"] - 3):
+                self.fr_smoothing(x_corr_c, b_c, param["Npre"], param, res_c)
+            else:
+                self.V_cycle_FAS(x_corr_c, b_c, param, nlevel + 1, res_c)
+            utils.add_vector_scalar_inplace(x_corr_c, x_c, np.float32(-1))
+            self.add_prolongation(x, x_corr_c)
+        else:  # small coarse problem: every rank runs the rest of the cycle on all of it
+            x_full, b_full, res_full = self.gather_full(x_c), self.gather_full(b_c), self.gather_full(res_c)
+            x_corr_full = x_full.clone()
+            L_full = multigrid.operator(x_full, param, b_full)
+            utils.linear_operator_vectors_inplace(res_full, multigrid.normalisation_residual(param), L_full, np.float32(1))
+            del L_full
+            if nlevel >= (param["ncoarse"] - 3):
+                multigrid.smoothing(x_corr_full, b_full, param["Npre"], param, res_full)
+            else:
+                multigrid.V_cycle_FAS(x_corr_full, b_full, param, nlevel + 1, res_full)
+            utils.add_vector_scalar_inplace(x_corr_full, x_full, np.float32(-1))
+            x_corr_c = self._take_planes(x_corr_full, n_c, n_c // self.world)
+            self._ctx(n).call("pm_prolongation_slab", L.ptr(x), L.ptr(x_corr_c), n_c, x_corr_c.shape[0] - 2, 1)
+            del x_full, b_full, res_full, x_corr_full
+        del res_c, b_c, x_c, x_corr_c
+        self.fr_smoothing(x, b, param["Npost"], param, rhs)
+
+    def FAS(self, x, b, param):
+        """multigrid.FAS (multigrid.py:88) on level arrays; in place on x."""
+        if ("tolerance_FAS" not in param) or (param["nsteps"] % 3) == 0:
+            logging.info("Compute FAS Truncation error")
+            param["tolerance_FAS"] = param["epsrel"] * self.fr_truncation_error(x, b, param)
+        tolerance = param["tolerance_FAS"]
+        residual_err = 1e30
+        while residual_err > tolerance:
+            self.V_cycle_FAS(x, b, param)
+            residual_error_tmp = self.fr_residual_error(x, b, param)
+            logging.info(f"{residual_error_tmp=} {tolerance=}")
+            if residual_error_tmp < tolerance or residual_err / residual_error_tmp < 2:
+                break
+            residual_err = residual_error_tmp
+        return x
+
+    def fr_initialise_potential(self, b, param):
+        """cubic / quartic initialise_potential (cubic.py:217, quartic.py:214): per cell, whole level array."""
+        n = b.shape[1]
+        n_fr, q = self._fr(param)
+        out = self.torch.empty_like(b)
+        # the single-GPU kernel is element-wise over count = n^3 cells with h = 1/n: run it plane by plane range
+        name = "pm_cubic_initialise_potential" if n_fr == 1 else "pm_quartic_initialise_potential"
+        self._ctx(n).call(name + "_flat", L.ptr(b), q, n, b.numel(), L.ptr(out))
+        return out
+

@@ -131,12 +131,13 @@ def test_two_ranks_on_one_gpu_hip(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("theory", ["newton_mg", "mond", "mond_fft7pt", "newton_mg_replicated", "mond_replicated", "fr"])
+@pytest.mark.parametrize("theory", ["newton_mg", "mond", "mond_fft7pt", "fr", "newton_mg_replicated", "mond_replicated",
+                                    "fr_replicated"])
 def test_two_ranks_grid_solvers_hip(tmp_path, theory):
     """Multigrid / MOND / f(R) under slabs (HIP kernels, 2 ranks sharing cuda:0 over gloo) against the
-    single-process oracle, at the solvers' own accuracy.  Newton-multigrid and QUMOND run decomposed: halo-exchange
-    V-cycles (slab_multigrid.py), the MOND source stencil on slabs, the slab FFT for fft_7pt; the `_replicated`
-    variants and f(R) all-gather the density and solve the grid on every rank."""
+    single-process oracle, at the solvers' own accuracy.  Decomposed: halo-exchange V-cycles and FAS cycles
+    (slab_multigrid.py), the MOND source stencil and the f(R) force on slabs, the slab FFT for fft_7pt; the
+    `_replicated` variants all-gather the density and solve the grid on every rank."""
     n, steps, world = 32, 1, 2
     ranks = run_ranks(world, tmp_path, "hip", n, steps, theory=theory)
     base = theory.replace("_replicated", "")
@@ -145,7 +146,7 @@ def test_two_ranks_grid_solvers_hip(tmp_path, theory):
     acc0 = np.concatenate([r["acc0"] for r in ranks])
     sa = np.abs(ref["acc0"]).max()
     np.testing.assert_allclose(acc0, ref["acc0"][ids0], rtol=0, atol=2e-3 * sa)
-    decomposed = theory in ("newton_mg", "mond", "mond_fft7pt")
+    decomposed = theory in ("newton_mg", "mond", "mond_fft7pt", "fr")
     sp = np.abs(ref["phi0"]).max()
     if decomposed:  # every rank holds its planes of the potential
         phi0 = np.concatenate([r["phi0"] for r in ranks], axis=0)
