@@ -131,6 +131,32 @@ def test_two_ranks_on_one_gpu_hip(tmp_path):
 
 
 @pytest.mark.gpu
+def test_four_ranks_on_one_gpu_hip(tmp_path):
+    """Four ranks (16 planes each at 64^3) sharing cuda:0: four-segment x lines in the pipelined slab FFT, two-tile
+    windows, ring neighbours that differ, particles crossing three boundaries."""
+    n, steps, world = 64, 2, 4
+    ranks = run_ranks(world, tmp_path, "hip", n, steps)
+    check_against_reference(ranks, reference_run(n, steps), n, world)
+
+
+@pytest.mark.gpu
+def test_four_ranks_mond_multigrid_hip(tmp_path):
+    """QUMOND with halo-exchange multigrid on four ranks: three distributed levels (64, 32, 16), replicated below."""
+    n, steps, world = 64, 1, 4
+    ranks = run_ranks(world, tmp_path, "hip", n, steps, theory="mond")
+    ref = reference_run(n, steps, theory="mond")
+    ids0 = np.concatenate([r["id0"] for r in ranks])
+    acc0 = np.concatenate([r["acc0"] for r in ranks])
+    np.testing.assert_allclose(acc0, ref["acc0"][ids0], rtol=0, atol=2e-3 * np.abs(ref["acc0"]).max())
+    phi0 = np.concatenate([r["phi0"] for r in ranks], axis=0)
+    np.testing.assert_allclose(phi0, ref["phi0"], rtol=0, atol=5e-4 * np.abs(ref["phi0"]).max())
+    ids = np.concatenate([r["id"] for r in ranks])
+    assert sorted(ids.tolist()) == list(range(n**3))
+    d = np.abs(np.concatenate([r["pos"] for r in ranks]) - ref["pos"][ids])
+    assert np.minimum(d, 1 - d).max() < 1e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("theory", ["newton_mg", "mond", "mond_fft7pt", "fr", "newton_mg_replicated", "mond_replicated",
                                     "fr_replicated"])
 def test_two_ranks_grid_solvers_hip(tmp_path, theory):
