@@ -252,6 +252,20 @@ class HipOps:
         self.ctx.call("pm_fftp_inverse", L.ptr(c), nx, L.ptr(out))
         return out
 
+    def gradient_fr(self, order, fr_n, f, phi_ext, u_ext, x0_phi, nx_force, x0_force):
+        """f(R) force (mesh.derivative_fR) on nx_force planes from potential / scalaron slabs with ghosts."""
+        n = self.n
+        out = self.torch.empty((nx_force, n, n, 3), dtype=self.torch.float32, device=phi_ext.device)
+        self.ctx.call("pm_gradient_fr_slab", int(order), int(fr_n), float(np.float32(f)), L.ptr(phi_ext), L.ptr(u_ext),
+                      phi_ext.shape[0], int(x0_phi), L.ptr(out), nx_force, int(x0_force))
+        return out
+
+    def level_kernels(self):
+        """Level operations of the slab multigrid (slab_multigrid.HipLevelKernels)."""
+        from .slab_multigrid import HipLevelKernels
+
+        return HipLevelKernels()
+
     def gradient(self, order, phi_ext, x0_phi, nx_force, x0_force):
         n = self.n
         out = self.torch.empty((nx_force, n, n, 3), dtype=self.torch.float32, device=phi_ext.device)
@@ -507,7 +521,7 @@ class Slab:
         nx = self.nx
         decomposed = THEORY == "newton" and LINEAR_NEWTON_SOLVER in ("fft", "fft_7pt") and not save_pk
         # Newton + multigrid and QUMOND: halo-exchange multigrid / slab FFT (HIP provider, >= 4 planes per rank)
-        grid_solvers = (not decomposed and not save_pk and _SLAB_MULTIGRID and isinstance(ops, HipOps)
+        grid_solvers = (not decomposed and not save_pk and _SLAB_MULTIGRID and hasattr(ops, "level_kernels")
                         and n >= 32 and nx >= 4 and nx % 2 == 0
                         and ((THEORY == "newton" and LINEAR_NEWTON_SOLVER == "multigrid")
                              or (THEORY == "mond" and LINEAR_NEWTON_SOLVER in ("multigrid", "fft_7pt"))
@@ -609,7 +623,7 @@ class Slab:
         from .slab_multigrid import SlabMultigrid
 
         n, nx, ops = self.n, self.nx, self.ops
-        mg = getattr(self, "_mg", None) or SlabMultigrid(self)
+        mg = getattr(self, "_mg", None) or SlabMultigrid(self, ops.level_kernels())
         self._mg = mg
         THEORY = param["theory"].casefold()
         SOLVER = param["linear_newton_solver"].casefold()
@@ -658,7 +672,7 @@ class Slab:
             g1 = np.float32(param["aexp"] * param["Om_m"] / (c2 * 6)) / (-fR_a)
             g2 = np.float32(Rbar / 3 * param["aexp"] ** 4 - param["Om_m"] * param["aexp"]) / (6 * c2) / (-fR_a)
             dens_term = torch.empty_like(dens)
-            self.ops.ctx.call("pm_linear_operator", L.ptr(dens_term), L.ptr(dens), float(g1), float(g2), dens.numel())
+            mg.k.linear_operator(dens_term, dens, g1, g2)
             param["fR_q"] = np.float32(-param["aexp"] ** 4 * Rbar / (18 * c2)) / (-fR_a)
             u0 = owned(additional_field)
             af = mg.fr_initialise_potential(dens_term, param) if u0 is None else mg.extend(u0)
@@ -707,9 +721,8 @@ class Slab:
         for f in (phi, u):
             from_left, from_right = exchange_planes(f[:H], f[nx - H:])
             ext.append(torch.cat([from_left, f, from_right], dim=0))
-        force = torch.empty((nx + 2, n, n, 3), dtype=torch.float32, device=phi.device)
-        ops.ctx.call("pm_gradient_fr_slab", int(order), int(param["fR_n"]), float(_solver.fr_half_c2(param)),
-                     L.ptr(ext[0]), L.ptr(ext[1]), nx + 2 * H, self.x_lo - H, L.ptr(force), nx + 2, self.x_lo - 1)
+        force = ops.gradient_fr(order, int(param["fR_n"]), _solver.fr_half_c2(param), ext[0], ext[1], self.x_lo - H, nx + 2,
+                                self.x_lo - 1)
         del ext
         vel, half_dt = (kick if kick is not None else (None, 0.0))
         acc, ma, mv = ops.interp_kick(scheme, force, nx + 2, self.x_lo - 1, position, vel, half_dt)

@@ -21,16 +21,115 @@ from . import _lib as L
 from . import laplacian, multigrid
 
 
-class SlabMultigrid:
-    def __init__(self, slab):
-        self.slab = slab
+class HipLevelKernels:
+    """The level operations of the slab multigrid through the C ABI (pmstep.h slab entry points).  Level arrays
+    are [nx + 2, n, n] torch CUDA tensors.  tests/slab_oracle_ops.py holds a CPU twin (test-only) with the same
+    methods so that the orchestration below can run under gloo without a GPU."""
+
+    device = "cuda"
+
+    def __init__(self):
         self.torch = L.require_gpu()
+
+    @staticmethod
+    def _dims(x):
+        return x.shape[1], x.shape[0] - 2
+
+    def gs(self, x, b, x_lo, colour) -> None:
+        n, nx = self._dims(x)
+        L.context(n).call("pm_lap_gauss_seidel_slab", L.ptr(x), L.ptr(b), n, nx, int(x_lo), int(colour), 1.25)
+
+    def restrict_residual(self, x, b, out) -> None:
+        n, nx = self._dims(x)
+        L.context(n).call("pm_lap_restrict_residual_slab", L.ptr(x), L.ptr(b), n, nx, L.ptr(out))
+
+    def restriction(self, x, scale, out) -> None:
+        n, nx = self._dims(x)
+        L.context(n).call("pm_restriction_slab", L.ptr(x), n, nx, float(scale), L.ptr(out))
+
+    def prolongation_add(self, y, x_c) -> None:
+        nc, nxc = self._dims(x_c)
+        L.context(2 * nc).call("pm_prolongation_slab", L.ptr(y), L.ptr(x_c), nc, nxc, 1)
+
+    def operator(self, x, out) -> None:
+        n, nx = self._dims(x)
+        L.context(n).call("pm_lap_operator_slab", L.ptr(x), None, n, nx, 0, L.ptr(out))
+
+    def residual_sumsq(self, x, b) -> float:
+        n, nx = self._dims(x)
+        s = C.c_double(0)
+        L.context(n).call("pm_lap_residual_sumsq_slab", L.ptr(x), L.ptr(b), n, nx, C.byref(s))
+        return s.value
+
+    def diff_sumsq(self, a, b, f) -> float:
+        s = C.c_double(0)
+        L.context(a.shape[1]).call("pm_diff_sumsq", L.ptr(a), L.ptr(b), float(f), a.numel(), C.byref(s))
+        return s.value
+
+    def linear_operator(self, out, x, f1, f2) -> None:
+        L.context(x.shape[1]).call("pm_linear_operator", L.ptr(out), L.ptr(x), float(f1), float(f2), x.numel())
+
+    def mond_rhs(self, pot, out, g0, kind, alpha) -> None:
+        n, nx = self._dims(pot)
+        L.context(n).call("pm_mond_rhs_slab", L.ptr(pot), L.ptr(out), n, nx, float(np.float32(g0)), int(kind),
+                          float(np.float32(alpha)))
+
+    # f(R)
+    def fr_operator(self, n_fr, x, b, q, rhs, out) -> None:
+        n, nx = self._dims(x)
+        L.context(n).call("pm_fr_operator_slab", n_fr, L.ptr(x), L.ptr(b), q, None if rhs is None else L.ptr(rhs), n, nx,
+                          L.ptr(out))
+
+    def fr_gs(self, n_fr, x, b, q, rhs, x_lo, colour) -> None:
+        n, nx = self._dims(x)
+        L.context(n).call("pm_fr_gauss_seidel_slab", n_fr, L.ptr(x), L.ptr(b), q, None if rhs is None else L.ptr(rhs), n,
+                          nx, int(x_lo), int(colour), 1.25)
+
+    def fr_residual_sumsq(self, n_fr, x, b, q) -> float:
+        n, nx = self._dims(x)
+        s = C.c_double(0)
+        L.context(n).call("pm_fr_residual_sumsq_slab", n_fr, L.ptr(x), L.ptr(b), q, n, nx, C.byref(s))
+        return s.value
+
+    def fr_initialise_potential(self, n_fr, b, q, out) -> None:
+        name = "pm_cubic_initialise_potential_flat" if n_fr == 1 else "pm_quartic_initialise_potential_flat"
+        L.context(b.shape[1]).call(name, L.ptr(b), q, b.shape[1], b.numel(), L.ptr(out))
+
+    # the small replicated coarse problems: the single-GPU cycle on full grids
+    def coarse_linear(self, res_full, param, nlevel):
+        x_full = laplacian.initialise_potential(res_full)
+        if nlevel >= (param["ncoarse"] - 3):
+            laplacian.smoothing(x_full, res_full, param["Npre"])
+        else:
+            multigrid.V_cycle(x_full, res_full, param, nlevel + 1)
+        return x_full
+
+    def coarse_fas(self, x_full, b_full, res_full, param, nlevel):
+        """Rest of a FAS cycle below this level; returns the coarse correction x_corr - x."""
+        from . import utils
+
+        x_corr_full = x_full.clone()
+        L_full = multigrid.operator(x_full, param, b_full)
+        utils.linear_operator_vectors_inplace(res_full, multigrid.normalisation_residual(param), L_full, np.float32(1))
+        del L_full
+        if nlevel >= (param["ncoarse"] - 3):
+            multigrid.smoothing(x_corr_full, b_full, param["Npre"], param, res_full)
+        else:
+            multigrid.V_cycle_FAS(x_corr_full, b_full, param, nlevel + 1, res_full)
+        utils.add_vector_scalar_inplace(x_corr_full, x_full, np.float32(-1))
+        return x_corr_full
+
+
+class SlabMultigrid:
+    def __init__(self, slab, kernels=None):
+        import torch
+
+        self.slab = slab
+        self.k = kernels if kernels is not None else HipLevelKernels()
+        self.torch = torch
         self.world, self.rank = slab.world, slab.rank
 
     # ---- level geometry / communication ---------------------------------------------------------
-    def _ctx(self, n):
-        return L.context(n)
-
     def nx_of(self, n_l: int) -> int:
         return n_l // self.world
 
@@ -40,7 +139,7 @@ class SlabMultigrid:
         return n_l >= 16 and n_l % self.world == 0 and nx >= 2 and nx % 2 == 0
 
     def new(self, n_l: int):
-        return self.torch.empty((self.nx_of(n_l) + 2, n_l, n_l), dtype=self.torch.float32, device="cuda")
+        return self.torch.empty((self.nx_of(n_l) + 2, n_l, n_l), dtype=self.torch.float32, device=self.k.device)
 
     def extend(self, owned):
         """[nx, n, n] owned planes -> level array with (unfilled) ghosts."""
@@ -77,60 +176,47 @@ class SlabMultigrid:
 
     # ---- level operations (pmstep.h slab entry points) ---------------------------------------------------
     def smoothing(self, x, b, nsweeps: int) -> None:
-        n, nx = x.shape[1], x.shape[0] - 2
-        ctx = self._ctx(n)
-        x_lo = self.rank * nx
+        x_lo = self.rank * (x.shape[0] - 2)
         for _ in range(int(nsweeps)):
             for colour in (1, 0):  # red, then black (laplacian.py:870-1022)
                 self.exchange(x)
-                ctx.call("pm_lap_gauss_seidel_slab", L.ptr(x), L.ptr(b), n, nx, x_lo, colour, 1.25)
+                self.k.gs(x, b, x_lo, colour)
 
     def restrict_residual(self, x, b):
-        n, nx = x.shape[1], x.shape[0] - 2
-        out = self.new(n // 2)
+        out = self.new(x.shape[1] // 2)
         self.exchange(x)
-        self._ctx(n).call("pm_lap_restrict_residual_slab", L.ptr(x), L.ptr(b), n, nx, L.ptr(out))
+        self.k.restrict_residual(x, b, out)
         return out
 
     def add_prolongation(self, x, x_c) -> None:
-        nc, nxc = x_c.shape[1], x_c.shape[0] - 2
         self.exchange(x_c)
-        self._ctx(2 * nc).call("pm_prolongation_slab", L.ptr(x), L.ptr(x_c), nc, nxc, 1)
+        self.k.prolongation_add(x, x_c)
 
     def initialise_potential(self, b):
         """-h^2/6 * b (laplacian.py:765) on the whole level array."""
         n = b.shape[1]
         out = self.torch.empty_like(b)
         h = np.float32(1.0 / n)
-        self._ctx(n).call("pm_linear_operator", L.ptr(out), L.ptr(b), float(np.float32(-float(h * h) / 6.0)), 0.0,
-                          b.numel())
+        self.k.linear_operator(out, b, np.float32(-float(h * h) / 6.0), 0.0)
         return out
 
     def residual_error(self, x, b) -> np.float32:
-        n, nx = x.shape[1], x.shape[0] - 2
         self.exchange(x)
-        s = C.c_double(0)
-        self._ctx(n).call("pm_lap_residual_sumsq_slab", L.ptr(x), L.ptr(b), n, nx, C.byref(s))
-        return np.float32(np.sqrt(self.all_sum(s.value)))
+        return np.float32(np.sqrt(self.all_sum(self.k.residual_sumsq(x, b))))
 
     def truncation_error(self, x) -> np.float32:
         """|| R(L x) - L(R x) || (laplacian.py:502) on slabs."""
-        n, nx = x.shape[1], x.shape[0] - 2
-        ctx = self._ctx(n)
+        n = x.shape[1]
         self.exchange(x)
         Lx = self.torch.empty_like(x)
-        ctx.call("pm_lap_operator_slab", L.ptr(x), None, n, nx, 0, L.ptr(Lx))
-        RLx = self.new(n // 2)
-        ctx.call("pm_restriction_slab", L.ptr(Lx), n, nx, 0.125, L.ptr(RLx))
-        Rx = self.new(n // 2)
-        ctx.call("pm_restriction_slab", L.ptr(x), n, nx, 0.125, L.ptr(Rx))
+        self.k.operator(x, Lx)
+        RLx, Rx = self.new(n // 2), self.new(n // 2)
+        self.k.restriction(Lx, 0.125, RLx)
+        self.k.restriction(x, 0.125, Rx)
         self.exchange(Rx)
         LRx = self.torch.empty_like(Rx)
-        self._ctx(n // 2).call("pm_lap_operator_slab", L.ptr(Rx), None, n // 2, nx // 2, 0, L.ptr(LRx))
-        s = C.c_double(0)
-        a, bb = RLx[1:-1], LRx[1:-1]  # owned planes: contiguous
-        ctx.call("pm_diff_sumsq", L.ptr(a), L.ptr(bb), 1.0, a.numel(), C.byref(s))
-        return np.float32(np.sqrt(self.all_sum(s.value)))
+        self.k.operator(Rx, LRx)
+        return np.float32(np.sqrt(self.all_sum(self.k.diff_sumsq(RLx[1:-1], LRx[1:-1], 1.0))))  # owned planes: contiguous
 
     # ---- the cycle (multigrid.py:474-517) -----------------------------------------------------------------------
     def V_cycle(self, x, b, param, nlevel: int = 0) -> None:
@@ -145,23 +231,16 @@ class SlabMultigrid:
             else:
                 self.V_cycle(x_corr_c, res_c, param, nlevel + 1)
         else:  # small coarse problem: every rank solves all of it
-            res_full = self.gather_full(res_c)
-            x_full = laplacian.initialise_potential(res_full)
-            if nlevel >= (param["ncoarse"] - 3):
-                laplacian.smoothing(x_full, res_full, param["Npre"])
-            else:
-                multigrid.V_cycle(x_full, res_full, param, nlevel + 1)
-            nxc = n_c // self.world if n_c % self.world == 0 else None
-            x_corr_c = self._take_planes(x_full, n_c, nxc)
-            del res_full, x_full
+            x_full = self.k.coarse_linear(self.gather_full(res_c), param, nlevel)
+            x_corr_c = self._take_planes(x_full, n_c, n_c // self.world if n_c % self.world == 0 else None)
+            del x_full
         del res_c
-        if x_corr_c.shape[0] - 2 == (x.shape[0] - 2) // 2:
-            if self.distributed(n_c):
-                self.add_prolongation(x, x_corr_c)
-            else:  # ghosts already taken from the full grid
-                self._ctx(n).call("pm_prolongation_slab", L.ptr(x), L.ptr(x_corr_c), n_c, x_corr_c.shape[0] - 2, 1)
-        else:
+        if x_corr_c.shape[0] - 2 != (x.shape[0] - 2) // 2:
             raise RuntimeError("inconsistent slab multigrid geometry")
+        if self.distributed(n_c):
+            self.add_prolongation(x, x_corr_c)
+        else:  # ghosts already taken from the full grid
+            self.k.prolongation_add(x, x_corr_c)
         del x_corr_c
         self.smoothing(x, b, param["Npost"])
 
@@ -196,10 +275,8 @@ class SlabMultigrid:
         return x
 
     def mond_rhs(self, pot, out, g0, kind: int, alpha) -> None:
-        n, nx = pot.shape[1], pot.shape[0] - 2
         self.exchange(pot)
-        self._ctx(n).call("pm_mond_rhs_slab", L.ptr(pot), L.ptr(out), n, nx, float(np.float32(g0)), int(kind),
-                          float(np.float32(alpha)))
+        self.k.mond_rhs(pot, out, g0, kind, alpha)
 
     # ---- f(R): Full Approximation Scheme on slabs (multigrid.py:88-138, 521-579; cubic.py / quartic.py) ----------
     def _fr(self, param):
@@ -210,51 +287,37 @@ class SlabMultigrid:
 
     def fr_operator(self, x, b, param, rhs=None):
         """operator(x, b, q) or, with rhs, residual_with_rhs = rhs - operator (cubic.py:23, 90)."""
-        n, nx = x.shape[1], x.shape[0] - 2
         n_fr, q = self._fr(param)
         self.exchange(x)
         out = self.torch.empty_like(x)
-        self._ctx(n).call("pm_fr_operator_slab", n_fr, L.ptr(x), L.ptr(b), q, None if rhs is None else L.ptr(rhs), n, nx,
-                          L.ptr(out))
+        self.k.fr_operator(n_fr, x, b, q, rhs, out)
         return out
 
     def fr_smoothing(self, x, b, nsweeps: int, param, rhs=None) -> None:
-        n, nx = x.shape[1], x.shape[0] - 2
         n_fr, q = self._fr(param)
-        ctx, x_lo = self._ctx(n), self.rank * nx
+        x_lo = self.rank * (x.shape[0] - 2)
         for _ in range(int(nsweeps)):
             for colour in (1, 0):
                 self.exchange(x)
-                ctx.call("pm_fr_gauss_seidel_slab", n_fr, L.ptr(x), L.ptr(b), q, None if rhs is None else L.ptr(rhs), n,
-                         nx, x_lo, colour, 1.25)
+                self.k.fr_gs(n_fr, x, b, q, rhs, x_lo, colour)
 
     def restriction(self, x, scale=0.125):
-        n, nx = x.shape[1], x.shape[0] - 2
-        out = self.new(n // 2)
-        self._ctx(n).call("pm_restriction_slab", L.ptr(x), n, nx, float(scale), L.ptr(out))
+        out = self.new(x.shape[1] // 2)
+        self.k.restriction(x, scale, out)
         return out
 
     def fr_residual_error(self, x, b, param) -> np.float32:
-        n, nx = x.shape[1], x.shape[0] - 2
         n_fr, q = self._fr(param)
         self.exchange(x)
-        s = C.c_double(0)
-        self._ctx(n).call("pm_fr_residual_sumsq_slab", n_fr, L.ptr(x), L.ptr(b), q, n, nx, C.byref(s))
-        return np.float32(np.sqrt(self.all_sum(s.value)))
+        return np.float32(np.sqrt(self.all_sum(self.k.fr_residual_sumsq(n_fr, x, b, q))))
 
     def fr_truncation_error(self, x, b, param) -> np.float32:
         """|| 4 R(L x) - L(R x, R b) || (cubic.py:1021)."""
-        n = x.shape[1]
         RLx = self.restriction(self.fr_operator(x, b, param))
         LRx = self.fr_operator(self.restriction(x), self.restriction(b), param)
-        s = C.c_double(0)
-        a, bb = RLx[1:-1], LRx[1:-1]
-        self._ctx(n).call("pm_diff_sumsq", L.ptr(a), L.ptr(bb), 4.0, a.numel(), C.byref(s))
-        return np.float32(np.sqrt(self.all_sum(s.value)))
+        return np.float32(np.sqrt(self.all_sum(self.k.diff_sumsq(RLx[1:-1], LRx[1:-1], 4.0))))
 
     def V_cycle_FAS(self, x, b, param, nlevel: int = 0, rhs=None) -> None:
-        from . import utils
-
         n = x.shape[1]
         n_c = n // 2
         self.fr_smoothing(x, b, param["Npre"], param, rhs)
@@ -267,28 +330,20 @@ class SlabMultigrid:
         if self.distributed(n_c):
             x_corr_c = x_c.clone()
             L_c = self.fr_operator(x_c, b_c, param)
-            utils.linear_operator_vectors_inplace(res_c, multigrid.normalisation_residual(param), L_c, np.float32(1))
+            res_c.mul_(float(multigrid.normalisation_residual(param))).add_(L_c)  # 4 res + L (multigrid.py:549)
             del L_c
             if nlevel >= (param["ncoarse"] - 3):
                 self.fr_smoothing(x_corr_c, b_c, param["Npre"], param, res_c)
             else:
                 self.V_cycle_FAS(x_corr_c, b_c, param, nlevel + 1, res_c)
-            utils.add_vector_scalar_inplace(x_corr_c, x_c, np.float32(-1))
+            x_corr_c.sub_(x_c)
             self.add_prolongation(x, x_corr_c)
         else:  # small coarse problem: every rank runs the rest of the cycle on all of it
-            x_full, b_full, res_full = self.gather_full(x_c), self.gather_full(b_c), self.gather_full(res_c)
-            x_corr_full = x_full.clone()
-            L_full = multigrid.operator(x_full, param, b_full)
-            utils.linear_operator_vectors_inplace(res_full, multigrid.normalisation_residual(param), L_full, np.float32(1))
-            del L_full
-            if nlevel >= (param["ncoarse"] - 3):
-                multigrid.smoothing(x_corr_full, b_full, param["Npre"], param, res_full)
-            else:
-                multigrid.V_cycle_FAS(x_corr_full, b_full, param, nlevel + 1, res_full)
-            utils.add_vector_scalar_inplace(x_corr_full, x_full, np.float32(-1))
-            x_corr_c = self._take_planes(x_corr_full, n_c, n_c // self.world)
-            self._ctx(n).call("pm_prolongation_slab", L.ptr(x), L.ptr(x_corr_c), n_c, x_corr_c.shape[0] - 2, 1)
-            del x_full, b_full, res_full, x_corr_full
+            corr_full = self.k.coarse_fas(self.gather_full(x_c), self.gather_full(b_c), self.gather_full(res_c), param,
+                                          nlevel)
+            x_corr_c = self._take_planes(corr_full, n_c, n_c // self.world)
+            self.k.prolongation_add(x, x_corr_c)
+            del corr_full
         del res_c, b_c, x_c, x_corr_c
         self.fr_smoothing(x, b, param["Npost"], param, rhs)
 
@@ -310,11 +365,8 @@ class SlabMultigrid:
 
     def fr_initialise_potential(self, b, param):
         """cubic / quartic initialise_potential (cubic.py:217, quartic.py:214): per cell, whole level array."""
-        n = b.shape[1]
         n_fr, q = self._fr(param)
         out = self.torch.empty_like(b)
-        # the single-GPU kernel is element-wise over count = n^3 cells with h = 1/n: run it plane by plane range
-        name = "pm_cubic_initialise_potential" if n_fr == 1 else "pm_quartic_initialise_potential"
-        self._ctx(n).call(name + "_flat", L.ptr(b), q, n, b.numel(), L.ptr(out))
+        self.k.fr_initialise_potential(n_fr, b, q, out)
         return out
 
