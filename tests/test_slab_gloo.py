@@ -121,6 +121,26 @@ def test_four_rank_slab_step(tmp_path):
     check_against_reference(ranks, reference_run(n, steps), n, world)
 
 
+@pytest.mark.parametrize("theory", ["newton_mg", "mond", "mond_fft7pt", "fr"])
+def test_two_rank_grid_solvers_cpu(tmp_path, theory):
+    """The halo-exchange multigrid / FAS / QUMOND orchestration of slab_multigrid.py on the CPU: 2 gloo ranks
+    with the test-only level-kernel provider (tests/slab_oracle_ops.py: oracle functions on embedded grids)
+    against the single-process oracle, at the solvers' own accuracy."""
+    n, steps, world = 32, 1, 2
+    ranks = run_ranks(world, tmp_path, "oracle", n, steps, theory=theory)
+    ref = reference_run(n, steps, theory=theory)
+    ids0 = np.concatenate([r["id0"] for r in ranks])
+    acc0 = np.concatenate([r["acc0"] for r in ranks])
+    np.testing.assert_allclose(acc0, ref["acc0"][ids0], rtol=0, atol=2e-3 * np.abs(ref["acc0"]).max())
+    phi0 = np.concatenate([r["phi0"] for r in ranks], axis=0)
+    assert phi0.shape == (n, n, n) and ranks[0]["phi0"].shape[0] == n // world   # decomposed, not replicated
+    np.testing.assert_allclose(phi0, ref["phi0"], rtol=0, atol=5e-4 * np.abs(ref["phi0"]).max())
+    ids = np.concatenate([r["id"] for r in ranks])
+    assert sorted(ids.tolist()) == list(range(n**3))
+    d = np.abs(np.concatenate([r["pos"] for r in ranks]) - ref["pos"][ids])
+    assert np.minimum(d, 1 - d).max() < 1e-4
+
+
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_hip(tmp_path):
     """Rehearsal of the multi-GPU path on the 1-GPU box: 2 ranks share cuda:0, gloo stages the
