@@ -232,3 +232,32 @@ def test_pm_theory_errors(amd, golden):
     p = dict(param_from_json(gf["param0_json"]), fR_n=3)
     with pytest.raises(NotImplementedError):
         amd.solver.pm(gf["pos"], p, tables=synth_tables())
+
+
+def test_multigrid_solves_the_7pt_problem_at_scale(amd):
+    """256^3, beyond the oracle: the multigrid solver and the FFT with the 7-point Green's function solve the same
+    discrete Poisson problem (laplacian.operator is the 7-point stencil), so their potentials must agree to the
+    multigrid's stopping tolerance, and applying the operator to either must give back the zero-mean source."""
+    from tests.helpers import zeldovich_particles
+
+    t = amd.torch
+    n = 256
+    pos_h, _ = zeldovich_particles(n, seed=8, rms_cells=1.0)
+    pos = t.from_numpy(pos_h).cuda()
+    base = {"theory": "newton", "mass_scheme": "TSC", "npart": n**3, "ncoarse": 8, "Om_m": 0.25733, "aexp": 0.5,
+            "gradient_stencil_order": 5, "save_power_spectrum": "no", "nthreads": 1, "Npre": 2, "Npost": 1,
+            "epsrel": 1e-3, "nsteps": 0}
+    acc_f, phi_f, _ = amd.solver.pm(pos, dict(base, linear_newton_solver="fft_7pt"))
+    acc_m, phi_m, _ = amd.solver.pm(pos, dict(base, linear_newton_solver="multigrid"))
+    phi_m = phi_m - phi_m.mean()          # the multigrid solution carries an arbitrary constant
+    phi_f = phi_f - phi_f.mean()
+    scale = float(phi_f.abs().max())
+    assert float((phi_m - phi_f).abs().max()) < 2e-3 * scale
+    assert float((acc_m - acc_f).abs().max()) < 2e-2 * float(acc_f.abs().max())
+    # L(phi_fft7) reproduces the source f1 (rho - 1) to fp32 round-off of the transform
+    rho = amd.mesh.TSC(pos, n)
+    f1 = np.float32(1.5 * base["aexp"] * base["Om_m"])
+    src = f1 * (rho - 1.0)
+    lap = amd.laplacian.operator(phi_f)
+    assert float((lap - src).abs().max()) < 2e-3 * float(src.abs().max())
+

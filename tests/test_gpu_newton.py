@@ -672,3 +672,36 @@ def test_run_nbody_loop_vs_oracle(amd):
     d = np.abs(out[0].cpu().numpy() - p)
     assert np.minimum(d, 1 - d).max() < 2e-5
 
+
+def test_tile_window_restricts_workgroups_not_results(amd):
+    """pm_set_tile_window (slabs: only the tiles of the rank's planes get a workgroup): particles confined to the
+    window give the same density and accelerations with and without it; straggler lists included."""
+    from pysco_amd import _lib as L
+
+    n = 64
+    t = amd.torch
+    rng = np.random.default_rng(31)
+    pos, _ = zeldovich_particles(n, seed=6, rms_cells=0.7)
+    x_lo, nx = 16, 32
+    inside = (np.floor(pos[:, 0] * n).astype(np.int64) >= x_lo) & (np.floor(pos[:, 0] * n).astype(np.int64) < x_lo + nx)
+    pos = amd.utils.reorder_particles(np.ascontiguousarray(pos[inside]))
+    pos[:, 1:] = np.mod(pos[:, 1:] + (0.4 / n) * rng.normal(size=(len(pos), 2)), 1.0).astype(np.float32)  # stragglers in y, z
+    pos[pos >= 1.0] = 0.0
+    phi = rng.normal(size=(n, n, n)).astype(np.float32)
+    pd, phid = t.from_numpy(pos).cuda(), t.from_numpy(phi).cuda()
+    ctx = L.context(n)
+    out = {}
+    for window in (False, True):
+        ctx.call("pm_set_tile_window", x_lo if window else 0, nx if window else n)
+        try:
+            ctx.call("pm_tile_lists", L.ptr(pd), len(pos))
+            rho = amd.mesh.TSC(pd, n)
+            acc = amd.mesh.derivative_interp_vec_kick("tsc", phid, 5, pd)
+            ctx.call("pm_tile_lists", None, 0)
+        finally:
+            ctx.call("pm_set_tile_window", 0, n)
+        out[window] = (rho.cpu().numpy(), acc.cpu().numpy())
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=0, atol=4e-6 * _scale(out[False][0]))
+    np.testing.assert_array_equal(out[True][1], out[False][1])
+    np.testing.assert_array_equal(out[True][1], orc.invTSC_vec(orc.derivative(phi, 5), pos))
+
