@@ -85,8 +85,46 @@ __global__ __launch_bounds__(BLK) void prolongation_kernel(float *__restrict__ y
     }
 }
 
+// four fine k-cells per thread (nc >= 8): the four coarse rows are read as one aligned float2 + two scalars each,
+// the fine row is one float4 read-modify-write; same expression per fine cell
+__global__ __launch_bounds__(BLK) void prolongation_rows_kernel(float *__restrict__ y, const float *__restrict__ xc,
+                                                                int log2nc, int add, XRange xf, XRange xcr) {
+    const int log2nf = log2nc + 1, nf = 1 << log2nf, nc = 1 << log2nc, mc = nc - 1, lq = log2nf - 2;
+    const float f0 = (float)(27.0 / 64), f1 = (float)(9.0 / 64), f2 = (float)(3.0 / 64), f3 = (float)(1.0 / 64);
+    const int64_t total = ((int64_t)xf.ni << log2nf) << lq;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int q = (int)(t & ((1 << lq) - 1)), jf = (int)((t >> lq) & (nf - 1)), fi = (int)(t >> (lq + log2nf));
+        const int i = xcr.i0 + (fi >> 1), j = jf >> 1;
+        const int ia = (i + ((fi & 1) ? 1 : -1)) & xcr.xmask, jb = (j + ((jf & 1) ? 1 : -1)) & mc;
+        auto ld = [&](int a, int bb, float *d) {  // d[0..3] = xc[a][bb][2q-1 .. 2q+2]
+            const float *r = xc + ((((int64_t)a << log2nc) + bb) << log2nc);
+            const float2 v = *reinterpret_cast<const float2 *>(r + 2 * q);
+            d[0] = r[(2 * q - 1) & mc], d[1] = v.x, d[2] = v.y, d[3] = r[(2 * q + 2) & mc];
+        };
+        float c00[4], cX[4], cY[4], cXY[4];
+        ld(i, j, c00), ld(ia, j, cX), ld(i, jb, cY), ld(ia, jb, cXY);
+        float *dst = y + cidx(xf.i0 + fi, jf, 4 * q, log2nf);
+        float4 o = add ? *reinterpret_cast<const float4 *>(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+            const int k = 1 + (c2 >> 1), kd = k + ((c2 & 1) ? 1 : -1);  // indices into the d[] arrays
+            const float tmp0 = f0 * c00[k];
+            const float v = tmp0 + f1 * (cX[k] + cY[k] + c00[kd]) + f2 * (cXY[k] + cX[kd] + cY[kd]) + f3 * cXY[kd];
+            ov[c2] = add ? ov[c2] + v : v;
+        }
+        *reinterpret_cast<float4 *>(dst) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+}
+
 static int prolongation_launch(pm_ctx *c, float *d_y, const float *d_xc, int nc, int add, XRange xf, XRange xcr) {
     const int64_t total = (int64_t)xf.ni * (2 * nc) * (2 * nc);
+    if (nc >= 8 && pm_aligned16(d_y) && pm_aligned16(d_xc)) {
+        hipLaunchKernelGGL(prolongation_rows_kernel, dim3(pm_stream_blocks(total / 4, BLK)), dim3(BLK), 0, c->stream, d_y,
+                           d_xc, ilog2(nc), add, xf, xcr);
+        PM_LAUNCH_CHECK();
+        return PM_OK;
+    }
     hipLaunchKernelGGL(prolongation_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_y, d_xc,
                        ilog2(nc), add, xf, xcr);
     PM_LAUNCH_CHECK();
@@ -174,9 +212,61 @@ __global__ __launch_bounds__(BLK) void lap_restrict_residual_kernel(const float 
 #undef B
 }
 
+// The same with 16-byte accesses (n >= 16): a thread computes two adjacent coarse cells (four fine k) from twelve
+// float4 of x (+ eight halo scalars) and four of b, instead of 40 scalar loads per coarse cell.  Same expression.
+__global__ __launch_bounds__(BLK) void lap_restrict_residual_rows_kernel(const float *__restrict__ x,
+                                                                         const float *__restrict__ b, int log2n,
+                                                                         float invh2, float *__restrict__ out, XRange xf,
+                                                                         XRange xc) {
+    const int n = 1 << log2n, m = n - 1, log2nc = log2n - 1, nc = n >> 1, lq = log2nc - 1;
+    const int64_t total = ((int64_t)xc.ni << log2nc) << lq;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int q = (int)(t & ((1 << lq) - 1)), j = (int)((t >> lq) & (nc - 1)), i = (int)(t >> (lq + log2nc));
+        const int ii = xf.i0 + 2 * i, jj = 2 * j, k0 = 4 * q;
+        auto row = [&](const float *g, int a, int bb) -> const float * {
+            return g + ((((int64_t)(a & xf.xmask) << log2n) + (bb & m)) << log2n);
+        };
+        auto ld4 = [&](const float *r, float *d) {  // d[1..4] = r[k0 .. k0+3]
+            const float4 v = *reinterpret_cast<const float4 *>(r + k0);
+            d[1] = v.x, d[2] = v.y, d[3] = v.z, d[4] = v.w;
+        };
+        auto ld6 = [&](const float *r, float *d) {  // d[0..5] = r[k0-1 .. k0+4]
+            ld4(r, d);
+            d[0] = r[(k0 - 1) & m], d[5] = r[(k0 + 4) & m];
+        };
+        float A[2][6], I[4][6], P[4][6], Q[2][6], Bi[2][6], Bp[2][6];
+        ld4(row(x, ii - 1, jj), A[0]), ld4(row(x, ii - 1, jj + 1), A[1]);
+        ld4(row(x, ii, jj - 1), I[0]), ld6(row(x, ii, jj), I[1]), ld6(row(x, ii, jj + 1), I[2]), ld4(row(x, ii, jj + 2), I[3]);
+        ld4(row(x, ii + 1, jj - 1), P[0]), ld6(row(x, ii + 1, jj), P[1]), ld6(row(x, ii + 1, jj + 1), P[2]);
+        ld4(row(x, ii + 1, jj + 2), P[3]);
+        ld4(row(x, ii + 2, jj), Q[0]), ld4(row(x, ii + 2, jj + 1), Q[1]);
+        ld4(row(b, ii, jj), Bi[0]), ld4(row(b, ii, jj + 1), Bi[1]), ld4(row(b, ii + 1, jj), Bp[0]);
+        ld4(row(b, ii + 1, jj + 1), Bp[1]);
+        float r2[2];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int kk = 1 + 2 * c2, kp1 = kk + 1, km1 = kk - 1, kp2 = kk + 2;  // indices into the d[] arrays
+            const float s = +A[0][kk] + A[0][kp1] + A[1][kk] + A[1][kp1] + I[0][kk] + I[0][kp1] + I[1][km1] + I[1][kp2] +
+                            I[2][km1] + I[2][kp2] + I[3][kk] + I[3][kp1] + P[0][kk] + P[0][kp1] + P[1][km1] + P[1][kp2] +
+                            P[2][km1] + P[2][kp2] + P[3][kk] + P[3][kp1] + Q[0][kk] + Q[0][kp1] + Q[1][kk] + Q[1][kp1] -
+                            3.0f * (I[1][kk] + I[1][kp1] + I[2][kk] + I[2][kp1] + P[1][kk] + P[1][kp1] + P[2][kk] +
+                                    P[2][kp1]);
+            r2[c2] = 0.125f * (-(s)*invh2 + Bi[0][kk] + Bi[0][kp1] + Bi[1][kk] + Bi[1][kp1] + Bp[0][kk] + Bp[0][kp1] +
+                               Bp[1][kk] + Bp[1][kp1]);
+        }
+        *reinterpret_cast<float2 *>(out + cidx(xc.i0 + i, j, 2 * q, log2nc)) = make_float2(r2[0], r2[1]);
+    }
+}
+
 static int lap_restrict_residual_launch(pm_ctx *c, const float *d_x, const float *d_b, int n, float *d_out, XRange xf,
                                         XRange xc) {
     const int64_t total = (int64_t)xc.ni * (n / 2) * (n / 2);
+    if (n >= 16 && pm_aligned16(d_x) && pm_aligned16(d_b) && pm_aligned16(d_out)) {
+        hipLaunchKernelGGL(lap_restrict_residual_rows_kernel, dim3(pm_stream_blocks(total / 2, BLK)), dim3(BLK), 0,
+                           c->stream, d_x, d_b, ilog2(n), (float)((double)n * n), d_out, xf, xc);
+        PM_LAUNCH_CHECK();
+        return PM_OK;
+    }
     hipLaunchKernelGGL(lap_restrict_residual_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_x,
                        d_b, ilog2(n), (float)((double)n * n), d_out, xf, xc);
     PM_LAUNCH_CHECK();
@@ -235,12 +325,48 @@ __global__ __launch_bounds__(BLK) void lap_residual_error_kernel(const float *__
     block_sum_to(acc, result);
 }
 
+// four k-cells per thread with 16-byte accesses (n >= 16); same expression per cell
+__global__ __launch_bounds__(BLK) void lap_residual_error_rows_kernel(const float *__restrict__ x,
+                                                                      const float *__restrict__ b, int log2n, float invh2,
+                                                                      double *__restrict__ result, XRange xr) {
+    const int n = 1 << log2n, m = n - 1, lq = log2n - 2;
+    const int64_t total = ((int64_t)xr.ni << log2n) << lq;
+    double acc = 0;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k0 = (int)(t & ((1 << lq) - 1)) << 2, j = (int)((t >> lq) & m), i = xr.i0 + (int)(t >> (lq + log2n));
+        auto row = [&](const float *g, int a, int bb) -> const float * {
+            return g + ((((int64_t)(a & xr.xmask) << log2n) + (bb & m)) << log2n);
+        };
+        const float *mine = row(x, i, j);
+        const float4 c4 = *reinterpret_cast<const float4 *>(mine + k0);
+        const float4 xm = *reinterpret_cast<const float4 *>(row(x, i - 1, j) + k0);
+        const float4 xp = *reinterpret_cast<const float4 *>(row(x, i + 1, j) + k0);
+        const float4 ym = *reinterpret_cast<const float4 *>(row(x, i, j - 1) + k0);
+        const float4 yp = *reinterpret_cast<const float4 *>(row(x, i, j + 1) + k0);
+        const float4 b4 = *reinterpret_cast<const float4 *>(row(b, i, j) + k0);
+        const float v[6] = {mine[(k0 - 1) & m], c4.x, c4.y, c4.z, c4.w, mine[(k0 + 4) & m]};
+        const float axm[4] = {xm.x, xm.y, xm.z, xm.w}, axp[4] = {xp.x, xp.y, xp.z, xp.w}, aym[4] = {ym.x, ym.y, ym.z, ym.w},
+                    ayp[4] = {yp.x, yp.y, yp.z, yp.w}, ab[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+            const float s = +axm[c2] + v[c2] + v[c2 + 2] + aym[c2] - 6.0f * v[c2 + 1] + ayp[c2] + axp[c2];
+            const float r = -(s)*invh2 + ab[c2];
+            acc += (double)(r * r);
+        }
+    }
+    block_sum_to(acc, result);
+}
+
 static int lap_residual_sumsq(pm_ctx *c, const float *d_x, const float *d_b, int n, XRange xr, double *h_sum) {
     PM_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(double), c->stream));
     const int64_t total = (int64_t)xr.ni * n * n;
     int blocks = pm_stream_blocks(total, BLK * 4);
-    hipLaunchKernelGGL(lap_residual_error_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n),
-                       (float)((double)n * n), c->d_hist, xr);
+    if (n >= 16 && pm_aligned16(d_x) && pm_aligned16(d_b))
+        hipLaunchKernelGGL(lap_residual_error_rows_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n),
+                           (float)((double)n * n), c->d_hist, xr);
+    else
+        hipLaunchKernelGGL(lap_residual_error_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n),
+                           (float)((double)n * n), c->d_hist, xr);
     PM_LAUNCH_CHECK();
     PM_HIP(hipMemcpyAsync(h_sum, c->d_hist, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PM_HIP(hipStreamSynchronize(c->stream));
