@@ -611,14 +611,17 @@ __device__ __forceinline__ double cubic_root(float pf, float d1f) {
     if (d > 0.0) {
         d = d1 + sqrt(d);
         if (d == 0.0) return -inv3 * pow(d1, inv3);
-        const double C = pow(0.5 * d, inv3);
+        // x^(1/3) of a positive x is cbrt (a third of pow's cost); a negative x keeps pow and its NaN, as the reference
+        const double hd = 0.5 * d;
+        const double C = hd > 0.0 ? cbrt(hd) : pow(hd, inv3);
         return -inv3 * (C - 3.0 * p / C);
     } else if (d < 0.0) {
-        const double d0 = -3.0 * p;
-        d = d1 / (2.0 * pow(d0, 1.5));
+        const double d0 = -3.0 * p;  // > 0 here (d < 0 needs p < 0)
+        const double sd0 = sqrt(d0);
+        d = d1 / (2.0 * (d0 * sd0));  // d0^1.5 without pow
         if (fabs(d) < 1.0) {
             const double theta = acos(d);
-            return (double)(float)(-2.0 * inv3 * sqrt(d0) * cos(inv3 * (theta + 2.0 * 3.14159265358979323846)));
+            return (double)(float)(-2.0 * inv3 * sd0 * cos(inv3 * (theta + 2.0 * 3.14159265358979323846)));
         }
         return -inv3 * pow(d1, inv3);
     }
