@@ -103,7 +103,17 @@ constexpr int PM_TI = 8, PM_TJ = 16, PM_TK = 16;      // tile extent in cells
 constexpr int PM_LI = 3, PM_LJ = 4, PM_LK = 4;        // log2 of the above
 constexpr int PM_HI = PM_TI + 2, PM_HJ = PM_TJ + 2, PM_HK = PM_TK + 2;
 constexpr int PM_TILE = PM_HI * PM_HJ * PM_HK;        // 3240 cells
-constexpr int PM_FSTRIDE = 3264;                      // floats per component plane of the LDS force tile (51 * 64)
+constexpr int PM_FSTRIDE = 3264;                      // cells per plane of the LDS force tile (51 * 64)
+// LDS force tile: an (x, y) plane of float2 per cell, then a z plane.  The gather reads a cell's (x, y) with
+// one ds_read_b64 straight into the register pair of a packed multiply/add (v_pk_mul_f32, v_pk_add_f32);
+// with three separate component planes the compiler paid a v_mov per operand to build those pairs.
+constexpr int PM_FZ = 2 * PM_FSTRIDE;                 // float offset of the z plane
+typedef float pm_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int force_tile_index(int c, int m) { return m < 2 ? 2 * c + m : PM_FZ + c; }
+__device__ __forceinline__ void force_tile_put(float *tile, int c, float gx, float gy, float gz) {
+    *reinterpret_cast<pm_v2f *>(tile + 2 * c) = pm_v2f{gx, gy};
+    tile[PM_FZ + c] = gz;
+}
 constexpr int PM_PPT = 8;                             // particles per thread
 constexpr int PM_CHUNK = BLK * PM_PPT;                // particles per workgroup
 constexpr int PM_MAX_PASSES = 6;
@@ -359,21 +369,22 @@ template <int SCHEME>
 __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, int j, int k, const TileId &t,
                                            const float *tile, float acc[3]) {
     const int li = i - t.ti * PM_TI + 1, lj = j - t.tj * PM_TJ + 1, lk = k - t.tk * PM_TK + 1;
-    // component planes (SoA): a wave's 64 cells of one ds_read_b32 spread over the 64 banks, where the
-    // float4-per-cell layout put 16 lanes on 16 four-bank slots (2-way conflicts for a Morton block)
-    struct F3 {
-        float x, y, z;
-    };
-    auto at = [&](int a, int b, int c) -> F3 {
-        const float *g = tile + ((li + a) * PM_HJ + (lj + b)) * PM_HK + (lk + c);
-        return F3{g[0], g[PM_FSTRIDE], g[2 * PM_FSTRIDE]};
-    };
+    const int c0 = (li * PM_HJ + lj) * PM_HK + lk;
+    const pm_v2f *txy = reinterpret_cast<const pm_v2f *>(tile);
+    const float *tz = tile + PM_FZ;
     // The running sums start from +0 (0 + w*g == w*g exactly) and add the terms in the reference's
-    // left-to-right order (mesh.py:3058-3086).
-    acc[0] = acc[1] = acc[2] = 0.f;
+    // left-to-right order (mesh.py:3058-3086); x and y ride in one packed register pair, which
+    // rounds each lane exactly like the scalar multiply and add.
+    pm_v2f axy = {0.f, 0.f};
+    float az = 0.f;
+    auto add = [&](int off, float w) {
+        const pm_v2f g = txy[c0 + off];
+        const float gz = tz[c0 + off];
+        axy = axy + pm_v2f{w, w} * g;
+        az = az + w * gz;
+    };
     if (SCHEME == PM_NGP) {
-        const F3 g = at(0, 0, 0);
-        acc[0] = g.x, acc[1] = g.y, acc[2] = g.z;
+        axy = txy[c0], az = tz[c0];
     } else if (SCHEME == PM_CIC) {
         float wx[2], wy[2], wz[2];
         int sx, sy, sz;
@@ -385,20 +396,14 @@ __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, 
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const float w = wx[a] * wy[b] * wz[c];
-                    const F3 g = at(a * sx, b * sy, c * sz);
-                    acc[0] = acc[0] + w * g.x;
-                    acc[1] = acc[1] + w * g.y;
-                    acc[2] = acc[2] + w * g.z;
-                }
+                for (int c = 0; c < 2; ++c) add((a * sx * PM_HJ + b * sy) * PM_HK + c * sz, wx[a] * wy[b] * wz[c]);
     } else {
         float wx[3], wy[3], wz[3];
         tsc_weights(xp, i, wx);
         tsc_weights(yp, j, wy);
         tsc_weights(zp, k, wz);
-        // the x-plane loop stays rolled: nine 16-byte LDS reads in flight instead of 27 keeps the
-        // kernel under 128 VGPRs (3 workgroups per CU)
+        // the x-plane loop stays rolled: nine cells in flight instead of 27 keeps the kernel under
+        // 128 VGPRs; inside one plane every offset is an instruction immediate
 #pragma unroll 1
         for (int a = 0; a < 3; ++a) {
             const float wxa = a == 0 ? wx[0] : (a == 1 ? wx[1] : wx[2]);
@@ -406,25 +411,27 @@ __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, 
             for (int b = 0; b < 3; ++b) {
                 const float wxy = wxa * wy[b];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float w = wxy * wz[c];
-                    const F3 g = at(a - 1, b - 1, c - 1);
-                    acc[0] = acc[0] + w * g.x;
-                    acc[1] = acc[1] + w * g.y;
-                    acc[2] = acc[2] + w * g.z;
-                }
+                for (int c = 0; c < 3; ++c) add(((a - 1) * PM_HJ + (b - 1)) * PM_HK + (c - 1), wxy * wz[c]);
             }
         }
     }
+    acc[0] = axy.x, acc[1] = axy.y, acc[2] = az;
 }
 
 // Same sum straight from global memory: the path of particles that are not inside the staged tile
 // (unsorted or drifted streams).  Deliberately compact (rolled loops, not inlined): it is the rare
 // path and must not set the register budget of the kernels that call it.
+// The sums come back by value (three VGPRs): handed a pointer, the callers' accumulators lived in scratch,
+// and the scratch reload's vmcnt(0) drained the particle prefetch queues once per particle.
+struct Acc3 {
+    float x, y, z;
+};
+
 template <int SCHEME>
-__device__ __noinline__ void gather_global(const float *__restrict__ grid, float xp, float yp, float zp, int i, int j,
-                                           int k, pm_geom geo, float acc[3]) {
+__device__ __noinline__ Acc3 gather_global(const float *__restrict__ grid, float xp, float yp, float zp, int i, int j,
+                                           int k, pm_geom geo) {
     auto at = [&](int ii, int jj, int kk) -> const float * { return grid + 3 * pm_cell(geo, ii, jj, kk); };
+    float acc[3];
     acc[0] = acc[1] = acc[2] = 0.f;
     if (SCHEME == PM_NGP) {
         const float *g = at(i, j, k);
@@ -467,6 +474,7 @@ __device__ __noinline__ void gather_global(const float *__restrict__ grid, float
             }
         }
     }
+    return Acc3{acc[0], acc[1], acc[2]};
 }
 
 template <int SCHEME, bool KICK>
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(BLK) void interp_tiled_kernel(const float *__restri
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int c = q * BLK + tid;
-                if (c < PM_TILE) tile[c] = gx[q], tile[PM_FSTRIDE + c] = gy[q], tile[2 * PM_FSTRIDE + c] = gz[q];
+                if (c < PM_TILE) force_tile_put(tile, c, gx[q], gy[q], gz[q]);
             }
         }
         __syncthreads();
@@ -546,8 +554,8 @@ __global__ __launch_bounds__(BLK) void interp_tiled_kernel(const float *__restri
             const int64_t p = base + r * BLK + tid;
             const float xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
             const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
-            float a[3];
-            gather_global<SCHEME>(grid, xp, yp, zp, i, j, k, geo, a);
+            const Acc3 r = gather_global<SCHEME>(grid, xp, yp, zp, i, j, k, geo);
+            const float a[3] = {r.x, r.y, r.z};
             finish(p, a);
         }
     // workgroup max -> two global atomics
@@ -1344,9 +1352,10 @@ struct PhiFetch {
 };
 
 template <int SCHEME, int ORDER>
-__device__ __noinline__ void gather_phi_global(const float *__restrict__ phi, float scale, float xp, float yp, float zp,
-                                               int i, int j, int k, pm_geom geo, float acc[3]) {
+__device__ __noinline__ Acc3 gather_phi_global(const float *__restrict__ phi, float scale, float xp, float yp, float zp,
+                                               int i, int j, int k, pm_geom geo) {
     PhiFetch<ORDER> fetch{phi, geo, scale};
+    float acc[3];
     acc[0] = acc[1] = acc[2] = 0.f;
     float g[3];
     if (SCHEME == PM_NGP) {
@@ -1383,6 +1392,7 @@ __device__ __noinline__ void gather_phi_global(const float *__restrict__ phi, fl
             for (int m = 0; m < 3; ++m) acc[m] = acc[m] + w * g[m];
         }
     }
+    return Acc3{acc[0], acc[1], acc[2]};
 }
 
 // One workgroup per tile: gather + second kick + CFL maxima.  ORDER == 0: `src` is the [.,n,n,3] force
@@ -1462,7 +1472,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
             const int f = u * BLK + tid;
             if (f < NF) {
                 const int c = f / 3, m = f - 3 * c;
-                tile[m * PM_FSTRIDE + c] = g[u];
+                tile[force_tile_index(c, m)] = g[u];
             }
         }
     } else {
@@ -1508,7 +1518,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
             const int c = u * BLK + tid;
-            if (c < PM_TILE) tile[c] = gx[u], tile[PM_FSTRIDE + c] = gy[u], tile[2 * PM_FSTRIDE + c] = gz[u];
+            if (c < PM_TILE) force_tile_put(tile, c, gx[u], gy[u], gz[u]);
         }
     }
     __syncthreads();
@@ -1528,10 +1538,12 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
             gather_lds<SCHEME>(xp, yp, zp, skip ? t.ti * PM_TI : i, skip ? t.tj * PM_TJ : j, skip ? t.tk * PM_TK : k, t,
                                tile, a);
         } else {  // no lists prepared (or positions changed behind them): the slow path, still correct
+            Acc3 r;
             if constexpr (ORDER == 0)
-                gather_global<SCHEME>(src, xp, yp, zp, i, j, k, geo, a);
+                r = gather_global<SCHEME>(src, xp, yp, zp, i, j, k, geo);
             else
-                gather_phi_global<SCHEME, ORDER>(src, scale, xp, yp, zp, i, j, k, geo, a);
+                r = gather_phi_global<SCHEME, ORDER>(src, scale, xp, yp, zp, i, j, k, geo);
+            a[0] = r.x, a[1] = r.y, a[2] = r.z;
         }
         if (!skip) {
 #pragma unroll
