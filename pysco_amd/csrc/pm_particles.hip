@@ -369,7 +369,8 @@ template <int SCHEME>
 __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, int j, int k, const TileId &t,
                                            const float *tile, float acc[3]) {
     const int li = i - t.ti * PM_TI + 1, lj = j - t.tj * PM_TJ + 1, lk = k - t.tk * PM_TK + 1;
-    const int c0 = (li * PM_HJ + lj) * PM_HK + lk;
+    // 24-bit multiplies: full rate, where v_mul_lo_u32 is quarter rate (li, lj, lk are small and >= 0)
+    const int c0 = (int)__umul24(__umul24((unsigned)li, PM_HJ) + (unsigned)lj, PM_HK) + lk;
     const pm_v2f *txy = reinterpret_cast<const pm_v2f *>(tile);
     const float *tz = tile + PM_FZ;
     // The running sums start from +0 (0 + w*g == w*g exactly) and add the terms in the reference's
@@ -999,50 +1000,41 @@ static int tile_work_for(pm_ctx *c, const float *pos, int64_t np, TileWork *work
     return tile_ranges(c, pos, np, work, blocks);
 }
 
-// Rolling depth-4 prefetch of the positions a thread will process (p, p+BLK, p+2BLK, ...): the
+// Rolling depth-4 prefetch of the positions a thread will process (r, r+BLK, r+2BLK, ... of its range): the
 // particle loop stays rolled (register budget) while four loads per lane are always in flight.
+// Indices are 32-bit and relative to the range's first particle (a workgroup's range is at most
+// PM_RANGE_CHUNK long): the range base stays in SGPRs and a lane's address is one 32-bit multiply, where
+// absolute 64-bit indices cost a quarter-rate v_mad_u64_u32 chain per load.
 struct PosQueue {
     float x[4], y[4], z[4];
-    const float *pos;
-    int64_t last;
-    __device__ __forceinline__ void load(int slot, int64_t p) {
-        p = p < last ? p : last;  // clamp: harmless reload of the range's last particle
-        x[slot] = pos[3 * p], y[slot] = pos[3 * p + 1], z[slot] = pos[3 * p + 2];
+    const float *base;
+    unsigned last;
+    __device__ __forceinline__ void load(int slot, unsigned r) {
+        r = min(r, last);  // clamp: harmless reload of the range's last particle
+        const float *pp = base + 3u * r;
+        x[slot] = pp[0], y[slot] = pp[1], z[slot] = pp[2];
     }
-    __device__ __forceinline__ void prime(const float *pos_, int64_t p0, int64_t end) {
-        pos = pos_, last = end - 1;
-        load(0, p0), load(1, p0 + BLK), load(2, p0 + 2 * BLK), load(3, p0 + 3 * BLK);
+    __device__ __forceinline__ void prime(const float *range_base, unsigned r0, unsigned count) {
+        base = range_base, last = count - 1u;
+        load(0, r0), load(1, r0 + BLK), load(2, r0 + 2 * BLK), load(3, r0 + 3 * BLK);
     }
-    __device__ __forceinline__ void pop(int64_t p, float &px, float &py, float &pz) {  // p = particle being popped
+    __device__ __forceinline__ void pop(unsigned r, float &px, float &py, float &pz) {  // r = particle being popped
         px = x[0], py = y[0], pz = z[0];
         x[0] = x[1], y[0] = y[1], z[0] = z[1];
         x[1] = x[2], y[1] = y[2], z[1] = z[2];
         x[2] = x[3], y[2] = y[3], z[2] = z[3];
-        load(3, p + 4 * BLK);
+        load(3, r + 4 * BLK);
     }
 };
 
 // the same for the velocities the fused kick updates (loaded at the top of an iteration they would be
 // waited for at its end, one memory latency per particle; four iterations ahead they are simply there)
 struct VelQueue {
-    float x[4], y[4], z[4];
-    const float *vel;
-    int64_t last;
-    __device__ __forceinline__ void load(int slot, int64_t p) {
-        p = p < last ? p : last;
-        x[slot] = vel[3 * p], y[slot] = vel[3 * p + 1], z[slot] = vel[3 * p + 2];
+    PosQueue q;
+    __device__ __forceinline__ void prime(const float *range_base, unsigned r0, unsigned count) {
+        q.prime(range_base, r0, count);
     }
-    __device__ __forceinline__ void prime(const float *vel_, int64_t p0, int64_t end) {
-        vel = vel_, last = end - 1;
-        load(0, p0), load(1, p0 + BLK), load(2, p0 + 2 * BLK), load(3, p0 + 3 * BLK);
-    }
-    __device__ __forceinline__ void pop(int64_t p, float v[3]) {
-        v[0] = x[0], v[1] = y[0], v[2] = z[0];
-        x[0] = x[1], y[0] = y[1], z[0] = z[1];
-        x[1] = x[2], y[1] = y[2], z[1] = z[2];
-        x[2] = x[3], y[2] = y[3], z[2] = z[3];
-        load(3, p + 4 * BLK);
-    }
+    __device__ __forceinline__ void pop(unsigned r, float v[3]) { q.pop(r, v[0], v[1], v[2]); }
 };
 
 template <int SCHEME>
@@ -1060,14 +1052,15 @@ __global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__rest
     const float nf = (float)n;
     const TileId t = tile_of_key(key);
     PosQueue q;
-    if (has_range) q.prime(pos, s + tid, e);
+    const unsigned cnt = has_range ? (unsigned)(e - s) : 0u;
+    if (has_range) q.prime(pos + 3 * s, tid, cnt);
     for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0;
     __syncthreads();
     if (has_range) {
 #pragma unroll 1
-        for (int64_t p = s + tid; p < e; p += BLK) {
+        for (unsigned r = tid; r < cnt; r += BLK) {
             float x, y, z;
-            q.pop(p, x, y, z);
+            q.pop(r, x, y, z);
             const float xp = x * nf, yp = y * nf, zp = z * nf;
             const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
             if (in_tile(i, j, k, t)) {
@@ -1449,8 +1442,8 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     PosQueue q;
     VelQueue qv;
     if (ORDER == 0 && has_range) {
-        q.prime(pos, s + tid, e);
-        if (KICK) qv.prime(vel, s + tid, e);
+        q.prime(pos + 3 * s, tid, (unsigned)(e - s));
+        if (KICK) qv.prime(vel + 3 * s, tid, (unsigned)(e - s));
     }
     if constexpr (ORDER == 0) {
         // tile fill, float-granular: consecutive lanes read consecutive floats of a tile row (18 cells x 3
@@ -1511,8 +1504,8 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         // the particle queues are primed only now: held across the fill and the differentiation their 24
         // registers pushed the kernel into scratch (20 bytes per lane written and read back by every thread)
         if (has_range) {
-            q.prime(pos, s + tid, e);
-            if (KICK) qv.prime(vel, s + tid, e);
+            q.prime(pos + 3 * s, tid, (unsigned)(e - s));
+            if (KICK) qv.prime(vel + 3 * s, tid, (unsigned)(e - s));
         }
         __syncthreads();  // every stencil has read its potential: the buffer becomes the force tile
 #pragma unroll
@@ -1525,7 +1518,10 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     // gather, second kick (utils.py:297, y += a*x) and the CFL maxima in one pass: the acceleration never
     // leaves its registers (PMC: re-reading it in a separate coalesced pass cost a further 12.9 GB of fetch)
     unsigned ma = 0, mv = 0;  // bit patterns of max|a|, max|v| (integer order == float order, NaN on top)
-    auto serve = [&](int64_t p, float x, float y, float z, const float v[3], bool own_range) {
+    // (o, w, p): where the particle's acceleration and velocity go -- the range's own base with a 32-bit
+    // relative index, or the arrays' base with the 64-bit index of a listed straggler
+    auto serve = [&](float *__restrict__ o, float *__restrict__ w3, auto p, float x, float y, float z, const float v[3],
+                     bool own_range) {
         const float xp = x * nf, yp = y * nf, zp = z * nf;
         const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
         const bool inside = in_tile(i, j, k, t);
@@ -1546,26 +1542,29 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
             a[0] = r.x, a[1] = r.y, a[2] = r.z;
         }
         if (!skip) {
+            float *op = o + 3 * p, *wp = w3 + 3 * p;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                out[3 * p + m] = a[m];
+                op[m] = a[m];
                 ma = max(ma, __float_as_uint(a[m]) & 0x7fffffffu);
                 if (KICK) {
                     const float w = v[m] + mhalf_dt * a[m];
-                    vel[3 * p + m] = w;
+                    wp[m] = w;
                     mv = max(mv, __float_as_uint(w) & 0x7fffffffu);
                 }
             }
         }
     };
     if (has_range) {
+        float *const o = out + 3 * s, *const w3 = KICK ? vel + 3 * s : nullptr;
+        const unsigned cnt = (unsigned)(e - s);
 #pragma unroll 1
-        for (int64_t p = s + tid; p < e; p += BLK) {
+        for (unsigned r = tid; r < cnt; r += BLK) {
             float x, y, z;
-            q.pop(p, x, y, z);
+            q.pop(r, x, y, z);
             float v[3] = {0.f, 0.f, 0.f};
-            if (KICK) qv.pop(p, v);
-            serve(p, x, y, z, v, true);
+            if (KICK) qv.pop(r, v);
+            serve(o, w3, r, x, y, z, v, true);
         }
     }
 #pragma unroll 1
@@ -1573,7 +1572,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         const int64_t p = lists.idx[l];
         float v[3] = {0.f, 0.f, 0.f};
         if (KICK) v[0] = vel[3 * p], v[1] = vel[3 * p + 1], v[2] = vel[3 * p + 2];
-        serve(p, pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], v, false);
+        serve(out, vel, p, pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], v, false);
     }
     for (int off = 32; off > 0; off >>= 1) {
         ma = max(ma, (unsigned)__shfl_down((int)ma, off, 64));
