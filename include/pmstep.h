@@ -170,7 +170,8 @@ int pm_kick_drift_wrap_deposit_slab(pm_ctx *ctx, int scheme, float *d_pos, float
  * potential of its tile in LDS, differentiates it there with the reference's stencil and gathers from the
  * result, so the [n,n,n,3] force grid is never written or read.  Same bits as pm_gradient followed by
  * pm_interp_kick.  d_phi holds nx_phi planes starting at global plane x0_phi (single GPU: n, 0; slabs: the
- * owned planes + reach+1 ghosts each side).  d_vel may be NULL (no kick).  Needs n >= 16. */
+ * owned planes + reach+1 ghosts each side).  d_vel may be NULL (no kick).  Needs n >= 16 and a 16-byte
+ * aligned d_phi (any hipMalloc / torch allocation is). */
 int pm_gradient_interp_kick(pm_ctx *ctx, int order, int scheme, const float *d_phi, int nx_phi, int x0_phi,
                             const float *d_pos, int64_t np, float *d_acc, float *d_vel, float half_dt);
 /* utils.max_abs of the acc / vel arrays written by the last pm_interp_kick (syncs).  *h_max_vel is 0

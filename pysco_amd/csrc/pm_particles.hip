@@ -109,6 +109,7 @@ constexpr int PM_FSTRIDE = 3264;                      // cells per plane of the 
 // with three separate component planes the compiler paid a v_mov per operand to build those pairs.
 constexpr int PM_FZ = 2 * PM_FSTRIDE;                 // float offset of the z plane
 typedef float pm_v2f __attribute__((ext_vector_type(2)));
+typedef float pm_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int force_tile_index(int c, int m) { return m < 2 ? 2 * c + m : PM_FZ + c; }
 __device__ __forceinline__ void force_tile_put(float *tile, int c, float gx, float gy, float gz) {
     *reinterpret_cast<pm_v2f *>(tile + 2 * c) = pm_v2f{gx, gy};
@@ -1416,19 +1417,25 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     const float scale = grad_scale<ORDER>(n);
     const TileId t = tile_of_key(key);
     constexpr int R = GradReach<ORDER>::R;
-    constexpr int DX = PM_HI + 2 * R, DY = PM_HJ + 2 * R, DZ = PM_HK + 2 * R;  // potential tile
-    constexpr int NPHI = DX * DY * DZ;                                        // 6776 (R=2), 9216 (R=3)
-    constexpr int NQP = ORDER == 0 ? 1 : (NPHI + BLK - 1) / BLK;
-    float gphi[NQP];
-    if constexpr (ORDER != 0) {  // consecutive lanes read consecutive z (rows of DZ floats); all loads in flight
-        const int gi0 = t.ti * PM_TI - 1 - R, gj0 = t.tj * PM_TJ - 1 - R, gk0 = t.tk * PM_TK - 1 - R;
+    // Potential tile: DX x DY rows of DZ = 24 floats, row r starting at global k = 16 tk - 4.  A row is six
+    // aligned float4 (n is a multiple of 16, so the periodic wrap never splits a quad): the fill is 6-9
+    // 16-byte loads per thread whose LDS address is just 16 * q, where the 22-float rows of single dwords
+    // took 27 loads per thread and a divide-by-22 decode each (the kernel is VALU-bound).
+    constexpr int DX = PM_HI + 2 * R, DY = PM_HJ + 2 * R, DZ = 24, KOFF = 3;  // cell lk sits at row position lk + KOFF
+    static_assert(PM_TK == 16 && PM_HK + KOFF + R <= DZ && KOFF >= R, "row window 16 tk - 4 .. 16 tk + 19");
+    constexpr int NPHI = DX * DY * DZ;   // 7392 (R=2), 9216 (R=3)
+    constexpr int NQUAD = NPHI / 4;
+    constexpr int NQP = ORDER == 0 ? 1 : (NQUAD + BLK - 1) / BLK;
+    pm_v4f gphi[NQP];
+    if constexpr (ORDER != 0) {  // all loads in flight before anything waits
+        const int gi0 = t.ti * PM_TI - 1 - R, gj0 = t.tj * PM_TJ - 1 - R, gk0 = t.tk * PM_TK - 4;
 #pragma unroll
         for (int u = 0; u < NQP; ++u) {
-            const int f = u * BLK + tid;
-            if (f < NPHI) {
-                const int c = f % DZ, ab = f / DZ;
-                gphi[u] = src[pm_cell(geo, gi0 + ab / DY, gj0 + ab % DY, gk0 + c)];
-            }
+            // clamped, not guarded: behind a guard the compiler sinks the load to its LDS write and waits
+            // for each one in turn
+            const int qd = min(u * BLK + tid, NQUAD - 1);
+            const int c4 = qd % 6, ab = qd / 6;
+            gphi[u] = *reinterpret_cast<const pm_v4f *>(src + pm_cell(geo, gi0 + ab / DY, gj0 + ab % DY, gk0 + 4 * c4));
         }
     }
     unsigned ls = 0, le = 0;  // incoming stragglers (first workgroup of the tile only)
@@ -1473,20 +1480,23 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         float *ptile = tile;
 #pragma unroll
         for (int u = 0; u < NQP; ++u) {
-            const int f = u * BLK + tid;
-            if (f < NPHI) ptile[f] = gphi[u];
+            const int qd = u * BLK + tid;
+            if (qd < NQUAD) reinterpret_cast<pm_v4f *>(ptile)[qd] = gphi[u];
         }
         __syncthreads();
         // differentiate: thread owns force-tile cells tid, tid + BLK, ...
         constexpr int NC = (PM_TILE + BLK - 1) / BLK;  // 13
         float gx[NC], gy[NC], gz[NC];
+        // cell c = u * BLK + tid -> (li, lj, lk) and its potential-tile index, stepped instead of divided:
+        // BLK = 14 * 18 + 4 cells further on is (lj + 14, lk + 4) with at most one carry each
+        static_assert(BLK == 14 * PM_HK + 4 && PM_HJ == PM_HK && BLK / PM_HK < PM_HJ, "cell stepping");
+        int lk = tid % PM_HK, lj = tid / PM_HK;  // li = 0: BLK < 18 * 18
+        int pc = (R * DY + (lj + R)) * DZ + (lk + KOFF);
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
             const int c = u * BLK + tid;
             if (c < PM_TILE) {
-                const int lk = c % PM_HK, lij = c / PM_HK;
-                const int lj = lij % PM_HJ, li = lij / PM_HJ;
-                const float *ctr = ptile + ((li + R) * DY + (lj + R)) * DZ + (lk + R);
+                const float *ctr = ptile + pc;
                 float sa[7], sb[7];
 #pragma unroll
                 for (int o = 0; o < 7; ++o) sa[o] = sb[o] = 0.f;
@@ -1500,6 +1510,9 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                 for (int o = -R; o <= R; ++o) sa[o + 3] = ctr[o];
                 gz[u] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
             }
+            lk += 4, lj += 14, pc += 14 * DZ + 4;
+            if (lk >= PM_HK) lk -= PM_HK, lj += 1, pc += DZ - PM_HK;
+            if (lj >= PM_HJ) lj -= PM_HJ, pc += (DY - PM_HJ) * DZ;
         }
         // the particle queues are primed only now: held across the fill and the differentiation their 24
         // registers pushed the kernel into scratch (20 bytes per lane written and read back by every thread)
@@ -1714,6 +1727,7 @@ extern "C" int pm_gradient_interp_kick(pm_ctx *c, int order, int scheme, const f
     PM_REQUIRE(c && d_phi && np >= 0 && ((d_pos && d_acc) || np == 0), "bad argument");
     PM_REQUIRE(c->n >= 16, "pm_gradient_interp_kick needs n >= 16 (use pm_gradient + pm_interp below that)");
     PM_REQUIRE(nx_phi >= 1 && nx_phi <= c->n, "bad potential slab");
+    PM_REQUIRE(((uintptr_t)d_phi & 15u) == 0, "d_phi must be 16-byte aligned (the tile fill reads float4)");
     PM_REQUIRE((np + PM_CHUNK - 1) / PM_CHUNK < 2147483647LL, "too many particles for one launch");
     PM_HIP(hipMemsetAsync(c->d_scratch + 8, 0, 2 * sizeof(unsigned), c->stream));
     if (np == 0) return PM_OK;
