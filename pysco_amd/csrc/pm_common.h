@@ -65,18 +65,23 @@ __device__ __forceinline__ int64_t pm_cell(const pm_geom &g, int gi, int gj, int
 }
 
 // utils.periodic_wrap (utils.py:1120-1149); eps = -(2^-25)*(1+1e-6) as a double
+// Written as selects: the early-return form compiled to three branches per coordinate inside the
+// particle loops.  For a float y, (double)y > eps is y >= -(2^-25)(1 + 8*2^-23): eight ulps below
+// -2^-25 is the last float above eps, so the test needs no fp64.
 __device__ __forceinline__ float pm_wrap01(float y) {
-    const double eps = -(1.0 / 33554432.0) * (1.0 + 1e-6);
-    if (y < 0.0f) return ((double)y > eps) ? 0.0f : y + 1.0f;
-    if (y >= 1.0f) return y - 1.0f;
-    return y;
+    const float eps_f = __uint_as_float(0xb3000008u);  // -(2^-25)(1 + 8*2^-23)
+    const float neg = (y >= eps_f) ? 0.0f : y + 1.0f;
+    float r = (y >= 1.0f) ? y - 1.0f : y;
+    r = (y < 0.0f) ? neg : r;
+    return r;
 }
 
 // leapfrog first half for one coordinate (integration.py:250-258): v += -half_dt*a; x += dt*v; wrap(x)
-// (the reference's a == +-1 special cases of y += a*x, utils.py:289-295, are kept for the drift)
+// (the reference's a == +-1 special cases of y += a*x, utils.py:289-295, need no branch: 1*v and -1*v are
+// exact, so x + dt*v rounds once exactly like x + v and x - v; the build never contracts to an fma)
 __device__ __forceinline__ void pm_kick_drift_wrap_one(float &x, float &v, float a, float mhalf_dt, float dt) {
     v = v + mhalf_dt * a;
-    x = (dt == 1.0f) ? x + v : ((dt == -1.0f) ? x - v : x + dt * v);
+    x = x + dt * v;
     x = pm_wrap01(x);
 }
 

@@ -1149,11 +1149,11 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
             const int64_t p = p0 + u * BLK;
             if (p < e) {
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    pm_kick_drift_wrap_one(x[u][m], v[u][m], a[u][m], mhalf_dt, dt);
-                    vel[3 * p + m] = v[u][m];
-                    pos[3 * p + m] = x[u][m];
-                }
+                for (int m = 0; m < 3; ++m) pm_kick_drift_wrap_one(x[u][m], v[u][m], a[u][m], mhalf_dt, dt);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) vel[3 * p + m] = v[u][m];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) pos[3 * p + m] = x[u][m];
                 if (lv.idx && (x[u][0] < lv.x_lo || x[u][0] >= lv.x_hi)) {  // slab: leaves this rank's planes
                     const int slot = atomicAdd(lv.count, 1);
                     if (slot < lv.cap) lv.idx[slot] = p;
