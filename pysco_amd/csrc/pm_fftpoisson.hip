@@ -27,14 +27,34 @@
 
 #define FBLK 512  // 8 wavefronts = 8 lines
 
+// Complex arithmetic on 2-vectors: one packed instruction per complex add, three per multiply, one per
+// multiplication by +-i.  The half swaps and single-half sign flips ride on the VOP3P op_sel / neg
+// modifiers; the compiler folds a swap or a negation of BOTH halves by itself but builds (-x, y) with a
+// v_xor and a v_mov, and left to its SLP vectoriser it pairs halves of different values and shuffles
+// them back (a third of a 1024-point transform's VALU instructions) -- hence four one-line asm helpers.
+typedef float cv2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cv2 cv(float2 a) { return cv2{a.x, a.y}; }
+__device__ __forceinline__ float2 cf(cv2 a) { return make_float2(a.x, a.y); }
+#define FFTP_PK_ADD(name, mods)                                                          \
+    __device__ __forceinline__ cv2 name(cv2 a, cv2 b) {                                   \
+        cv2 r;                                                                            \
+        asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(r) : "v"(a), "v"(b));                   \
+        return r;                                                                         \
+    }
+FFTP_PK_ADD(add_neglo, "neg_lo:[0,1]")                                  // a + (-b.x,  b.y)
+FFTP_PK_ADD(add_neghi, "neg_hi:[0,1]")                                  // a + ( b.x, -b.y)
+FFTP_PK_ADD(add_swap_neglo, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")  // a + (-b.y,  b.x) = a + i b
+FFTP_PK_ADD(add_swap_neghi, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")  // a + ( b.y, -b.x) = a - i b
+#undef FFTP_PK_ADD
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    const cv2 t = cv2{a.x, a.x} * cv(b), u = cv2{a.y, a.y} * cv2{b.y, b.x};
+    return cf(add_neglo(t, u));
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return cf(cv(a) + cv(b)); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return cf(cv(a) - cv(b)); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
-__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
+__device__ __forceinline__ float2 mul_mi(float2 a) { return cf(add_swap_neghi(cv2{0.f, 0.f}, cv(a))); }  // a * (-i)
+__device__ __forceinline__ float2 mul_pi(float2 a) { return cf(add_swap_neglo(cv2{0.f, 0.f}, cv(a))); }  // a * (+i)
 
 // LDS addressing: element e of a line lives at PADI(e) = e + e/16 and lines are NP(n) = n + n/16 + 4 apart.
 // The extra slot per 16 elements spreads the stride-16 (and stride-8) scatter of a stage's outputs over
@@ -51,12 +71,17 @@ __device__ __forceinline__ float2 mul_j(float2 a) {  // a * (-i) forward, a * (+
 }
 template <bool INV>
 __device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
-    const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = mul_j<INV>(csub(a1, a3));
-    a0 = cadd(s02, s13), a1 = cadd(d02, d13), a2 = csub(s02, s13), a3 = csub(d02, d13);
+    const cv2 s02 = cv(a0) + cv(a2), d02 = cv(a0) - cv(a2), s13 = cv(a1) + cv(a3), d = cv(a1) - cv(a3);
+    // a1 = d02 + j d, a3 = d02 - j d with j = -i (forward) or +i (inverse)
+    a0 = cf(s02 + s13), a2 = cf(s02 - s13);
+    a1 = cf(INV ? add_swap_neglo(d02, d) : add_swap_neghi(d02, d));
+    a3 = cf(INV ? add_swap_neghi(d02, d) : add_swap_neglo(d02, d));
 }
 template <bool INV>
 __device__ __forceinline__ float2 cmul_w(float2 a, float c, float sn) {  // a * exp(-/+ i theta), (c, sn) = (cos, sin) theta
-    return INV ? make_float2(a.x * c - a.y * sn, a.x * sn + a.y * c) : make_float2(a.x * c + a.y * sn, a.y * c - a.x * sn);
+    // forward: (a.x c + a.y sn, a.y c - a.x sn); inverse: (a.x c - a.y sn, a.y c + a.x sn)
+    const cv2 t = cv(a) * cv2{c, c}, u = cv2{a.y, a.x} * cv2{sn, sn};
+    return cf(INV ? add_neglo(t, u) : add_neghi(t, u));
 }
 template <int R, bool INV>
 struct Dft;
@@ -118,8 +143,17 @@ __device__ __forceinline__ void stockham_stage(float2 *ln, const float2 *tw, int
     for (int i = 0; i < BPL; ++i) {
         const int j = lane + 64 * i;
         if (j < nb) {
+            // PADI(j + t nb) = PADI(j) + t (nb + nb/16) when nb is a multiple of 16: one add per element
+            // instead of the shift-add-add of PADI (a third of the stage's VALU work was address arithmetic)
+            if (nb >= 16) {
+                const float2 *src = ln + PADI(j);
+                const int rs = nb + (nb >> 4);
 #pragma unroll
-            for (int t = 0; t < R; ++t) a[i][t] = ln[PADI(j + t * nb)];
+                for (int t = 0; t < R; ++t) a[i][t] = src[t * rs];
+            } else {
+#pragma unroll
+                for (int t = 0; t < R; ++t) a[i][t] = ln[PADI(j + t * nb)];
+            }
         }
     }
 #pragma unroll
@@ -145,8 +179,17 @@ __device__ __forceinline__ void stockham_stage(float2 *ln, const float2 *tw, int
         const int j = lane + 64 * i;
         if (j < nb) {
             const int base = ((j >> lNs) << (lNs + (R == 16 ? 4 : (R == 8 ? 3 : 2)))) + (j & (Ns - 1));
+            if (lNs == 0 || lNs >= 4) {
+                // Ns = 1: base is a multiple of R <= 16, so base + t stays in base's 16-group; Ns a multiple
+                // of 16: PADI(base + t Ns) = PADI(base) + t (Ns + Ns/16).  Either way immediate offsets.
+                float2 *dst = ln + PADI(base);
+                const int ws = lNs == 0 ? 1 : Ns + (Ns >> 4);
 #pragma unroll
-            for (int t = 0; t < R; ++t) ln[PADI(base + (t << lNs))] = a[i][t];
+                for (int t = 0; t < R; ++t) dst[t * ws] = a[i][t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < R; ++t) ln[PADI(base + (t << lNs))] = a[i][t];
+            }
         }
     }
 }
