@@ -46,9 +46,14 @@ FFTP_PK_ADD(add_neghi, "neg_hi:[0,1]")                                  // a + (
 FFTP_PK_ADD(add_swap_neglo, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")  // a + (-b.y,  b.x) = a + i b
 FFTP_PK_ADD(add_swap_neghi, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")  // a + ( b.y, -b.x) = a - i b
 #undef FFTP_PK_ADD
+// a b = (a.x b.x - a.y b.y, a.x b.y + a.y b.x): a packed multiply and a packed fma (the transform is held to a
+// tolerance, not to the bits of a CPU FFT, so the fused rounding is welcome here; the build's -ffp-contract=off
+// protects the kernels that reproduce the reference's fp32 arithmetic)
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    const cv2 t = cv2{a.x, a.x} * cv(b), u = cv2{a.y, a.y} * cv2{b.y, b.x};
-    return cf(add_neglo(t, u));
+    const cv2 t = cv2{a.x, a.x} * cv(b);
+    cv2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(cv(a)), "v"(cv(b)), "v"(t));
+    return cf(r);  // (a.y * -b.y + t.x, a.y * b.x + t.y)
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return cf(cv(a) + cv(b)); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return cf(cv(a) - cv(b)); }
