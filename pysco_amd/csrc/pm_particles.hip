@@ -1484,19 +1484,27 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
             if (qd < NQUAD) reinterpret_cast<pm_v4f *>(ptile)[qd] = gphi[u];
         }
         __syncthreads();
-        // differentiate: thread owns force-tile cells tid, tid + BLK, ...
-        constexpr int NC = (PM_TILE + BLK - 1) / BLK;  // 13
+        // differentiate.  Lane -> cell mapping chosen for the LDS banks (ds_read_b32: 32 lanes per group on 32
+        // slots): a half-wave takes 4 consecutive (i, j) rows x 8 consecutive k; with the 24-float rows of the
+        // potential tile its 32 reads fall on 32 different slots for every stencil offset, where consecutive
+        // cells (18 + 14 of two rows) always collided two-fold.  A wave = 4 rows x k 0..15; the two last
+        // k-cells of every row go in a tail pass.
+        constexpr int NROWS = PM_HI * PM_HJ, NBLK = NROWS / 4;  // 180 rows, 45 blocks of 4 rows x 16 k
+        static_assert(NROWS % 4 == 0 && PM_HK == 18 && BLK == 256, "differentiation blocks");
+        constexpr int NCM = (NBLK + 3) / 4, NTAIL = (2 * NROWS + BLK - 1) / BLK, NC = NCM + NTAIL;  // 12 + 2
         float gx[NC], gy[NC], gz[NC];
-        // cell c = u * BLK + tid -> (li, lj, lk) and its potential-tile index, stepped instead of divided:
-        // BLK = 14 * 18 + 4 cells further on is (lj + 14, lk + 4) with at most one carry each
-        static_assert(BLK == 14 * PM_HK + 4 && PM_HJ == PM_HK && BLK / PM_HK < PM_HJ, "cell stepping");
-        int lk = tid % PM_HK, lj = tid / PM_HK;  // li = 0: BLK < 18 * 18
-        int pc = (R * DY + (lj + R)) * DZ + (lk + KOFF);
+        const int wv = tid >> 6, ln = tid & 63;
+        const int kk = (ln & 7) + ((ln >> 5) << 3), jr = (ln >> 3) & 3;
+        // cell (row r = li * 18 + lj, k) of pass slot u, or -1
+        auto cell_row = [&](int u) { return u < NCM ? ((u * 4 + wv) < NBLK ? 4 * (u * 4 + wv) + jr : -1)
+                                                    : ((tid + (u - NCM) * BLK) < 2 * NROWS ? (tid + (u - NCM) * BLK) >> 1 : -1); };
+        auto cell_k = [&](int u) { return u < NCM ? kk : 16 + (tid & 1); };
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
-            const int c = u * BLK + tid;
-            if (c < PM_TILE) {
-                const float *ctr = ptile + pc;
+            const int r = cell_row(u), k = cell_k(u);
+            if (r >= 0) {
+                const int li = r / PM_HJ, lj = r - li * PM_HJ;
+                const float *ctr = ptile + ((li + R) * DY + (lj + R)) * DZ + (k + KOFF);
                 float sa[7], sb[7];
 #pragma unroll
                 for (int o = 0; o < 7; ++o) sa[o] = sb[o] = 0.f;
@@ -1510,9 +1518,6 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                 for (int o = -R; o <= R; ++o) sa[o + 3] = ctr[o];
                 gz[u] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
             }
-            lk += 4, lj += 14, pc += 14 * DZ + 4;
-            if (lk >= PM_HK) lk -= PM_HK, lj += 1, pc += DZ - PM_HK;
-            if (lj >= PM_HJ) lj -= PM_HJ, pc += (DY - PM_HJ) * DZ;
         }
         // the particle queues are primed only now: held across the fill and the differentiation their 24
         // registers pushed the kernel into scratch (20 bytes per lane written and read back by every thread)
@@ -1523,8 +1528,8 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         __syncthreads();  // every stencil has read its potential: the buffer becomes the force tile
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
-            const int c = u * BLK + tid;
-            if (c < PM_TILE) force_tile_put(tile, c, gx[u], gy[u], gz[u]);
+            const int r = cell_row(u);
+            if (r >= 0) force_tile_put(tile, r * PM_HK + cell_k(u), gx[u], gy[u], gz[u]);
         }
     }
     __syncthreads();
