@@ -362,8 +362,8 @@ extern "C" int pm_interp(pm_ctx *c, int scheme, int ncomp, const float *d_grid, 
 // reductions of the next step (integration.py:294, 325).
 //
 // The direct kernel above is bound by the L1 tag rate (27 scattered 12-byte loads per particle).
-// Here the workgroup stages the force tile of its chunk (8x16x16 cells + halo, three component planes,
-// 39.2 KB) in LDS with coalesced loads and every particle does 27 x 3 ds_read_b32.  Sum order is the
+// Here the workgroup stages the force tile of its chunk (8x16x16 cells + halo: an (x, y) float2 plane and
+// a z plane, 39.2 KB) in LDS with coalesced loads and every particle does 27 x (ds_read_b64 + ds_read_b32).  Sum order is the
 // reference's, so the accelerations are bit-identical to the direct kernel and to the oracle.
 
 template <int SCHEME>
@@ -1409,7 +1409,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         return;
     else
         has_range = true;
-    __shared__ float tile[3 * PM_FSTRIDE];  // 39.2 KB: three component planes (ORDER > 0: first the potential tile)
+    __shared__ float tile[3 * PM_FSTRIDE];  // 39.2 KB: (x, y) plane + z plane (ORDER > 0: first the potential tile)
     __shared__ unsigned s_max[2][BLK / 64];
     const int tid = threadIdx.x;
     const int n = geo.n;
