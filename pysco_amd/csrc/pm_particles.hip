@@ -376,7 +376,11 @@ __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, 
                                            const float *tile, float acc[3]) {
     const int li = i - t.ti * PM_TI + 1, lj = j - t.tj * PM_TJ + 1, lk = k - t.tk * PM_TK + 1;
     // 24-bit multiplies: full rate, where v_mul_lo_u32 is quarter rate (li, lj, lk are small and >= 0)
-    const int c0 = (int)__umul24(__umul24((unsigned)li, PM_HJ) + (unsigned)lj, PM_HK) + lk;
+    // 24-bit multiply-adds, as asm: from C (`* 18`, `__umul24`, shift-adds alike) the compiler canonicalises to
+    // a multiply by 18 and selects the quarter-rate v_mul_lo_u32 (li, lj, lk are small and >= 0)
+    int r0, c0;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r0) : "v"(li), "n"(PM_HJ), "v"(lj));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(c0) : "v"(r0), "n"(PM_HK), "v"(lk));
     const pm_v2f *txy = reinterpret_cast<const pm_v2f *>(tile);
     const float *tz = tile + PM_FZ;
     // The running sums start from +0 (0 + w*g == w*g exactly) and add the terms in the reference's
