@@ -94,11 +94,13 @@ def alg_bytes(n, npart):
         "pm_kick_drift_wrap": 60.0 * npart,          # read x,v,a; write x,v
         "pm_deposit": 12.0 * npart + 4.0 * cells,    # read x; write rho
         "pm_kick_drift_wrap_deposit": 60.0 * npart + 4.0 * cells,  # the two above in one kernel (x read once)
+        "pm_kick_drift_wrap_deposit_khalo": 60.0 * npart + 4.0 * cells,  # same work, k-halo cells via a side buffer
         "pm_linear_operator": 8.0 * cells,           # rhs scaling (fused into the FFT in the ideal count)
         "pm_fft_r2c": 24.0 * cells,                  # 3 axis passes, read+write
         "pm_greens": 2.0 * spec,                     # read+write half spectrum (0 in the fused ideal)
         "pm_fft_c2r": 24.0 * cells,
         "pm_poisson_fft_fused": 48.0 * cells,       # r2c + Green's function + c2r in five LDS-FFT passes
+        "pm_poisson_fft_fused_khalo": 48.0 * cells,  # the same, the z pass also folding the k-halo buffer in
         "pm_gradient": 16.0 * cells,                 # read phi, write F(3)
         "pm_interp": 24.0 * npart + 12.0 * cells,    # read x, F; write a
         "pm_interp_kick": 48.0 * npart + 12.0 * cells,  # gather + second kick + CFL maxima: read x,v,F; write v,a
@@ -247,7 +249,7 @@ def main():
     ab = alg_bytes(n, npart / world)
     for k in ab:  # per-rank share of the grid stages in slab mode
         if k not in ("pm_kick_drift_wrap", "pm_deposit", "pm_interp", "pm_interp_kick", "pm_gradient_interp_kick",
-                     "pm_kick_drift_wrap_deposit",
+                     "pm_kick_drift_wrap_deposit", "pm_kick_drift_wrap_deposit_khalo",
                      "pm_axpy", "pm_max_abs"):
             ab[k] /= world
     if world > 1:
@@ -279,8 +281,11 @@ def main():
         kernels = json.load(open(pmc_path))["kernels"]
         stage_kernels = {"pm_gradient_interp_kick": ["interp_ranges_kernel<3, 5, true>"],
                          "pm_kick_drift_wrap_deposit": ["kdw_deposit_kernel<3>", "deposit_list_kernel<3>"],
+                         "pm_kick_drift_wrap_deposit_khalo": ["kdw_deposit_kernel<3>", "deposit_list_kernel<3>"],
                          "pm_poisson_fft_fused": ["fftp_z_r2c", "fftp_y<true>", "fftp_x_green<1>", "fftp_y<false>",
-                                                  "fftp_z_c2r"]}.get(dom["stage"], [])
+                                                  "fftp_z_c2r"],
+                         "pm_poisson_fft_fused_khalo": ["fftp_z_r2c", "fftp_y<true>", "fftp_x_green<1>", "fftp_y<false>",
+                                                        "fftp_z_c2r"]}.get(dom["stage"], [])
         if stage_kernels and all(k in kernels for k in stage_kernels):
             traffic = sum(kernels[k]["hbm_bytes"] for k in stage_kernels)
     roofline = {"bound": "hbm", "kernel": dom["stage"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

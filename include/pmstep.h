@@ -106,6 +106,9 @@ int pm_poisson_fft(pm_ctx *ctx, int kind, int p, const float *d_rhs, float *d_ph
  * function applied between the forward and inverse x transforms (32 <= n <= 1024). */
 int pm_poisson_fft_fused(pm_ctx *ctx, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
                          const float *h_s, float c0);
+/* pm_poisson_fft_fused on a density deposited by pm_kick_drift_wrap_deposit_khalo (d_rhs = that d_rho) */
+int pm_poisson_fft_fused_khalo(pm_ctx *ctx, int kind, int p, const float *d_rhs, const float *d_khalo, float *d_phi,
+                               const float *h_k2, const float *h_s, float c0);
 /* The three stages of pm_poisson_fft_fused, exposed for the slab-decomposed solve (nx = local x-planes):
  *   pm_fftp_forward : d_rhs [nx,n,n] real            -> d_C [n (ky), n/2+1 (kz), nx]   (z r2c + y forward)
  *   pm_fftp_xgreen  : in place on d_C laid out [n/nx segments][nky][n/2+1][nx] -- what an all-to-all over
@@ -158,6 +161,16 @@ int pm_tile_lists_info(pm_ctx *ctx, int64_t *stragglers, int64_t *np, int *compl
  * keeps them, so the gather of the same step reuses them.  Single-GPU layout, n >= 16, np < 2^32. */
 int pm_kick_drift_wrap_deposit(pm_ctx *ctx, int scheme, float *d_pos, float *d_vel, const float *d_acc,
                                float half_dt, float dt, int64_t np, float *d_rho);
+/* The same with the k-halo cells of the tiles kept out of d_rho.  The flush of a tile (8 x 16 x 16 cells + one
+ * halo cell per side) adds to the density with global float atomics, which the memory side executes as one
+ * 64-byte read-modify-write per touched sector: the two k-halo cells at the ends of every tile row cost one
+ * request each, as much as the row's 16 own cells -- half of the flush.  Here the first-chunk workgroup of tile
+ * (ti, tj, tk) writes them with plain stores to d_khalo[((ti*(n/16) + tj)*(n/16) + tk)][2 (low, high)][10][18]
+ * ((n/8)(n/16)(n/16) * 360 floats, all written) and d_rho lacks exactly those contributions.  Consumers:
+ * pm_poisson_fft_fused_khalo (adds them while its z pass loads the density) or pm_khalo_apply (completes d_rho). */
+int pm_kick_drift_wrap_deposit_khalo(pm_ctx *ctx, int scheme, float *d_pos, float *d_vel, const float *d_acc,
+                                     float half_dt, float dt, int64_t np, float *d_rho, float *d_khalo);
+int pm_khalo_apply(pm_ctx *ctx, float *d_rho, const float *d_khalo);
 /* The same on a slab (pm_set_slab, pm_set_tile_window in force): d_rho is the rank's [nx_slab, n, n] density
  * array, which must be wide enough (ghost planes) for the footprint of every particle AFTER the drift -- the
  * caller bounds the drift (it knows dt, max|v|, max|a|) and chooses the ghost width; the particles whose new x

@@ -50,6 +50,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_pk": (_vp, _i, _vp, _vp, _vp, _vp, _vp),
     "pm_poisson_fft": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),
     "pm_poisson_fft_fused": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),
+    "pm_poisson_fft_fused_khalo": (_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f),
     "pm_fftp_forward": (_vp, _vp, _i, _vp),
     "pm_fftp_xgreen": (_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _f),
     "pm_fftp_inverse": (_vp, _vp, _i, _vp),
@@ -63,6 +64,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_tile_lists": (_vp, _vp, _i64),
     "pm_tile_lists_info": (_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)),
     "pm_kick_drift_wrap_deposit": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp),
+    "pm_kick_drift_wrap_deposit_khalo": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _vp),
+    "pm_khalo_apply": (_vp, _vp, _vp),
     "pm_kick_drift_wrap_deposit_slab": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _f, _f, _vp, _i, C.POINTER(_i)),
     "pm_gradient_interp_kick": (_vp, _i, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _f),
     "pm_last_maxabs": (_vp, C.POINTER(_f), C.POINTER(_f)),

@@ -24,6 +24,7 @@
 // stage: the lanes of a wave read all their inputs before the first output is written.
 // Replaces solver.fft (solver.py:453-522 without the P(k) branch) + fourier.py:104-147, 251-294, 460-595.
 #include "pm_common.h"
+#include <type_traits>
 
 #define FBLK 512  // 8 wavefronts = 8 lines
 
@@ -281,6 +282,20 @@ __device__ __forceinline__ void batched(int first, int total, int stride, Load l
     }
 }
 
+// One batch, no loop: for trip counts known to fit (total <= U * stride).  Before a LOOP the compiler drains
+// vmcnt whenever registers loaded earlier stay live across it, which would serialise those loads with this batch.
+template <int U, typename Load, typename Use>
+__device__ __forceinline__ void batched_once(int first, int total, int stride, Load load, Use use) {
+    if (first < total) {
+        decltype(load(0)) v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = load(min(first + u * stride, total - 1));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (first + u * stride < total) use(first + u * stride, v[u]);
+    }
+}
+
 __device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restrict__ g_tw, int n, int) {
     batched<2>(threadIdx.x, n, FBLK, [&](int t) { return *reinterpret_cast<const fft_v2f *>(g_tw + t); },
                [&](int t, fft_v2f v) { tw[t] = make_float2(v.x, v.y); });
@@ -315,16 +330,27 @@ __device__ __forceinline__ void lds_store_lines(const float2 *buf, float2 *__res
 // ---- P1: z r2c, two real lines per complex FFT, transposed write ---------------------------------
 // workgroup = 16 real lines (x fixed, y0..y0+15) = 8 complex lines
 __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho, float2 *__restrict__ B,
-                                                   const float2 *__restrict__ g_tw, int n, int log2n, int nx) {
+                                                   const float2 *__restrict__ g_tw, int n, int log2n, int nx,
+                                                   const float *__restrict__ khalo) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *buf = lds, *tw = lds + 8 * NP(n);
     const int nh = (n >> 1) + 1;
     const int64_t line0 = (int64_t)blockIdx.x * 16;  // flat (x*n + y) index of the first real line
     load_twiddles(tw, g_tw, n, log2n);
-    {   // contiguous load of 16*n floats; real line 2m -> re, 2m+1 -> im of complex line m
+    // k-halo buffer (pm_kick_drift_wrap_deposit_khalo): the contributions of every tile to the two k-cells just
+    // outside it are not in rho but in khalo[((ti Tj + tj) Tk + tk)][low | high][li][lj] (tiles of 8 x 16 x 16
+    // cells, li in 0..9 and lj in 0..17 with the one-cell halo).  This workgroup holds the 16 lines
+    // (x, y0 .. y0 + 15), i.e. row li = x % 8 + 1 of the tile column (x / 8, y0 / 16): cell k = 16 m + 15
+    // receives the low halo of the tiles at tk = m + 1, cell k = 16 m the high halo of those at tk = m - 1, from
+    // the own tile column and -- on its faces -- from the neighbouring ones.  16 lanes read 16 consecutive lj
+    // (64-byte pieces); the loads are issued here, ahead of the density's, unguarded (a lane off the j faces
+    // re-reads its own entry and drops it), and are consumed after the line buffer is filled.
+    constexpr int KH_PER_THREAD = 4;  // 2 x (n / 16) x 16 entries over FBLK threads, n <= 1024
+    const int kT = n >> 4;
+    auto fill = [&]() {  // contiguous load of 16*n floats; real line 2m -> re, 2m+1 -> im of complex line m
         const float4 *src = reinterpret_cast<const float4 *>(rho + line0 * n);
         const int nq = n >> 2;
-        batched<8>(
+        batched_once<8>(  // 16 n / 4 quads <= 8 FBLK for n <= 1024
             threadIdx.x, 16 * nq, FBLK, [&](int t) { return *reinterpret_cast<const fft_v4f *>(src + t); },
             [&](int t, fft_v4f v) {
                 const int rl = t / nq, z0 = (t - rl * nq) << 2;
@@ -332,8 +358,57 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
                 float *dst = reinterpret_cast<float *>(buf + (rl >> 1) * NP(n) + PADI(z0)) + (rl & 1);
                 dst[0] = v.x, dst[2] = v.y, dst[4] = v.z, dst[6] = v.w;
             });
-    }
-    __syncthreads();
+        __syncthreads();
+    };
+    // fill + k-halo: two straight-line variants (interior row of the tile column / row on an i face) of the
+    // whole front of the kernel, so that the k-halo loads stay in flight across the density loads (with the
+    // face test inside, every pair of loads got its own basic block and vmcnt(0); joined after a branch, the
+    // loaded values were copied -- and waited for -- at the join)
+    auto front = [&](auto with_iface) {
+        constexpr bool IFACE = decltype(with_iface)::value;
+        const int Ti = n >> 3;
+        const int x = (int)(line0 >> log2n), y0 = (int)(line0 & (n - 1));
+        const int ti = x >> 3, tj = y0 >> 4, xi = x & 7;
+        const int di = xi == 0 ? -1 : 1;
+        const int tin = (ti + di + Ti) % Ti, lin = xi + 1 - 8 * di;
+        float kraw[KH_PER_THREAD][IFACE ? 4 : 2];  // own tile column, its j-face neighbour[, the i-face one, the edge one]
+#pragma unroll
+        for (int u = 0; u < KH_PER_THREAD; ++u) {
+            const int idx = min((int)threadIdx.x + u * FBLK, 32 * kT - 1);
+            const int rl = idx & 15, sm = idx >> 4, side = sm >= kT, m = sm - (side ? kT : 0);
+            const int tk = side ? (m + kT - 1) % kT : (m + 1) % kT;
+            const bool jf = rl == 0 || rl == 15;
+            const int tjn = rl == 0 ? (tj + kT - 1) % kT : (tj + 1) % kT, ljn = rl == 0 ? 17 : 0;
+            auto at = [&](int tii, int tjj, int li, int lj) {
+                return khalo[((((int64_t)tii * kT + tjj) * kT + tk) * 2 + side) * 180 + li * 18 + lj];
+            };
+            // unconditional loads: off the j faces the second one re-reads the first entry and is dropped
+            const int tj2 = jf ? tjn : tj, lj2 = jf ? ljn : rl + 1;
+            kraw[u][0] = at(ti, tj, xi + 1, rl + 1);
+            kraw[u][1] = at(ti, tj2, xi + 1, lj2);
+            if (IFACE) kraw[u][2] = at(tin, tj, lin, rl + 1), kraw[u][3] = at(tin, tj2, lin, lj2);
+        }
+        fill();
+#pragma unroll
+        for (int u = 0; u < KH_PER_THREAD; ++u) {  // the 2 x T boundary cells of each of the 16 lines
+            const int idx = threadIdx.x + u * FBLK;
+            if (idx < 32 * kT) {
+                const int rl = idx & 15, sm = idx >> 4, side = sm >= kT, m = sm - (side ? kT : 0);
+                const bool jf = rl == 0 || rl == 15;
+                float sum = kraw[u][0] + (jf ? kraw[u][1] : 0.f);
+                if (IFACE) sum = (sum + kraw[u][2]) + (jf ? kraw[u][3] : 0.f);
+                float *dst = reinterpret_cast<float *>(buf + (rl >> 1) * NP(n) + PADI(side ? 16 * m : 16 * m + 15)) + (rl & 1);
+                *dst += sum;
+            }
+        }
+        __syncthreads();
+    };
+    if (!khalo)
+        fill();
+    else if ((((int)(line0 >> log2n)) & 7) == 0 || (((int)(line0 >> log2n)) & 7) == 7)
+        front(std::true_type{});
+    else
+        front(std::false_type{});
     fft_forward_lds(buf, tw, n, log2n, 8);
     // unpack and write B[x][kz][y]: thread = (complex line m, kz) -> the two real lines' spectra A, B are
     // adjacent in y: one 16-byte store; 8 threads cover the 128 B of one kz
@@ -555,7 +630,7 @@ static inline size_t fftp_lds_bytes(int n) {
 
 // ---- stages (each a C-ABI entry point so that a slab driver can pipeline them against its all-to-alls) ----
 // P1: d_rhs [nx, n, n] real -> the context's B (all kz)
-static int fftp_z_forward(pm_ctx *c, const float *d_rhs, int nx) {
+static int fftp_z_forward(pm_ctx *c, const float *d_rhs, int nx, const float *d_khalo = nullptr) {
     PM_REQUIRE(c && d_rhs, "NULL argument");
     FFTP_CHECK_N(c);
     const int n = c->n, log2n = c->log2n, nh = n / 2 + 1;
@@ -564,7 +639,7 @@ static int fftp_z_forward(pm_ctx *c, const float *d_rhs, int nx) {
     int rc = ensure_fused_buffers(c, (size_t)nh * nx * n * sizeof(float2), 0);
     if (rc) return rc;
     hipLaunchKernelGGL(fftp_z_r2c, dim3((unsigned)((int64_t)nx * n / 16)), dim3(FBLK), fftp_lds_bytes(n), c->stream,
-                       d_rhs, (float2 *)c->fp_B, (const float2 *)c->fp_tw, n, log2n, nx);
+                       d_rhs, (float2 *)c->fp_B, (const float2 *)c->fp_tw, n, log2n, nx, d_khalo);
     PM_LAUNCH_CHECK();
     return PM_OK;
 }
@@ -616,8 +691,9 @@ extern "C" int pm_fftp_y_inverse(pm_ctx *c, const void *d_C, int nx, int kz0, in
 extern "C" int pm_fftp_z_inverse(pm_ctx *c, int nx, float *d_phi) { return fftp_z_inverse(c, nx, d_phi); }
 
 // P1 + P2 on nx local x-planes: d_rhs [nx, n, n] real -> d_C [n (ky), n/2+1 (kz), nx] complex
-static int fftp_forward_impl(pm_ctx *c, const float *d_rhs, int nx, void *d_C, int kzmajor) {
-    int rc = fftp_z_forward(c, d_rhs, nx);
+static int fftp_forward_impl(pm_ctx *c, const float *d_rhs, int nx, void *d_C, int kzmajor,
+                             const float *d_khalo = nullptr) {
+    int rc = fftp_z_forward(c, d_rhs, nx, d_khalo);
     if (rc) return rc;
     return fftp_y_pass(c, true, d_C, nx, 0, c->n / 2 + 1, kzmajor);
 }
@@ -698,16 +774,28 @@ extern "C" int pm_fftp_xgreen_kz(pm_ctx *c, int kind, int p, void *d_C, int nx, 
     return fftp_xgreen_impl(c, kind, p, d_C, nx, nky, ky0, h_k2, h_s, c0, 0, kz0, nkz);
 }
 
-extern "C" int pm_poisson_fft_fused(pm_ctx *c, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
-                                    const float *h_s, float c0) {
+static int poisson_fft_fused(pm_ctx *c, int kind, int p, const float *d_rhs, const float *d_khalo, float *d_phi,
+                             const float *h_k2, const float *h_s, float c0) {
     PM_REQUIRE(c && d_rhs && d_phi && h_k2 && h_s, "NULL argument");
     FFTP_CHECK_N(c);
     const int n = c->n;
     int rc = ensure_fused_buffers(c, 0, (size_t)n * n * (n / 2 + 1) * sizeof(float2));
     if (rc) return rc;
-    rc = fftp_forward_impl(c, d_rhs, n, c->fp_C, 1);  // single GPU: C is kz-major (see the header)
+    rc = fftp_forward_impl(c, d_rhs, n, c->fp_C, 1, d_khalo);  // single GPU: C is kz-major (see the header)
     if (rc) return rc;
     rc = fftp_xgreen_impl(c, kind, p, c->fp_C, n, n, 0, h_k2, h_s, c0, 1, 0, n / 2 + 1);
     if (rc) return rc;
     return fftp_inverse_impl(c, c->fp_C, n, d_phi, 1);
+}
+
+extern "C" int pm_poisson_fft_fused(pm_ctx *c, int kind, int p, const float *d_rhs, float *d_phi, const float *h_k2,
+                                    const float *h_s, float c0) {
+    return poisson_fft_fused(c, kind, p, d_rhs, nullptr, d_phi, h_k2, h_s, c0);
+}
+
+// The same for a density whose k-halo contributions are still in d_khalo (pm_kick_drift_wrap_deposit_khalo)
+extern "C" int pm_poisson_fft_fused_khalo(pm_ctx *c, int kind, int p, const float *d_rhs, const float *d_khalo,
+                                          float *d_phi, const float *h_k2, const float *h_s, float c0) {
+    PM_REQUIRE(d_khalo, "NULL argument");
+    return poisson_fft_fused(c, kind, p, d_rhs, d_khalo, d_phi, h_k2, h_s, c0);
 }

@@ -1136,6 +1136,7 @@ __global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__rest
 // (pm_tile_lists semantics) for the gather of the same step.
 
 constexpr int PM_SCAP = 1024;  // stragglers staged in LDS per workgroup before the global append
+constexpr int PM_KHALO_TILE = 2 * PM_HI * PM_HJ;  // floats per tile in the k-halo buffer: [low | high][li][lj]
 
 // slab decomposition: particles whose new x leaves [x_lo, x_hi) are listed for the migration (idx == NULL: off)
 struct Leavers {
@@ -1150,10 +1151,24 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
                                                           const float *__restrict__ acc, float mhalf_dt, float dt,
                                                           TileWork work, pm_geom geo, float *__restrict__ rho,
                                                           unsigned *__restrict__ lkeys, unsigned *__restrict__ lidx,
-                                                          unsigned subcap, unsigned *__restrict__ counts, Leavers lv) {
+                                                          unsigned subcap, unsigned *__restrict__ counts, Leavers lv,
+                                                          float *__restrict__ khalo) {
     unsigned key;
     int64_t s, e;
-    if (!tile_work_item(work, key, s, e)) return;
+    // k-halo buffer (pm_kick_drift_wrap_deposit_khalo): the first-chunk workgroup of tile (ti, tj, tk) owns
+    // khalo[((ti Tj + tj) Tk + tk)][2][PM_HI PM_HJ] and writes all of it, empty tile or not
+    const bool first_chunk = blockIdx.x < work.nlaunch;
+    float *kt = nullptr;
+    if (khalo && first_chunk) {
+        const TileId t0 = tile_of_key(tile_key_of_block(blockIdx.x, work));
+        const int T = geo.n >> PM_LJ;
+        kt = khalo + ((size_t)(t0.ti * T + t0.tj) * T + t0.tk) * PM_KHALO_TILE;
+    }
+    if (!tile_work_item(work, key, s, e)) {
+        if (kt)
+            for (int c = threadIdx.x; c < PM_KHALO_TILE; c += BLK) kt[c] = 0.f;
+        return;
+    }
     __shared__ pm_acc_t tile[PM_TILE];  // 25.9 KB
     __shared__ unsigned s_k[PM_SCAP], s_p[PM_SCAP];
     __shared__ unsigned s_cnt, s_base;
@@ -1211,9 +1226,18 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
         }
     }
     __syncthreads();
+    // Flush.  The global float atomics execute at the memory side as 64-byte read-modify-writes, one per
+    // touched 64-byte sector whatever it carries: a row's 16 own cells are one request, but the two k-halo
+    // cells at its ends are one request each -- 360 of a tile's 540 requests and half of the flush time
+    // (2.5 of 5.0 ms at 1024^3, measured by leaving them out).  With a k-halo buffer they go there as plain
+    // coalesced stores and reach the density when the z pass of the FFT loads it (pm_fftpoisson.hip).
     for (int c = tid; c < PM_TILE; c += BLK) {
         const pm_acc_t w = tile[c];
-        if (w != 0) unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), weight_of_acc(w));
+        const int lij = c / PM_HK, lk = c - lij * PM_HK;
+        if (kt && (lk == 0 || lk == PM_HK - 1))
+            kt[(lk ? PM_HI * PM_HJ : 0) + lij] = weight_of_acc(w);
+        else if (w != 0)
+            unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), weight_of_acc(w));
     }
     const unsigned cnt = min(s_cnt, (unsigned)PM_SCAP);
     if (cnt == 0) return;
@@ -1257,7 +1281,7 @@ __global__ __launch_bounds__(BLK) void deposit_list_kernel(const float *__restri
 
 template <int SCHEME>
 static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *acc, float half_dt, float dt, int64_t np,
-                              float *rho, Leavers lv) {
+                              float *rho, Leavers lv, float *khalo) {
     TileWork work;
     unsigned blocks = 0;
     tile_lists_drop(c);
@@ -1271,7 +1295,7 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));
     PM_HIP(hipMemsetAsync(b.counts, 0, PM_NSUB * PM_SUB_STRIDE * sizeof(unsigned), c->stream));
     hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, vel, acc, -half_dt, dt, work,
-                       pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv);
+                       pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv, khalo);
     PM_LAUNCH_CHECK();
     const unsigned *idx = nullptr;
     unsigned listed = 0;
@@ -1285,6 +1309,7 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
         // updated; deposit them again from scratch with the kernels that serve stragglers themselves.
         c->lists_pos = nullptr;
         PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));
+        if (khalo) PM_HIP(hipMemsetAsync(khalo, 0, (size_t)ntiles * PM_KHALO_TILE * sizeof(float), c->stream));
         hipLaunchKernelGGL((deposit_tiled_kernel<SCHEME>), dim3((unsigned)((np + PM_CHUNK - 1) / PM_CHUNK)), dim3(BLK), 0,
                            c->stream, pos, np, pm_ctx_geom(c), rho);
         PM_LAUNCH_CHECK();
@@ -1302,11 +1327,11 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
 }
 
 static int kdw_deposit_scheme(pm_ctx *c, int scheme, float *d_pos, float *d_vel, const float *d_acc, float half_dt,
-                              float dt, int64_t np, float *d_rho, Leavers lv) {
+                              float dt, int64_t np, float *d_rho, Leavers lv, float *khalo = nullptr) {
     switch (scheme) {
-        case PM_NGP: return kdw_deposit_launch<PM_NGP>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, lv);
-        case PM_CIC: return kdw_deposit_launch<PM_CIC>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, lv);
-        case PM_TSC: return kdw_deposit_launch<PM_TSC>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, lv);
+        case PM_NGP: return kdw_deposit_launch<PM_NGP>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, lv, khalo);
+        case PM_CIC: return kdw_deposit_launch<PM_CIC>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, lv, khalo);
+        case PM_TSC: return kdw_deposit_launch<PM_TSC>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, lv, khalo);
     }
     pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme);
     return PM_EINVAL;
@@ -1318,6 +1343,43 @@ extern "C" int pm_kick_drift_wrap_deposit(pm_ctx *c, int scheme, float *d_pos, f
     PM_REQUIRE(c->n >= 16 && np < 4294967296LL, "pm_kick_drift_wrap_deposit needs n >= 16 and np < 2^32");
     PM_REQUIRE(c->slab_nx == c->n, "pm_kick_drift_wrap_deposit is the single-GPU form (no slab set)");
     return kdw_deposit_scheme(c, scheme, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, Leavers{0.f, 1.f, nullptr, 0, nullptr});
+}
+
+// The same with the k-halo cells of the tiles kept out of d_rho (pmstep.h): d_khalo[(n/8)(n/16)(n/16)][2][180].
+extern "C" int pm_kick_drift_wrap_deposit_khalo(pm_ctx *c, int scheme, float *d_pos, float *d_vel, const float *d_acc,
+                                                float half_dt, float dt, int64_t np, float *d_rho, float *d_khalo) {
+    PM_REQUIRE(c && d_pos && d_vel && d_acc && d_rho && d_khalo && np > 0, "bad argument");
+    PM_REQUIRE(c->n >= 16 && np < 4294967296LL, "pm_kick_drift_wrap_deposit_khalo needs n >= 16 and np < 2^32");
+    PM_REQUIRE(c->slab_nx == c->n && c->tile_nx == c->n, "pm_kick_drift_wrap_deposit_khalo is the single-GPU form");
+    return kdw_deposit_scheme(c, scheme, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, Leavers{0.f, 1.f, nullptr, 0, nullptr},
+                              d_khalo);
+}
+
+// d_rho += the k-halo buffer: completes a density deposited by pm_kick_drift_wrap_deposit_khalo for consumers
+// other than pm_poisson_fft_fused_khalo (one global atomic per entry, as the flush would have done)
+__global__ __launch_bounds__(BLK) void khalo_apply_kernel(const float *__restrict__ khalo, pm_geom geo,
+                                                         float *__restrict__ rho) {
+    const int T = geo.n >> PM_LJ;
+    const int64_t total = (int64_t)(geo.n >> PM_LI) * T * T * PM_KHALO_TILE;
+    for (int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLK) {
+        const float v = khalo[e];
+        if (v == 0.f) continue;
+        const int r = (int)(e % PM_KHALO_TILE);
+        int64_t tile = e / PM_KHALO_TILE;
+        const int tk = (int)(tile % T), tj = (int)((tile / T) % T), ti = (int)(tile / ((int64_t)T * T));
+        const int side = r / (PM_HI * PM_HJ), lij = r - side * (PM_HI * PM_HJ), li = lij / PM_HJ, lj = lij - li * PM_HJ;
+        unsafeAtomicAdd(rho + pm_cell(geo, ti * PM_TI - 1 + li, tj * PM_TJ - 1 + lj, tk * PM_TK - 1 + (side ? PM_HK - 1 : 0)), v);
+    }
+}
+
+extern "C" int pm_khalo_apply(pm_ctx *c, float *d_rho, const float *d_khalo) {
+    PM_REQUIRE(c && d_rho && d_khalo, "NULL argument");
+    PM_REQUIRE(c->n >= 16 && c->slab_nx == c->n, "pm_khalo_apply is the single-GPU form");
+    const int64_t total = ((int64_t)c->n * c->n * c->n >> (PM_LI + PM_LJ + PM_LK)) * PM_KHALO_TILE;
+    hipLaunchKernelGGL(khalo_apply_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_khalo, pm_ctx_geom(c),
+                       d_rho);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
 }
 
 // The same on a slab (pm_set_slab: d_rho is [nx_slab, n, n] starting at global plane x0, wide enough for

@@ -58,6 +58,19 @@ def euler(position, velocity, acceleration, potential, additional_field, dt, tab
 
 
 _FUSE_DEPOSIT = True  # tests flip this to compare with the separate kick-drift-wrap and deposit
+_USE_KHALO = True     # ... and this for the plain flush (every tile cell through global atomics)
+_khalo_buffers = {}
+
+
+def _khalo_buffer(torch, ncells_1d, device):
+    """(n/8)(n/16)(n/16) tiles x 2 faces x 10 x 18 floats (pmstep.h: pm_kick_drift_wrap_deposit_khalo), kept per size."""
+    key = (str(device), ncells_1d)
+    buf = _khalo_buffers.get(key)
+    if buf is None:
+        _khalo_buffers.clear()
+        buf = _khalo_buffers[key] = torch.empty(((ncells_1d // 8) * (ncells_1d // 16) ** 2 * 360,), dtype=torch.float32,
+                                                device=device)
+    return buf
 
 
 def leapfrog(position, velocity, acceleration, potential, additional_field, dt, tables, param):
@@ -76,9 +89,18 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
             # the deposit of pm() rides on the streaming update (pmstep.h: pm_kick_drift_wrap_deposit)
             torch = L.require_gpu()
             density = torch.empty((ncells_1d,) * 3, dtype=torch.float32, device=position.device)
-            L.context(ncells_1d).call("pm_kick_drift_wrap_deposit", scheme, L.ptr(position), L.ptr(velocity),
-                                      L.ptr(acceleration), float(half_dt), float(np.float32(dt)), position.shape[0],
-                                      L.ptr(density))
+            if _USE_KHALO:
+                # the tiles' k-halo cells go to a side buffer with plain stores instead of one 64-byte
+                # read-modify-write each; solver.pm hands it to the FFT solve (or completes the density)
+                khalo = _khalo_buffer(torch, ncells_1d, position.device)
+                L.context(ncells_1d).call("pm_kick_drift_wrap_deposit_khalo", scheme, L.ptr(position), L.ptr(velocity),
+                                          L.ptr(acceleration), float(half_dt), float(np.float32(dt)),
+                                          position.shape[0], L.ptr(density), L.ptr(khalo))
+                density = (density, khalo)
+            else:
+                L.context(ncells_1d).call("pm_kick_drift_wrap_deposit", scheme, L.ptr(position), L.ptr(velocity),
+                                          L.ptr(acceleration), float(half_dt), float(np.float32(dt)),
+                                          position.shape[0], L.ptr(density))
         else:
             L.context(4).call("pm_kick_drift_wrap", L.ptr(position), L.ptr(velocity), L.ptr(acceleration),
                               float(half_dt), float(np.float32(dt)), position.shape[0])

@@ -61,8 +61,11 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     ctx.call("pm_tile_lists", L.ptr(pos_d), pos_d.shape[0])
     try:
         # TSC == TSC_seq here (solver.py:86-89)
+        khalo = None
         if _density is not None:
-            density = _density
+            # integration.leapfrog hands over the density its fused kick + drift + deposit made, possibly with
+            # the tiles' k-halo contributions still in a side buffer (pmstep.h: pm_kick_drift_wrap_deposit_khalo)
+            density, khalo = _density if isinstance(_density, tuple) else (_density, None)
         else:
             density = mesh.CIC(pos_d, ncells_1d) if MASS_SCHEME == "cic" else mesh.TSC(pos_d, ncells_1d)
 
@@ -76,7 +79,7 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
         fuse_gradient = fuse_gradient and lists_complete
         potential_d, additional_field_d, force = _solve_grid(density, param, _dev(potential),
                                                              _dev(additional_field), tables,
-                                                             want_force=not fuse_gradient)
+                                                             want_force=not fuse_gradient, khalo=khalo)
         del density
 
         if fuse_gradient:
@@ -102,7 +105,7 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     return acceleration.cpu().numpy(), potential_d.cpu().numpy(), additional_field_d.cpu().numpy()
 
 
-def _solve_grid(density, param, potential_d, additional_field_d, tables, want_force=True):
+def _solve_grid(density, param, potential_d, additional_field_d, tables, want_force=True, khalo=None):
     """Everything of pm() between the deposit and the interpolation, on a full [n,n,n] density grid:
     normalisation, [P(k)], extra field, rhs, Poisson solve, force.  Returns (potential, additional_field,
     force[n,n,n,3]).  Shared by the single-GPU pm() and the replicated grid solve of the slab layer
@@ -122,8 +125,16 @@ def _solve_grid(density, param, potential_d, additional_field_d, tables, want_fo
     else:
         param["parametrized_mu_z"] = np.float32(1)
 
+    # A k-halo side buffer is consumed by the fused FFT solve of the Newtonian path only (its z pass adds it
+    # while loading the density); every other consumer gets the completed density.
+    if khalo is not None and not (THEORY in ("newton", "parametrized") and _USE_FUSED_FFT and 32 <= ncells_1d <= 1024
+                                  and param["linear_newton_solver"].casefold() in ("fft", "fft_7pt")):
+        L.context(ncells_1d).call("pm_khalo_apply", L.ptr(density), L.ptr(khalo))
+        khalo = None
     if ncells_1d**3 != param["npart"]:
         utils.prod_vector_scalar_inplace(density, np.float32(ncells_1d**3 / param["npart"]))
+        if khalo is not None:
+            utils.prod_vector_scalar_inplace(khalo, np.float32(ncells_1d**3 / param["npart"]))
 
     SAVE_POWER_SPECTRUM = param["save_power_spectrum"].casefold()
     if SAVE_POWER_SPECTRUM == "yes":
@@ -136,6 +147,9 @@ def _solve_grid(density, param, potential_d, additional_field_d, tables, want_fo
         raise NotImplementedError(f"{SAVE_POWER_SPECTRUM=}, should be 'yes', 'z_out' or 'no'")
 
     LINEAR_NEWTON_SOLVER = param["linear_newton_solver"].casefold()
+    if khalo is not None and param["save_pk"]:  # the P(k) path transforms the density with rocFFT
+        L.context(ncells_1d).call("pm_khalo_apply", L.ptr(density), L.ptr(khalo))
+        khalo = None
     if param["save_pk"] and "multigrid" == LINEAR_NEWTON_SOLVER:  # solver.py:134-140
         density_fourier = fourier.fft_3D_real(density)
         k, Pk, Nmodes = fourier.fourier_grid_to_Pk(density_fourier, param["MAS_index"])
@@ -165,7 +179,7 @@ def _solve_grid(density, param, potential_d, additional_field_d, tables, want_fo
     elif LINEAR_NEWTON_SOLVER in ("fft", "fft_7pt"):
         if fold_scale:
             f1 = np.float32(1.5 * param["aexp"] * param["Om_m"] * param["parametrized_mu_z"])
-            potential_d = fft(rhs, param, _source_scale=f1)
+            potential_d = fft(rhs, param, _source_scale=f1, _khalo=khalo)
         else:
             potential_d = fft(rhs, param)
     elif LINEAR_NEWTON_SOLVER == "full_fft":
@@ -301,7 +315,7 @@ def rhs_poisson(density, additional_field, param) -> None:
         utils.linear_operator_inplace(density, f1, -f1)
 
 
-def fft(rhs, param, _source_scale=None):
+def fft(rhs, param, _source_scale=None, _khalo=None):
     """FFT Poisson solve (solver.py:453-522): r2c -> [P(k)] -> Green's function -> c2r.
     `_source_scale` (private) multiplies the Green's function: see the fold in pm()."""
     torch = L.require_gpu()
@@ -324,8 +338,14 @@ def fft(rhs, param, _source_scale=None):
     phi = torch.empty_like(rhs_d)
     if not want_pk and 32 <= n <= 1024 and _USE_FUSED_FFT:
         # five LDS-resident FFT passes with the Green's function inside the x pass (csrc/pm_fftpoisson.hip)
-        ctx.call("pm_poisson_fft_fused", kind, p, L.ptr(rhs_d), L.ptr(phi), L.hptr(k2), L.hptr(s), c0)
+        if _khalo is not None:
+            ctx.call("pm_poisson_fft_fused_khalo", kind, p, L.ptr(rhs_d), L.ptr(_khalo), L.ptr(phi), L.hptr(k2),
+                     L.hptr(s), c0)
+        else:
+            ctx.call("pm_poisson_fft_fused", kind, p, L.ptr(rhs_d), L.ptr(phi), L.hptr(k2), L.hptr(s), c0)
         return phi
+    if _khalo is not None:
+        raise RuntimeError("a k-halo buffer reached the unfused FFT path (solver._solve_grid should have applied it)")
     # three C-ABI calls (== pm_poisson_fft) so that per-stage event timing sees each of them
     rhs_fourier = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64, device=rhs_d.device)
     ctx.call("pm_fft_r2c", L.ptr(rhs_d), L.ptr(rhs_fourier))

@@ -285,6 +285,54 @@ def test_fused_kick_drift_wrap_deposit(amd, sorted_stream):
         np.testing.assert_array_equal(a_out.cpu().numpy(), oinv(orc.derivative(phi, 5), new_pos))
 
 
+@pytest.mark.parametrize("n,sorted_stream", [(32, True), (64, True), (128, True), (64, False)])
+def test_fused_kick_drift_wrap_deposit_khalo(amd, n, sorted_stream):
+    """pm_kick_drift_wrap_deposit_khalo: positions / velocities bit-exact with the plain form; density + the
+    k-halo buffer (pm_khalo_apply) == the oracle's deposit; and pm_poisson_fft_fused_khalo on the incomplete
+    density == pm_poisson_fft_fused on the complete one.  n = 32 has two tiles along k (both k-neighbours of a
+    tile are the same tile), the unsorted stream takes the re-deposit fallback (all-zero buffer)."""
+    from pysco_amd import _lib as L
+
+    rng = np.random.default_rng(5 + n)
+    pos, vel = zeldovich_particles(n, seed=n, rms_cells=1.0)
+    if sorted_stream:
+        pos, vel = amd.utils.reorder_particles(pos, vel)
+    acc = (rng.normal(size=pos.shape) * 0.3).astype(np.float32)
+    vel = (vel * np.float32(0.5 / max(np.abs(vel).max(), 1e-30) / n)).astype(np.float32)
+    half_dt, dt = np.float32(0.01), np.float32(1.3)
+    t = amd.torch
+    ctx = L.context(n)
+    nk = (n // 8) * (n // 16) ** 2 * 360
+    k2, s, c0 = amd.fourier.green_tables(n, L.GREEN_COMPENSATED)
+    for scheme_id, odep in ((L.TSC, orc.TSC), (L.CIC, orc.CIC)):
+        a_d = t.from_numpy(acc).cuda()
+        p_ref, v_ref = t.from_numpy(pos).cuda(), t.from_numpy(vel).cuda()
+        rho_ref = t.empty((n, n, n), dtype=t.float32, device="cuda")
+        ctx.call("pm_kick_drift_wrap_deposit", scheme_id, L.ptr(p_ref), L.ptr(v_ref), L.ptr(a_d), float(half_dt),
+                 float(dt), len(pos), L.ptr(rho_ref))
+        ctx.call("pm_tile_lists", None, 0)
+        p_d, v_d = t.from_numpy(pos).cuda(), t.from_numpy(vel).cuda()
+        rho = t.empty((n, n, n), dtype=t.float32, device="cuda")
+        kh = t.full((nk,), float("nan"), dtype=t.float32, device="cuda")  # every entry must be written
+        ctx.call("pm_kick_drift_wrap_deposit_khalo", scheme_id, L.ptr(p_d), L.ptr(v_d), L.ptr(a_d), float(half_dt),
+                 float(dt), len(pos), L.ptr(rho), L.ptr(kh))
+        ctx.call("pm_tile_lists", None, 0)
+        assert t.equal(p_d, p_ref) and t.equal(v_d, v_ref)
+        assert bool(t.isfinite(kh).all())
+        if sorted_stream:
+            assert float(kh.abs().sum()) > 0 and abs(float(rho.sum(dtype=t.float64)) - len(pos)) > 1.0  # really split
+        phi_k = t.empty_like(rho)
+        ctx.call("pm_poisson_fft_fused_khalo", L.GREEN_COMPENSATED, 3, L.ptr(rho), L.ptr(kh), L.ptr(phi_k), L.hptr(k2),
+                 L.hptr(s), c0)
+        ctx.call("pm_khalo_apply", L.ptr(rho), L.ptr(kh))
+        ref = odep(p_d.cpu().numpy(), n)
+        np.testing.assert_allclose(rho.cpu().numpy(), ref, rtol=0, atol=4e-6 * _scale(ref))
+        assert abs(float(rho.sum(dtype=t.float64)) - len(pos)) < 1e-5 * len(pos)
+        phi = t.empty_like(rho)
+        ctx.call("pm_poisson_fft_fused", L.GREEN_COMPENSATED, 3, L.ptr(rho_ref), L.ptr(phi), L.hptr(k2), L.hptr(s), c0)
+        np.testing.assert_allclose(phi_k.cpu().numpy(), phi.cpu().numpy(), rtol=0, atol=2e-6 * _scale(phi.cpu().numpy()))
+
+
 @pytest.mark.parametrize("n", [64, 128])
 def test_gradient_marching_kernel_bit_exact(amd, n):
     """n >= 128 takes the marching (2.5-D) gradient kernel: same bits as the oracle for every order."""

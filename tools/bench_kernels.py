@@ -116,6 +116,21 @@ def main():
                                         npart, L.ptr(rho)))
             rows.append((f"kick_drift_wrap + deposit {name}", t, (60 * npart + 4 * n**3) / t / 1e6))
         ctx.call("pm_tile_lists", None, 0)
+    if want("kdwdepk"):
+        from pysco_amd import fourier as F2
+        kh = torch.empty(((n // 8) * (n // 16) ** 2 * 360,), dtype=torch.float32, device="cuda")
+        t = timeit(lambda: ctx.call("pm_kick_drift_wrap_deposit_khalo", 3, L.ptr(pos), L.ptr(vel), L.ptr(acc), 1e-9, 1e-9,
+                                    npart, L.ptr(rho), L.ptr(kh)))
+        rows.append(("kick_drift_wrap + deposit TSC, k-halo buffer", t, (60 * npart + 4 * n**3) / t / 1e6))
+        ctx.call("pm_tile_lists", None, 0)
+        k2, s_, c0 = F2.green_tables(n, 1)
+        phi = torch.empty_like(rho)
+        t = timeit(lambda: ctx.call("pm_poisson_fft_fused", 1, 3, L.ptr(rho), L.ptr(phi), L.hptr(k2), L.hptr(s_), c0))
+        rows.append(("poisson_fft_fused", t, 48 * n**3 / t / 1e6))
+        t = timeit(lambda: ctx.call("pm_poisson_fft_fused_khalo", 1, 3, L.ptr(rho), L.ptr(kh), L.ptr(phi), L.hptr(k2),
+                                    L.hptr(s_), c0))
+        rows.append(("poisson_fft_fused_khalo", t, 48 * n**3 / t / 1e6))
+        del kh, phi
     if want("stream"):
         t = timeit(lambda: ctx.call("pm_kick_drift_wrap", L.ptr(pos), L.ptr(vel), L.ptr(acc), 1e-9, 1e-9, npart))
         rows.append(("kick_drift_wrap", t, 60 * npart / t / 1e6))
