@@ -161,16 +161,22 @@ int pm_tile_lists_info(pm_ctx *ctx, int64_t *stragglers, int64_t *np, int *compl
  * keeps them, so the gather of the same step reuses them.  Single-GPU layout, n >= 16, np < 2^32. */
 int pm_kick_drift_wrap_deposit(pm_ctx *ctx, int scheme, float *d_pos, float *d_vel, const float *d_acc,
                                float half_dt, float dt, int64_t np, float *d_rho);
-/* The same with the k-halo cells of the tiles kept out of d_rho.  The flush of a tile (8 x 16 x 16 cells + one
- * halo cell per side) adds to the density with global float atomics, which the memory side executes as one
- * 64-byte read-modify-write per touched sector: the two k-halo cells at the ends of every tile row cost one
- * request each, as much as the row's 16 own cells -- half of the flush.  Here the first-chunk workgroup of tile
- * (ti, tj, tk) writes them with plain stores to d_khalo[((ti*(n/16) + tj)*(n/16) + tk)][2 (low, high)][10][18]
- * ((n/8)(n/16)(n/16) * 360 floats, all written) and d_rho lacks exactly those contributions.  Consumers:
- * pm_poisson_fft_fused_khalo (adds them while its z pass loads the density) or pm_khalo_apply (completes d_rho). */
+/* The same with the halo cells of the tiles kept out of d_rho.  The flush of a tile (8 x 16 x 16 cells + one halo
+ * cell per side) adds to the density with global float atomics, which the memory side executes as one 64-byte
+ * read-modify-write per touched sector, whatever it carries: at 1024^3 the flush is 5 of the call's 17 ms, half
+ * of it the single k-halo cells at the two ends of every tile row.  Here the first workgroup of every tile uses
+ * no atomics: it STORES the tile's own cells into d_rho (which need not be cleared) and its halo cells into
+ * d_khalo (pm_khalo_floats(n) floats, every one written), laid out as
+ *   K  [tile column (ti, tj)][li 0..9][low, high][tk][lj 0..17] the k-halo cells,
+ *   Hi [tile column (ti, tj)][low, high][lj 0..17][k 0..n)     the i-halo planes (their cells inside in k),
+ *   Hj [tile column (ti, tj)][low, high][li 1..8][k 0..n)      the j-halo rows (inside in i and k);
+ * only surplus workgroups of over-full tiles and listed stragglers still add to d_rho atomically.  d_rho then
+ * lacks exactly the contributions held in d_khalo.  Consumers: pm_poisson_fft_fused_khalo (its z pass adds the
+ * buffer to the density lines it loads) or pm_khalo_apply (adds it into d_rho). */
 int pm_kick_drift_wrap_deposit_khalo(pm_ctx *ctx, int scheme, float *d_pos, float *d_vel, const float *d_acc,
                                      float half_dt, float dt, int64_t np, float *d_rho, float *d_khalo);
 int pm_khalo_apply(pm_ctx *ctx, float *d_rho, const float *d_khalo);
+int64_t pm_khalo_floats(int n);
 /* The same on a slab (pm_set_slab, pm_set_tile_window in force): d_rho is the rank's [nx_slab, n, n] density
  * array, which must be wide enough (ghost planes) for the footprint of every particle AFTER the drift -- the
  * caller bounds the drift (it knows dt, max|v|, max|a|) and chooses the ghost width; the particles whose new x

@@ -66,6 +66,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_kick_drift_wrap_deposit": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp),
     "pm_kick_drift_wrap_deposit_khalo": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _vp),
     "pm_khalo_apply": (_vp, _vp, _vp),
+    "pm_khalo_floats": (_i,),
     "pm_kick_drift_wrap_deposit_slab": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _f, _f, _vp, _i, C.POINTER(_i)),
     "pm_gradient_interp_kick": (_vp, _i, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _f),
     "pm_last_maxabs": (_vp, C.POINTER(_f), C.POINTER(_f)),
@@ -109,7 +110,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_fft1d_x": (_vp, _vp, _i64, _i),
     "pm_greens_slab": (_vp, _i, _i, _vp, _vp, _vp, _f, _i, _i),
 }
-_RESTYPES = {"pm_last_error": C.c_char_p}
+_RESTYPES = {"pm_last_error": C.c_char_p, "pm_khalo_floats": C.c_int64}
 
 _lib = None
 

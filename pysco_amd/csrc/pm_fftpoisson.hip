@@ -360,17 +360,26 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
             });
         __syncthreads();
     };
-    // fill + k-halo: two straight-line variants (interior row of the tile column / row on an i face) of the
-    // whole front of the kernel, so that the k-halo loads stay in flight across the density loads (with the
-    // face test inside, every pair of loads got its own basic block and vmcnt(0); joined after a branch, the
-    // loaded values were copied -- and waited for -- at the join)
+    // fill + halo buffer: two straight-line variants (interior row of the tile column / row on an i face) of the
+    // whole front of the kernel, so that the halo loads stay in flight across the density loads (with the face
+    // test inside, every pair of loads got its own basic block and vmcnt(0); joined after a branch, the loaded
+    // values were copied -- and waited for -- at the join).
+    // The buffer (pm_particles.hip, HaloBuf) has three parts: K [tile column][li][low|high][tk][lj] (the k-halo cells),
+    // Hi [tile column][low|high][lj 0..17][k] and Hj [tile column][low|high][li 1..8][k] (whole lines along k).
+    // The 16 lines (x, y0 .. y0 + 15) of this workgroup are row li = x % 8 + 1 of tile column (x / 8, y0 / 16):
+    //  * line y0 also receives the high j-halo row of column tj - 1, line y0 + 15 the low one of tj + 1 (Hj);
+    //  * on an i face (x % 8 == 0 or 7) every line receives a row of the neighbouring column's i-halo plane
+    //    (Hi, lj = 1..16), and lines y0 / y0 + 15 the edge rows lj = 17 / 0 of the diagonal columns;
+    //  * K as before.
     auto front = [&](auto with_iface) {
         constexpr bool IFACE = decltype(with_iface)::value;
-        const int Ti = n >> 3;
+        const int Ti = n >> 3, nq = n >> 2;
         const int x = (int)(line0 >> log2n), y0 = (int)(line0 & (n - 1));
         const int ti = x >> 3, tj = y0 >> 4, xi = x & 7;
-        const int di = xi == 0 ? -1 : 1;
+        const int di = xi == 0 ? -1 : 1, iside = xi == 0 ? 1 : 0;  // the neighbour's high plane (li = 9) or low one (li = 0)
         const int tin = (ti + di + Ti) % Ti, lin = xi + 1 - 8 * di;
+        const int64_t nk = ((int64_t)n * n * n >> 11) * 360;
+        const float *hi = khalo + nk, *hj = hi + (int64_t)Ti * kT * 36 * n;
         float kraw[KH_PER_THREAD][IFACE ? 4 : 2];  // own tile column, its j-face neighbour[, the i-face one, the edge one]
 #pragma unroll
         for (int u = 0; u < KH_PER_THREAD; ++u) {
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
             const bool jf = rl == 0 || rl == 15;
             const int tjn = rl == 0 ? (tj + kT - 1) % kT : (tj + 1) % kT, ljn = rl == 0 ? 17 : 0;
             auto at = [&](int tii, int tjj, int li, int lj) {
-                return khalo[((((int64_t)tii * kT + tjj) * kT + tk) * 2 + side) * 180 + li * 18 + lj];
+                return khalo[(((((int64_t)tii * kT + tjj) * 10 + li) * 2 + side) * kT + tk) * 18 + lj];
             };
             // unconditional loads: off the j faces the second one re-reads the first entry and is dropped
             const int tj2 = jf ? tjn : tj, lj2 = jf ? ljn : rl + 1;
@@ -388,9 +397,24 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
             kraw[u][1] = at(ti, tj2, xi + 1, lj2);
             if (IFACE) kraw[u][2] = at(tin, tj, lin, rl + 1), kraw[u][3] = at(tin, tj2, lin, lj2);
         }
+        // j-halo rows for lines 0 and 15 (+ the edge rows on an i face): one quad per thread (2 n / 4 <= FBLK)
+        const int jt = min((int)threadIdx.x, 2 * nq - 1), jw = jt / nq, jq = jt - jw * nq;
+        const int tjx = jw ? (tj + 1) % kT : (tj + kT - 1) % kT;
+        fft_v4f jv = *reinterpret_cast<const fft_v4f *>(hj + ((((int64_t)ti * kT + tjx) * 2 + (jw ? 0 : 1)) * 8 + xi) * n + 4 * jq);
+        fft_v4f ev = {0.f, 0.f, 0.f, 0.f};
+        if (IFACE)
+            ev = *reinterpret_cast<const fft_v4f *>(hi + ((((int64_t)tin * kT + tjx) * 2 + iside) * 18 + (jw ? 0 : 17)) * n + 4 * jq);
+        // the neighbouring column's i-halo plane, one row per line: fetched here too (8 quads per thread)
+        fft_v4f iv[IFACE ? 8 : 1];
+        if (IFACE) {
+            const float *src = hi + (((int64_t)tin * kT + tj) * 2 + iside) * 18 * n + n;  // row lj = 1
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                iv[u] = *reinterpret_cast<const fft_v4f *>(src + 4 * (int64_t)min((int)threadIdx.x + u * FBLK, 16 * nq - 1));
+        }
         fill();
 #pragma unroll
-        for (int u = 0; u < KH_PER_THREAD; ++u) {  // the 2 x T boundary cells of each of the 16 lines
+        for (int u = 0; u < KH_PER_THREAD; ++u) {  // K: the 2 x T boundary cells of each of the 16 lines
             const int idx = threadIdx.x + u * FBLK;
             if (idx < 32 * kT) {
                 const int rl = idx & 15, sm = idx >> 4, side = sm >= kT, m = sm - (side ? kT : 0);
@@ -402,6 +426,23 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
             }
         }
         __syncthreads();
+        auto add4 = [&](int rl, int z0, fft_v4f v) {
+            float *dst = reinterpret_cast<float *>(buf + (rl >> 1) * NP(n) + PADI(z0)) + (rl & 1);
+            dst[0] += v.x, dst[2] += v.y, dst[4] += v.z, dst[6] += v.w;
+        };
+        if ((int)threadIdx.x < 2 * nq) add4(jw ? 15 : 0, 4 * jq, IFACE ? jv + ev : jv);
+        __syncthreads();
+        if (IFACE) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = threadIdx.x + u * FBLK;
+                if (t < 16 * nq) {
+                    const int rl = t / nq;
+                    add4(rl, (t - rl * nq) << 2, iv[u]);
+                }
+            }
+            __syncthreads();
+        }
     };
     if (!khalo)
         fill();

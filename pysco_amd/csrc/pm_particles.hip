@@ -705,6 +705,7 @@ struct TileWork {
     unsigned ntiles;        // tiles of the whole mesh (size of the tables)
     unsigned nlaunch;       // first-chunk workgroups = tiles inside the particle window (== ntiles on a single GPU)
     int ti0, lnti, lT;      // window: first tile in x, log2 of its tiles in x, log2 of the tiles per side in y / z
+    unsigned boff;          // workgroup index = blockIdx.x + boff (a launch of the surplus workgroups only)
 };
 
 // Incoming stragglers per tile (pm_tile_lists): particles that the sorted order files under another
@@ -743,7 +744,7 @@ __device__ __forceinline__ unsigned tile_key_of_block(unsigned b, const TileWork
 }
 
 __device__ __forceinline__ bool tile_work_item(const TileWork &w, unsigned &key, int64_t &s, int64_t &e) {
-    const unsigned b = blockIdx.x;
+    const unsigned b = blockIdx.x + w.boff;
     if (b < w.nlaunch) {
         key = tile_key_of_block(b, w);
         s = w.start[key];
@@ -770,7 +771,7 @@ __device__ __forceinline__ bool tile_work_item(const TileWork &w, unsigned &key,
 static void tile_window(const pm_ctx *c, TileWork *w) {
     const int n = c->n;
     w->ntiles = (unsigned)(((int64_t)n * n * n) >> (PM_LI + PM_LJ + PM_LK));
-    w->nlaunch = w->ntiles, w->ti0 = 0, w->lnti = 0, w->lT = 0;
+    w->nlaunch = w->ntiles, w->ti0 = 0, w->lnti = 0, w->lT = 0, w->boff = 0;
     const int nti = c->tile_nx >> PM_LI, T = n >> PM_LJ;
     if (c->tile_nx < n && nti >= 1 && (nti & (nti - 1)) == 0 && (c->tile_x_lo % PM_TI) == 0 && (c->tile_nx % PM_TI) == 0) {
         w->ti0 = c->tile_x_lo >> PM_LI;
@@ -1136,7 +1137,23 @@ __global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__rest
 // (pm_tile_lists semantics) for the gather of the same step.
 
 constexpr int PM_SCAP = 1024;  // stragglers staged in LDS per workgroup before the global append
-constexpr int PM_KHALO_TILE = 2 * PM_HI * PM_HJ;  // floats per tile in the k-halo buffer: [low | high][li][lj]
+// Halo buffer of the fused kick + drift + deposit (pmstep.h: pm_kick_drift_wrap_deposit_khalo), three parts:
+//   K  [tile column (ti, tj)][li 0..9][low | high][tk][lj 0..17]   the k-halo cells (lk = 0, 17) of every tile
+//   Hi [tile column (ti, tj)][low | high][lj 0..17][k 0..n)         the i-halo planes (li = 0, 9), lk = 1..16
+//   Hj [tile column (ti, tj)][low | high][li 1..8][k 0..n)          the j-halo rows (lj = 0, 17), li and lk inside
+// Hi and Hj are whole lines along k, so that the FFT's z pass adds them to the density lines it loads.
+constexpr int PM_KHALO_TILE = 2 * PM_HI * PM_HJ;  // floats per tile in K
+struct HaloBuf {
+    float *k, *hi, *hj;
+};
+__host__ __device__ inline int64_t halo_k_floats(int n) { return ((int64_t)n * n * n >> (PM_LI + PM_LJ + PM_LK)) * PM_KHALO_TILE; }
+__host__ __device__ inline int64_t halo_i_floats(int n) { return (int64_t)(n >> PM_LI) * (n >> PM_LJ) * 2 * PM_HJ * n; }
+__host__ __device__ inline int64_t halo_j_floats(int n) { return (int64_t)(n >> PM_LI) * (n >> PM_LJ) * 2 * PM_TI * n; }
+static HaloBuf halo_parts(float *base, int n) {
+    HaloBuf h;
+    h.k = base, h.hi = base ? base + halo_k_floats(n) : nullptr, h.hj = base ? h.hi + halo_i_floats(n) : nullptr;
+    return h;
+}
 
 // slab decomposition: particles whose new x leaves [x_lo, x_hi) are listed for the migration (idx == NULL: off)
 struct Leavers {
@@ -1152,21 +1169,30 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
                                                           TileWork work, pm_geom geo, float *__restrict__ rho,
                                                           unsigned *__restrict__ lkeys, unsigned *__restrict__ lidx,
                                                           unsigned subcap, unsigned *__restrict__ counts, Leavers lv,
-                                                          float *__restrict__ khalo) {
+                                                          HaloBuf halo) {
     unsigned key;
     int64_t s, e;
-    // k-halo buffer (pm_kick_drift_wrap_deposit_khalo): the first-chunk workgroup of tile (ti, tj, tk) owns
-    // khalo[((ti Tj + tj) Tk + tk)][2][PM_HI PM_HJ] and writes all of it, empty tile or not
-    const bool first_chunk = blockIdx.x < work.nlaunch;
-    float *kt = nullptr;
-    if (khalo && first_chunk) {
-        const TileId t0 = tile_of_key(tile_key_of_block(blockIdx.x, work));
-        const int T = geo.n >> PM_LJ;
-        kt = khalo + ((size_t)(t0.ti * T + t0.tj) * T + t0.tk) * PM_KHALO_TILE;
-    }
+    // Halo buffer: the first-chunk workgroup of a tile owns the tile's entries of K, Hi, Hj and the tile's own
+    // cells of rho, and writes all of them with plain stores, empty tile or not (rho is not cleared first).
+    const bool owner = halo.k && (blockIdx.x + work.boff) < work.nlaunch;
+    const int n_ = geo.n, T_ = n_ >> PM_LJ;
+    TileId t0{0, 0, 0};
+    if (owner) t0 = tile_of_key(tile_key_of_block(blockIdx.x + work.boff, work));
+    auto halo_store = [&](int c, float v) {  // cell c of the haloed tile t0
+        const int lij = c / PM_HK, lk = c - lij * PM_HK, li = lij / PM_HJ, lj = lij - li * PM_HJ;
+        const int64_t col = (int64_t)t0.ti * T_ + t0.tj;
+        if (lk == 0 || lk == PM_HK - 1)
+            halo.k[(((col * PM_HI + li) * 2 + (lk ? 1 : 0)) * T_ + t0.tk) * PM_HJ + lj] = v;
+        else if (li == 0 || li == PM_HI - 1)
+            halo.hi[((col * 2 + (li ? 1 : 0)) * PM_HJ + lj) * n_ + t0.tk * PM_TK + lk - 1] = v;
+        else if (lj == 0 || lj == PM_HJ - 1)
+            halo.hj[((col * 2 + (lj ? 1 : 0)) * PM_TI + (li - 1)) * n_ + t0.tk * PM_TK + lk - 1] = v;
+        else
+            rho[pm_cell(geo, t0.ti * PM_TI - 1 + li, t0.tj * PM_TJ - 1 + lj, t0.tk * PM_TK - 1 + lk)] = v;
+    };
     if (!tile_work_item(work, key, s, e)) {
-        if (kt)
-            for (int c = threadIdx.x; c < PM_KHALO_TILE; c += BLK) kt[c] = 0.f;
+        if (owner)
+            for (int c = threadIdx.x; c < PM_TILE; c += BLK) halo_store(c, 0.f);
         return;
     }
     __shared__ pm_acc_t tile[PM_TILE];  // 25.9 KB
@@ -1227,15 +1253,15 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
     }
     __syncthreads();
     // Flush.  The global float atomics execute at the memory side as 64-byte read-modify-writes, one per
-    // touched 64-byte sector whatever it carries: a row's 16 own cells are one request, but the two k-halo
-    // cells at its ends are one request each -- 360 of a tile's 540 requests and half of the flush time
-    // (2.5 of 5.0 ms at 1024^3, measured by leaving them out).  With a k-halo buffer they go there as plain
-    // coalesced stores and reach the density when the z pass of the FFT loads it (pm_fftpoisson.hip).
+    // touched 64-byte sector whatever it carries (at 1024^3 the flush was 5.0 of the kernel's 16.8 ms: 2.5 the
+    // single k-halo cells at the ends of every row, 2.3 the rows of own cells, 0.2 the i/j-halo rows; without
+    // it the kernel runs at the speed of the plain streaming update).  With a halo buffer the owner of a tile
+    // uses no atomics at all: own cells are stored, halo cells go to the buffer, and the z pass of the FFT
+    // adds the buffer to the density lines it loads (pm_fftpoisson.hip).
     for (int c = tid; c < PM_TILE; c += BLK) {
         const pm_acc_t w = tile[c];
-        const int lij = c / PM_HK, lk = c - lij * PM_HK;
-        if (kt && (lk == 0 || lk == PM_HK - 1))
-            kt[(lk ? PM_HI * PM_HJ : 0) + lij] = weight_of_acc(w);
+        if (owner)
+            halo_store(c, weight_of_acc(w));
         else if (w != 0)
             unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), weight_of_acc(w));
     }
@@ -1292,10 +1318,24 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     rc = list_bufs(c, np, ntiles, &b);
     if (rc) return rc;
     const size_t cells = (size_t)c->slab_nx * c->n * c->n;
-    PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));
+    const HaloBuf halo = halo_parts(khalo, c->n);
+    if (!khalo) PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));  // owners store every cell otherwise
     PM_HIP(hipMemsetAsync(b.counts, 0, PM_NSUB * PM_SUB_STRIDE * sizeof(unsigned), c->stream));
-    hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, vel, acc, -half_dt, dt, work,
-                       pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv, khalo);
+    if (!khalo) {
+        hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, vel, acc, -half_dt, dt,
+                           work, pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv, halo);
+    } else {
+        // owners first (plain stores), then the surplus workgroups of over-full tiles, which add with atomics
+        hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME>), dim3(work.nlaunch), dim3(BLK), 0, c->stream, pos, vel, acc, -half_dt,
+                           dt, work, pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv, halo);
+        if (blocks > work.nlaunch) {
+            TileWork extra = work;
+            extra.boff = work.nlaunch;
+            hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME>), dim3(blocks - work.nlaunch), dim3(BLK), 0, c->stream, pos, vel,
+                               acc, -half_dt, dt, extra, pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv,
+                               halo);
+        }
+    }
     PM_LAUNCH_CHECK();
     const unsigned *idx = nullptr;
     unsigned listed = 0;
@@ -1309,7 +1349,9 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
         // updated; deposit them again from scratch with the kernels that serve stragglers themselves.
         c->lists_pos = nullptr;
         PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));
-        if (khalo) PM_HIP(hipMemsetAsync(khalo, 0, (size_t)ntiles * PM_KHALO_TILE * sizeof(float), c->stream));
+        if (khalo)
+            PM_HIP(hipMemsetAsync(khalo, 0, (size_t)(halo_k_floats(c->n) + halo_i_floats(c->n) + halo_j_floats(c->n)) * sizeof(float),
+                                  c->stream));
         hipLaunchKernelGGL((deposit_tiled_kernel<SCHEME>), dim3((unsigned)((np + PM_CHUNK - 1) / PM_CHUNK)), dim3(BLK), 0,
                            c->stream, pos, np, pm_ctx_geom(c), rho);
         PM_LAUNCH_CHECK();
@@ -1355,31 +1397,56 @@ extern "C" int pm_kick_drift_wrap_deposit_khalo(pm_ctx *c, int scheme, float *d_
                               d_khalo);
 }
 
-// d_rho += the k-halo buffer: completes a density deposited by pm_kick_drift_wrap_deposit_khalo for consumers
-// other than pm_poisson_fft_fused_khalo (one global atomic per entry, as the flush would have done)
-__global__ __launch_bounds__(BLK) void khalo_apply_kernel(const float *__restrict__ khalo, pm_geom geo,
-                                                         float *__restrict__ rho) {
-    const int T = geo.n >> PM_LJ;
-    const int64_t total = (int64_t)(geo.n >> PM_LI) * T * T * PM_KHALO_TILE;
-    for (int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLK) {
-        const float v = khalo[e];
-        if (v == 0.f) continue;
-        const int r = (int)(e % PM_KHALO_TILE);
-        int64_t tile = e / PM_KHALO_TILE;
-        const int tk = (int)(tile % T), tj = (int)((tile / T) % T), ti = (int)(tile / ((int64_t)T * T));
-        const int side = r / (PM_HI * PM_HJ), lij = r - side * (PM_HI * PM_HJ), li = lij / PM_HJ, lj = lij - li * PM_HJ;
-        unsafeAtomicAdd(rho + pm_cell(geo, ti * PM_TI - 1 + li, tj * PM_TJ - 1 + lj, tk * PM_TK - 1 + (side ? PM_HK - 1 : 0)), v);
+// d_rho += the halo buffer: completes a density deposited by pm_kick_drift_wrap_deposit_khalo for consumers
+// other than pm_poisson_fft_fused_khalo (one global atomic per non-zero entry, as the flush would have done)
+__global__ __launch_bounds__(BLK) void khalo_apply_kernel(HaloBuf halo, pm_geom geo, float *__restrict__ rho) {
+    const int n = geo.n, T = n >> PM_LJ;
+    const int64_t nk = halo_k_floats(n), ni = halo_i_floats(n), nj = halo_j_floats(n);
+    for (int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x; e < nk + ni + nj; e += (int64_t)gridDim.x * BLK) {
+        float v;
+        int gi, gj, gk;
+        if (e < nk) {
+            v = halo.k[e];  // (((col * 10 + li) * 2 + side) * T + tk) * 18 + lj
+            const int lj = (int)(e % PM_HJ);
+            int64_t r = e / PM_HJ;
+            const int tk = (int)(r % T);
+            r /= T;
+            const int side = (int)(r & 1), li = (int)((r >> 1) % PM_HI);
+            const int64_t col = (r >> 1) / PM_HI;
+            gi = (int)(col / T) * PM_TI - 1 + li, gj = (int)(col % T) * PM_TJ - 1 + lj, gk = tk * PM_TK - 1 + (side ? PM_HK - 1 : 0);
+        } else if (e < nk + ni) {
+            const int64_t f = e - nk;
+            v = halo.hi[f];
+            gk = (int)(f % n);
+            const int64_t row = f / n;  // ((col * 2 + side) * 18 + lj)
+            const int lj = (int)(row % PM_HJ), side = (int)((row / PM_HJ) & 1);
+            const int64_t col = row / (2 * PM_HJ);
+            gi = (int)(col / T) * PM_TI - 1 + (side ? PM_HI - 1 : 0), gj = (int)(col % T) * PM_TJ - 1 + lj;
+        } else {
+            const int64_t f = e - nk - ni;
+            v = halo.hj[f];
+            gk = (int)(f % n);
+            const int64_t row = f / n;  // ((col * 2 + side) * 8 + li - 1)
+            const int li = (int)(row % PM_TI) + 1, side = (int)((row / PM_TI) & 1);
+            const int64_t col = row / (2 * PM_TI);
+            gi = (int)(col / T) * PM_TI - 1 + li, gj = (int)(col % T) * PM_TJ - 1 + (side ? PM_HJ - 1 : 0);
+        }
+        if (v != 0.f) unsafeAtomicAdd(rho + pm_cell(geo, gi, gj, gk), v);
     }
 }
 
 extern "C" int pm_khalo_apply(pm_ctx *c, float *d_rho, const float *d_khalo) {
     PM_REQUIRE(c && d_rho && d_khalo, "NULL argument");
     PM_REQUIRE(c->n >= 16 && c->slab_nx == c->n, "pm_khalo_apply is the single-GPU form");
-    const int64_t total = ((int64_t)c->n * c->n * c->n >> (PM_LI + PM_LJ + PM_LK)) * PM_KHALO_TILE;
-    hipLaunchKernelGGL(khalo_apply_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_khalo, pm_ctx_geom(c),
-                       d_rho);
+    const int64_t total = halo_k_floats(c->n) + halo_i_floats(c->n) + halo_j_floats(c->n);
+    hipLaunchKernelGGL(khalo_apply_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream,
+                       halo_parts(const_cast<float *>(d_khalo), c->n), pm_ctx_geom(c), d_rho);
     PM_LAUNCH_CHECK();
     return PM_OK;
+}
+
+extern "C" int64_t pm_khalo_floats(int n) {
+    return n >= 16 ? halo_k_floats(n) + halo_i_floats(n) + halo_j_floats(n) : 0;
 }
 
 // The same on a slab (pm_set_slab: d_rho is [nx_slab, n, n] starting at global plane x0, wide enough for

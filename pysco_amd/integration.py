@@ -63,12 +63,12 @@ _khalo_buffers = {}
 
 
 def _khalo_buffer(torch, ncells_1d, device):
-    """(n/8)(n/16)(n/16) tiles x 2 faces x 10 x 18 floats (pmstep.h: pm_kick_drift_wrap_deposit_khalo), kept per size."""
+    """The halo side buffer of pm_kick_drift_wrap_deposit_khalo (pmstep.h; 0.58 n^3 floats), kept per size."""
     key = (str(device), ncells_1d)
     buf = _khalo_buffers.get(key)
     if buf is None:
         _khalo_buffers.clear()
-        buf = _khalo_buffers[key] = torch.empty(((ncells_1d // 8) * (ncells_1d // 16) ** 2 * 360,), dtype=torch.float32,
+        buf = _khalo_buffers[key] = torch.empty((int(L.load_library().pm_khalo_floats(ncells_1d)),), dtype=torch.float32,
                                                 device=device)
     return buf
 
@@ -90,8 +90,9 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
             torch = L.require_gpu()
             density = torch.empty((ncells_1d,) * 3, dtype=torch.float32, device=position.device)
             if _USE_KHALO:
-                # the tiles' k-halo cells go to a side buffer with plain stores instead of one 64-byte
-                # read-modify-write each; solver.pm hands it to the FFT solve (or completes the density)
+                # the tiles' halo cells go to a side buffer and the own cells to the density, all with plain
+                # stores instead of memory-side atomics; solver.pm hands the buffer to the FFT solve (or has
+                # it added to the density)
                 khalo = _khalo_buffer(torch, ncells_1d, position.device)
                 L.context(ncells_1d).call("pm_kick_drift_wrap_deposit_khalo", scheme, L.ptr(position), L.ptr(velocity),
                                           L.ptr(acceleration), float(half_dt), float(np.float32(dt)),

@@ -285,7 +285,7 @@ def test_fused_kick_drift_wrap_deposit(amd, sorted_stream):
         np.testing.assert_array_equal(a_out.cpu().numpy(), oinv(orc.derivative(phi, 5), new_pos))
 
 
-@pytest.mark.parametrize("n,sorted_stream", [(32, True), (64, True), (128, True), (64, False)])
+@pytest.mark.parametrize("n,sorted_stream", [(32, True), (64, True), (128, True), (64, False), (64, "clustered")])
 def test_fused_kick_drift_wrap_deposit_khalo(amd, n, sorted_stream):
     """pm_kick_drift_wrap_deposit_khalo: positions / velocities bit-exact with the plain form; density + the
     k-halo buffer (pm_khalo_apply) == the oracle's deposit; and pm_poisson_fft_fused_khalo on the incomplete
@@ -295,6 +295,8 @@ def test_fused_kick_drift_wrap_deposit_khalo(amd, n, sorted_stream):
 
     rng = np.random.default_rng(5 + n)
     pos, vel = zeldovich_particles(n, seed=n, rms_cells=1.0)
+    if sorted_stream == "clustered":  # 64x the mean density in 1/64 of the box: tiles of 30+ chunks (surplus workgroups)
+        pos = ((pos * np.float32(0.25)) % np.float32(1.0)).astype(np.float32)
     if sorted_stream:
         pos, vel = amd.utils.reorder_particles(pos, vel)
     acc = (rng.normal(size=pos.shape) * 0.3).astype(np.float32)
@@ -302,7 +304,7 @@ def test_fused_kick_drift_wrap_deposit_khalo(amd, n, sorted_stream):
     half_dt, dt = np.float32(0.01), np.float32(1.3)
     t = amd.torch
     ctx = L.context(n)
-    nk = (n // 8) * (n // 16) ** 2 * 360
+    nk = int(L.load_library().pm_khalo_floats(n))
     k2, s, c0 = amd.fourier.green_tables(n, L.GREEN_COMPENSATED)
     for scheme_id, odep in ((L.TSC, orc.TSC), (L.CIC, orc.CIC)):
         a_d = t.from_numpy(acc).cuda()
@@ -312,8 +314,8 @@ def test_fused_kick_drift_wrap_deposit_khalo(amd, n, sorted_stream):
                  float(dt), len(pos), L.ptr(rho_ref))
         ctx.call("pm_tile_lists", None, 0)
         p_d, v_d = t.from_numpy(pos).cuda(), t.from_numpy(vel).cuda()
-        rho = t.empty((n, n, n), dtype=t.float32, device="cuda")
-        kh = t.full((nk,), float("nan"), dtype=t.float32, device="cuda")  # every entry must be written
+        rho = t.full((n, n, n), float("nan"), dtype=t.float32, device="cuda")  # every cell must be written
+        kh = t.full((nk,), float("nan"), dtype=t.float32, device="cuda")       # ... and every buffer entry
         ctx.call("pm_kick_drift_wrap_deposit_khalo", scheme_id, L.ptr(p_d), L.ptr(v_d), L.ptr(a_d), float(half_dt),
                  float(dt), len(pos), L.ptr(rho), L.ptr(kh))
         ctx.call("pm_tile_lists", None, 0)
@@ -321,6 +323,8 @@ def test_fused_kick_drift_wrap_deposit_khalo(amd, n, sorted_stream):
         assert bool(t.isfinite(kh).all())
         if sorted_stream:
             assert float(kh.abs().sum()) > 0 and abs(float(rho.sum(dtype=t.float64)) - len(pos)) > 1.0  # really split
+        # rho was not cleared by the call: the owners' plain stores must have covered every cell
+        assert bool(t.isfinite(rho).all())
         phi_k = t.empty_like(rho)
         ctx.call("pm_poisson_fft_fused_khalo", L.GREEN_COMPENSATED, 3, L.ptr(rho), L.ptr(kh), L.ptr(phi_k), L.hptr(k2),
                  L.hptr(s), c0)

@@ -118,7 +118,7 @@ def main():
         ctx.call("pm_tile_lists", None, 0)
     if want("kdwdepk"):
         from pysco_amd import fourier as F2
-        kh = torch.empty(((n // 8) * (n // 16) ** 2 * 360,), dtype=torch.float32, device="cuda")
+        kh = torch.empty((int(L.load_library().pm_khalo_floats(n)),), dtype=torch.float32, device="cuda")
         t = timeit(lambda: ctx.call("pm_kick_drift_wrap_deposit_khalo", 3, L.ptr(pos), L.ptr(vel), L.ptr(acc), 1e-9, 1e-9,
                                     npart, L.ptr(rho), L.ptr(kh)))
         rows.append(("kick_drift_wrap + deposit TSC, k-halo buffer", t, (60 * npart + 4 * n**3) / t / 1e6))
