@@ -285,7 +285,7 @@ def test_fused_kick_drift_wrap_deposit(amd, sorted_stream):
         np.testing.assert_array_equal(a_out.cpu().numpy(), oinv(orc.derivative(phi, 5), new_pos))
 
 
-@pytest.mark.parametrize("n,sorted_stream", [(32, True), (64, True), (128, True), (64, False), (64, "clustered")])
+@pytest.mark.parametrize("n,sorted_stream", [(16, True), (32, True), (64, True), (128, True), (64, False), (64, "clustered")])
 def test_fused_kick_drift_wrap_deposit_khalo(amd, n, sorted_stream):
     """pm_kick_drift_wrap_deposit_khalo: positions / velocities bit-exact with the plain form; density + the
     k-halo buffer (pm_khalo_apply) == the oracle's deposit; and pm_poisson_fft_fused_khalo on the incomplete
@@ -326,15 +326,18 @@ def test_fused_kick_drift_wrap_deposit_khalo(amd, n, sorted_stream):
         # rho was not cleared by the call: the owners' plain stores must have covered every cell
         assert bool(t.isfinite(rho).all())
         phi_k = t.empty_like(rho)
-        ctx.call("pm_poisson_fft_fused_khalo", L.GREEN_COMPENSATED, 3, L.ptr(rho), L.ptr(kh), L.ptr(phi_k), L.hptr(k2),
-                 L.hptr(s), c0)
+        if n >= 32:  # the LDS-FFT passes start at n = 32; below, pm_khalo_apply is the only consumer
+            ctx.call("pm_poisson_fft_fused_khalo", L.GREEN_COMPENSATED, 3, L.ptr(rho), L.ptr(kh), L.ptr(phi_k), L.hptr(k2),
+                     L.hptr(s), c0)
         ctx.call("pm_khalo_apply", L.ptr(rho), L.ptr(kh))
         ref = odep(p_d.cpu().numpy(), n)
         np.testing.assert_allclose(rho.cpu().numpy(), ref, rtol=0, atol=4e-6 * _scale(ref))
         assert abs(float(rho.sum(dtype=t.float64)) - len(pos)) < 1e-5 * len(pos)
-        phi = t.empty_like(rho)
-        ctx.call("pm_poisson_fft_fused", L.GREEN_COMPENSATED, 3, L.ptr(rho_ref), L.ptr(phi), L.hptr(k2), L.hptr(s), c0)
-        np.testing.assert_allclose(phi_k.cpu().numpy(), phi.cpu().numpy(), rtol=0, atol=2e-6 * _scale(phi.cpu().numpy()))
+        if n >= 32:
+            phi = t.empty_like(rho)
+            ctx.call("pm_poisson_fft_fused", L.GREEN_COMPENSATED, 3, L.ptr(rho_ref), L.ptr(phi), L.hptr(k2), L.hptr(s), c0)
+            np.testing.assert_allclose(phi_k.cpu().numpy(), phi.cpu().numpy(), rtol=0,
+                                       atol=2e-6 * _scale(phi.cpu().numpy()))
 
 
 @pytest.mark.parametrize("n", [64, 128])
