@@ -491,6 +491,39 @@ def test_integrate_vs_golden(amd, golden, integ, nsteps, resident):
         amd.integration.integrate(p, v, acc, pot, extra, tables, param, t_next)
 
 
+@pytest.mark.parametrize("theory_solver", [("newton", "fft"), ("newton", "fft_7pt"), ("newton", "multigrid")])
+def test_leapfrog_halo_buffer_vs_plain_flush(amd, theory_solver):
+    """integration.leapfrog with the halo side buffer (pm_kick_drift_wrap_deposit_khalo + the FFT solve that
+    consumes it, or pm_khalo_apply for the other solvers) against the plain atomic flush: same trajectories.
+    The particle number differs from the cell number, so the density normalisation also scales the buffer."""
+    import bench
+
+    n, npart_1d = 64, 48
+    t = amd.torch
+    pos_h, vel_h = zeldovich_particles(npart_1d, seed=11, rms_cells=0.6)
+    tables = bench.synth_tables()
+    out = {}
+    for use in (True, False):
+        amd.integration._USE_KHALO = use
+        try:
+            param, _ = bench.make_param(n, npart_1d**3)
+            param["theory"], param["linear_newton_solver"] = theory_solver
+            param.update({"Npre": 2, "Npost": 1, "epsrel": 1e-2, "ncoarse": 6, "tolerance": 1e-20})
+            pos, vel = t.from_numpy(pos_h).cuda(), t.from_numpy(vel_h * np.float32(0.02)).cuda()
+            pos, vel = amd.utils.reorder_particles(pos, vel)
+            acc, pot, extra = amd.solver.pm(pos, param, tables=tables)
+            for _ in range(3):
+                pos, vel, acc, pot, extra = amd.integration.integrate(pos, vel, acc, pot, extra, tables, param,
+                                                                      np.float32(1.0))
+            out[use] = (pos.cpu().numpy(), vel.cpu().numpy(), acc.cpu().numpy())
+        finally:
+            amd.integration._USE_KHALO = True
+    d = np.abs(out[True][0] - out[False][0])
+    assert np.minimum(d, 1 - d).max() <= 2e-6
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=0, atol=2e-5 * _scale(out[False][1]))
+    np.testing.assert_allclose(out[True][2], out[False][2], rtol=0, atol=2e-4 * _scale(out[False][2]))
+
+
 def test_full_size_properties(amd):
     """256^3 (17M particles): size-independent properties -- mass conservation, zero net force,
     deposit/gather adjointness, and sorted/unsorted agreement -- where the oracle is too slow."""
