@@ -230,13 +230,17 @@ def main():
     torch.cuda.synchronize()
     L.profile_start()
     t0 = time.perf_counter()
+    straggler_frac = []
     for _ in range(args.steps):
         pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, t_far)
+        if world == 1:
+            straggler_frac.append(utils.straggler_fraction(n)[0])
+        L.profile_mark()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     wall = time.perf_counter() - t0
-    stages = L.profile_stop()
+    stages, per_step = L.profile_stop(per_step=True)
     if dist is not None:  # the step is over when the slowest rank is
         tw = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -303,6 +307,13 @@ def main():
                                   "Morton-sorted once", "ncells_1d": n, "npart": npart,
                       "parallelism": "1 GPU" if world == 1 else f"{world} x-slabs, RCCL all-to-all FFT transposes + ring halos"},
            "roofline": roofline}
+    # the first and last five timed steps: straggler fraction (particles outside the tile the sort filed them
+    # under) and milliseconds per C-ABI stage, so a drift of the step time with the age of the sort shows
+    show = sorted(set(list(range(min(5, args.steps))) + list(range(max(0, args.steps - 5), args.steps))))
+    out["per_step"] = [{"step": i + 1, "stragglers": None if not straggler_frac or straggler_frac[i] is None
+                        else round(straggler_frac[i], 5),
+                        "ms": {k[3:]: round(v, 3) for k, v in sorted(per_step[i].items(), key=lambda kv: -kv[1])[:3]}}
+                       for i in show]
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         del pos, vel, acc, phi, extra
         torch.cuda.empty_cache()

@@ -173,16 +173,30 @@ def profile_start() -> None:
     _profiler = []
 
 
-def profile_stop() -> Dict[str, Tuple[int, float]]:
-    """Stop recording; returns {entry point: (calls, total milliseconds)} after synchronising."""
+def profile_mark() -> None:
+    """End of one step: profile_stop(per_step=True) splits the record here."""
+    if _profiler is not None:
+        _profiler.append((None, None, None))
+
+
+def profile_stop(per_step: bool = False):
+    """Stop recording; returns {entry point: (calls, total milliseconds)} after synchronising -- with
+    `per_step`, also the list of {entry point: milliseconds} of every stretch closed by profile_mark()."""
     global _profiler
     rec, _profiler = _profiler or [], None
     _torch().cuda.synchronize()
     out: Dict[str, Tuple[int, float]] = {}
+    steps, cur = [], {}
     for name, e0, e1 in rec:
+        if name is None:
+            steps.append(cur)
+            cur = {}
+            continue
+        ms = e0.elapsed_time(e1)
         c, t = out.get(name, (0, 0.0))
-        out[name] = (c + 1, t + e0.elapsed_time(e1))
-    return out
+        out[name] = (c + 1, t + ms)
+        cur[name] = cur.get(name, 0.0) + ms
+    return (out, steps) if per_step else out
 
 
 class Context:
