@@ -28,12 +28,13 @@ B_ALG_PER_PARTICLE = 200.0  # fused-ideal bytes per part
 
 
 def synth_tables():
-    """Monotone stand-ins for tables[0]=lna(t), [1]=t(lna), [3]=D1(lna) (EdS-like)."""
+    """Monotone stand-ins for tables[0]=lna(t), [1]=t(lna), [3]=D1(lna): Einstein-de Sitter, a = (1 + t)^(2/3),
+    tabulated on a grid uniform in ln a that is long enough for hundreds of steps of 10 % growth."""
     from scipy.interpolate import interp1d
 
-    t = np.linspace(-0.95, 0.0, 4000)
-    a = (1.0 + t) ** (2.0 / 3.0)
-    lna = np.log(a)
+    lna = np.linspace(np.log(0.02), np.log(0.5) + 400 * np.log(1.1), 60000)
+    a = np.exp(lna)
+    t = a**1.5 - 1.0
     return [interp1d(t, lna, fill_value="extrapolate"), interp1d(lna, t, fill_value="extrapolate"), None,
             interp1d(lna, a, fill_value="extrapolate")] + [None] * 9
 
@@ -105,6 +106,9 @@ def alg_bytes(n, npart):
         "pm_interp": 24.0 * npart + 12.0 * cells,    # read x, F; write a
         "pm_interp_kick": 48.0 * npart + 12.0 * cells,  # gather + second kick + CFL maxima: read x,v,F; write v,a
         "pm_gradient_interp_kick": 48.0 * npart + 4.0 * cells,  # the same reading phi instead of F (gradient fused)
+        # ... and writing the arrays out of place in tile order: the same algorithmic work (the 12 B/particle of the
+        # re-written position are this design's overhead, not compulsory traffic)
+        "pm_gradient_interp_kick_rebucket": 48.0 * npart + 4.0 * cells,
         "pm_axpy": 36.0 * npart,                     # second kick: read v,a; write v
         "pm_max_abs": 12.0 * npart,                  # CFL reductions (two per step)
     }
@@ -178,6 +182,9 @@ def main():
     ap.add_argument("--rms-cells", type=float, default=0.5)
     ap.add_argument("--cpu-ncells", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rebucket-fraction", type=float, default=None,
+                    help="param['rebucket_straggler_fraction'] of the timed loop (default: pysco_amd.main's; "
+                         "negative: off, i.e. the reference's in-place step + a full sort every n_reorder steps)")
     args = ap.parse_args()
 
     import torch
@@ -201,6 +208,7 @@ def main():
 
     from pysco_amd import _lib as L
     from pysco_amd import integration, solver, utils
+    from pysco_amd import main as pm_main
 
     n = args.ncells
     npart = n**3
@@ -220,22 +228,50 @@ def main():
         slab._slabs.clear()
     torch.cuda.empty_cache()
     param, tables = make_param(n, npart)
+    # the product's own loop body (pysco_amd.main.run_nbody): integrate() + the particle-order policy, with its
+    # incremental re-sorts and any full re-sort INSIDE the timed region
+    rebucket = pm_main.REBUCKET_FRACTION if args.rebucket_fraction is None else args.rebucket_fraction
+    if world == 1 and rebucket >= 0:
+        param["rebucket_straggler_fraction"] = rebucket
     acc, phi, extra = solver.pm(pos, param, tables=tables)
-    t_far = np.float32(1.0)
-    for _ in range(args.warmup):
+    t_far = np.float32(3.0e38)  # no snapshot inside the run: every step takes its own dt
+    if "rebucket_straggler_fraction" in param:
+        pm_main.reserve_step_buffers(pos)  # the second set of particle arrays (0.8 s of hipMalloc per 12.9 GB)
+
+    def step(pos, vel, acc, phi, extra):
+        param["nsteps"] += 1
         pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, t_far)
+        if world == 1:
+            pos, vel, acc = pm_main.reorder_policy(pos, vel, acc, param)
+        return pos, vel, acc, phi, extra
+
+    for _ in range(args.warmup):
+        pos, vel, acc, phi, extra = step(pos, vel, acc, phi, extra)
 
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     L.profile_start()
     t0 = time.perf_counter()
-    straggler_frac = []
-    for _ in range(args.steps):
-        pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, t_far)
+    straggler_frac, step_events = [], [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    step_events[0].record()
+    prof = None
+    if os.environ.get("PMSTEP_HOST_PROFILE"):  # development: where does the host spend the timed loop
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
+    for i in range(args.steps):
+        pos, vel, acc, phi, extra = step(pos, vel, acc, phi, extra)
         if world == 1:
             straggler_frac.append(utils.straggler_fraction(n)[0])
         L.profile_mark()
+        step_events[i + 1].record()
+    if prof is not None:
+        prof.disable()
+        import pstats
+
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(25)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -253,6 +289,7 @@ def main():
     ab = alg_bytes(n, npart / world)
     for k in ab:  # per-rank share of the grid stages in slab mode
         if k not in ("pm_kick_drift_wrap", "pm_deposit", "pm_interp", "pm_interp_kick", "pm_gradient_interp_kick",
+                     "pm_gradient_interp_kick_rebucket",
                      "pm_kick_drift_wrap_deposit", "pm_kick_drift_wrap_deposit_khalo",
                      "pm_axpy", "pm_max_abs"):
             ab[k] /= world
@@ -276,22 +313,18 @@ def main():
                       "alg_GBps": None if gbs is None else round(gbs, 1)})
     dom = table[0]
     achieved = dom["alg_GBps"] or 0.0
-    # HBM bytes the PMC counters saw for the dominant stage's kernels (per launch), from the committed
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/, tools/pmc_summary.py);
-    # only meaningful for the configuration they were collected on
+    # HBM bytes the PMC counters saw for the dominant stage's kernels, per launch of the stage, averaged over the
+    # timed steps of the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/, tools/pmc_summary.py).
+    # Only a summary collected with THIS command line (size, step counts, policy) describes this run: else null.
     traffic = None
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")
-    if world == 1 and n == 1024 and os.path.exists(pmc_path):
-        kernels = json.load(open(pmc_path))["kernels"]
-        stage_kernels = {"pm_gradient_interp_kick": ["interp_ranges_kernel<3, 5, true>"],
-                         "pm_kick_drift_wrap_deposit": ["kdw_deposit_kernel<3>", "deposit_list_kernel<3>"],
-                         "pm_kick_drift_wrap_deposit_khalo": ["kdw_deposit_kernel<3>", "deposit_list_kernel<3>"],
-                         "pm_poisson_fft_fused": ["fftp_z_r2c", "fftp_y<true>", "fftp_x_green<1>", "fftp_y<false>",
-                                                  "fftp_z_c2r"],
-                         "pm_poisson_fft_fused_khalo": ["fftp_z_r2c", "fftp_y<true>", "fftp_x_green<1>", "fftp_y<false>",
-                                                        "fftp_z_c2r"]}.get(dom["stage"], [])
-        if stage_kernels and all(k in kernels for k in stage_kernels):
-            traffic = sum(kernels[k]["hbm_bytes"] for k in stage_kernels)
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.json")
+    if world == 1 and os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        same = (pmc.get("ncells") == n and pmc.get("steps") == args.steps and pmc.get("warmup") == args.warmup
+                and pmc.get("rebucket_fraction") == param.get("rebucket_straggler_fraction")
+                and pmc.get("rms_cells") == args.rms_cells)
+        if same:
+            traffic = pmc.get("stages", {}).get(dom["stage"], {}).get("hbm_bytes_per_call")
     roofline = {"bound": "hbm", "kernel": dom["stage"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved / (HBM_PEAK / 1e9), 4), "traffic": traffic,
                 "alg_bytes_per_launch": ab.get(dom["stage"]),
@@ -304,7 +337,11 @@ def main():
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"Newton {n}^3 mesh / {n}^3 particles, TSC, FFT Poisson (compensated), "
                                   f"order-5 gradient, leapfrog KDK, Zel'dovich ICs rms {args.rms_cells} cell, "
-                                  "Morton-sorted once", "ncells_1d": n, "npart": npart,
+                                  "Morton-sorted once, then the product loop's order policy inside the timed steps ("
+                                  + (f"incremental tile re-sort above {param['rebucket_straggler_fraction']:g} stragglers"
+                                     if "rebucket_straggler_fraction" in param else "in-place steps")
+                                  + f", full sort above {pm_main.REORDER_FRACTION:g})",
+                      "ncells_1d": n, "npart": npart,
                       "parallelism": "1 GPU" if world == 1 else f"{world} x-slabs, RCCL all-to-all FFT transposes + ring halos"},
            "roofline": roofline}
     # the first and last five timed steps: straggler fraction (particles outside the tile the sort filed them
@@ -312,6 +349,7 @@ def main():
     show = sorted(set(list(range(min(5, args.steps))) + list(range(max(0, args.steps - 5), args.steps))))
     out["per_step"] = [{"step": i + 1, "stragglers": None if not straggler_frac or straggler_frac[i] is None
                         else round(straggler_frac[i], 5),
+                        "wall_ms": round(step_events[i].elapsed_time(step_events[i + 1]), 3),
                         "ms": {k[3:]: round(v, 3) for k, v in sorted(per_step[i].items(), key=lambda kv: -kv[1])[:3]}}
                        for i in show]
     if not args.no_cpu_baseline and rank == 0 and world == 1:

@@ -193,6 +193,27 @@ int pm_kick_drift_wrap_deposit_slab(pm_ctx *ctx, int scheme, float *d_pos, float
  * aligned d_phi (any hipMalloc / torch allocation is). */
 int pm_gradient_interp_kick(pm_ctx *ctx, int order, int scheme, const float *d_phi, int nx_phi, int x0_phi,
                             const float *d_pos, int64_t np, float *d_acc, float *d_vel, float half_dt);
+/* pm_gradient_interp_kick with the second kick, doubling as an incremental re-sort of the particle stream
+ * (the job of utils.reorder_particles, utils.py:1019, which main.py:146-150 calls every n_reorder steps; no
+ * reference counterpart for doing it inside the step).  The gather reads every particle's position and velocity
+ * and writes its velocity and acceleration anyway; here it writes position, kicked velocity and acceleration OUT
+ * OF PLACE, tile after tile (8 x 16 x 16 cells, the unit of the tile-range kernels), every particle into the
+ * range of the tile it is expected to be in after the next drift (x + dt_next * v clamped to one cell, the
+ * Courant bound of integration.py:324-326; dt_next from pm_set_predicted_dt, 0 = the tile it is in now).  The
+ * *_out stream enters the next step with (nearly) no stragglers, for 12 more bytes per particle than the
+ * in-place gather.  Values are those pm_gradient_interp_kick computes (same
+ * bits); only the particle order changes -- inside a tile it is the order of arrival, which no kernel result
+ * depends on.  d_id / d_id_out (both or neither): uint32 tags carried along, so a caller can follow the
+ * permutation.  Needs the ranges, lists and stay counts pm_kick_drift_wrap_deposit[_khalo] left prepared for
+ * exactly d_pos / np (fails otherwise; check pm_tile_lists_info's `complete` first).  The context remembers the
+ * tile offsets of d_pos_out: the next pm_kick_drift_wrap_deposit on it skips the range search.
+ * Single-GPU layout, n >= 16, max|acc| / max|vel| left for pm_last_maxabs as usual. */
+int pm_gradient_interp_kick_rebucket(pm_ctx *ctx, int order, int scheme, const float *d_phi, const float *d_pos,
+                                     const float *d_vel, int64_t np, float half_dt, float *d_pos_out, float *d_vel_out,
+                                     float *d_acc_out, const unsigned *d_id, unsigned *d_id_out);
+/* Guess of the next step's dt for the filing above; must be set before the pm_kick_drift_wrap_deposit[_khalo]
+ * whose counts the re-bucketing gather uses (the gather takes the value those counts were made with). */
+int pm_set_predicted_dt(pm_ctx *ctx, float dt_next);
 /* utils.max_abs of the acc / vel arrays written by the last pm_interp_kick (syncs).  *h_max_vel is 0
  * if that call had d_vel == NULL. */
 int pm_last_maxabs(pm_ctx *ctx, float *h_max_acc, float *h_max_vel);

@@ -69,6 +69,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_khalo_floats": (_i,),
     "pm_kick_drift_wrap_deposit_slab": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _f, _f, _vp, _i, C.POINTER(_i)),
     "pm_gradient_interp_kick": (_vp, _i, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _f),
+    "pm_gradient_interp_kick_rebucket": (_vp, _i, _i, _vp, _vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp),
+    "pm_set_predicted_dt": (_vp, _f),
     "pm_last_maxabs": (_vp, C.POINTER(_f), C.POINTER(_f)),
     "pm_set_gather_mode": (_vp, _i),
     "pm_restriction": (_vp, _vp, _i, _f, _vp),

@@ -157,6 +157,17 @@ struct pm_ctx {
     const void *lists_ptr[4];  // start, xstart (tile_tmp); idx, lstart (list_buf)
     void *list_buf;      // keys/indices (in, out), per-tile list offsets, sort scratch
     size_t list_buf_bytes;
+    // incremental re-sort (pm_gradient_interp_kick_rebucket): per-tile / per-workgroup counts of the particles that
+    // stayed in the tile they are filed under (written by the fused kick + drift + deposit), the tile offsets of
+    // the re-bucketed stream (two tables: the one the current layout was written with, the one being built)
+    void *rb_buf;
+    size_t rb_buf_bytes;
+    int stay_valid;            // the destination counts belong to the prepared lists (lists_pos)
+    float dt_pred, stay_dt_pred;  // guess of the next step's dt (pm_set_predicted_dt); the one the counts were made with
+    const float *sorted_pos;   // positions that were written tile by tile with table rb_cur (a hint: any table that
+    int64_t sorted_np;         // partitions [0, np) gives correct results, an exact one saves the bisection)
+    unsigned sorted_ntiles;
+    int rb_cur;
     // sort workspace (grown on demand)
     void *sort_tmp;
     size_t sort_tmp_bytes;

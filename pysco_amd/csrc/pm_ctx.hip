@@ -91,6 +91,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *c) {
     if (c->sort_tmp) hipFree(c->sort_tmp);
     if (c->tile_tmp) hipFree(c->tile_tmp);
     if (c->list_buf) hipFree(c->list_buf);
+    if (c->rb_buf) hipFree(c->rb_buf);
     hipFree(c->d_scratch);
     hipFree(c->d_tab);
     hipFree(c->d_hist);

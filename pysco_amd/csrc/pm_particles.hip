@@ -788,6 +788,40 @@ extern "C" int pm_set_tile_window(pm_ctx *c, int x_lo, int nx) {
     return PM_OK;
 }
 
+// Buffers of the incremental re-sort (pm_gradient_interp_kick_rebucket): every tile's new population, the
+// destination histogram of every workgroup, the fill counters, the widened counts and the two tile-offset tables.
+struct RbBufs {
+    unsigned *tile_count, *wg_hist, *fill;
+    int64_t *cnt, *table[2];
+    void *scan_tmp;
+    size_t scan_tmp_bytes;
+};
+
+static int rebucket_bufs(pm_ctx *c, unsigned ntiles, int64_t np, RbBufs *b) {
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t maxblocks = (size_t)ntiles + (size_t)(np / 4096) + 2;  // >= nlaunch + np / PM_RANGE_CHUNK + 1
+    const size_t t32 = up(((size_t)ntiles + 1) * sizeof(unsigned)), t64 = up(((size_t)ntiles + 1) * sizeof(int64_t));
+    const size_t w32 = up(maxblocks * 27 * sizeof(unsigned));
+    size_t tmp = 0;
+    int64_t *nullp = nullptr;
+    PM_HIP(rocprim::exclusive_scan(nullptr, tmp, nullp, nullp, (int64_t)0, (size_t)ntiles + 1, rocprim::plus<int64_t>(),
+                                   c->stream));
+    const size_t need = 2 * t32 + w32 + 3 * t64 + tmp;
+    if (c->rb_buf_bytes < need) {
+        if (c->rb_buf) PM_HIP(hipFree(c->rb_buf));
+        c->rb_buf = nullptr, c->rb_buf_bytes = 0, c->sorted_pos = nullptr, c->stay_valid = 0;
+        PM_HIP(hipMalloc(&c->rb_buf, need));
+        c->rb_buf_bytes = need;
+    }
+    char *p = (char *)c->rb_buf;
+    b->tile_count = (unsigned *)p, b->wg_hist = (unsigned *)(p + t32);
+    b->fill = (unsigned *)(p + t32 + w32);
+    b->cnt = (int64_t *)(p + 2 * t32 + w32);
+    b->table[0] = (int64_t *)(p + 2 * t32 + w32 + t64), b->table[1] = (int64_t *)(p + 2 * t32 + w32 + 2 * t64);
+    b->scan_tmp = p + 2 * t32 + w32 + 3 * t64, b->scan_tmp_bytes = tmp;
+    return PM_OK;
+}
+
 static int tile_ranges(pm_ctx *c, const float *pos, int64_t np, TileWork *out, unsigned *out_blocks) {
     const int n = c->n;
     const unsigned ntiles = (unsigned)(((int64_t)n * n * n) >> (PM_LI + PM_LJ + PM_LK));
@@ -812,10 +846,18 @@ static int tile_ranges(pm_ctx *c, const float *pos, int64_t np, TileWork *out, u
             *xstart = (int64_t *)(base + 3 * bytes);
     void *scan_tmp = base + 4 * bytes;
     const unsigned tb = (ntiles + 1 + BLK - 1) / BLK;
-    hipLaunchKernelGGL(tile_bounds_kernel, dim3(tb), dim3(BLK), 0, c->stream, pos, np, n, ntiles, raw);
-    PM_LAUNCH_CHECK();
-    PM_HIP(rocprim::inclusive_scan(scan_tmp, tmp_bytes, raw, start, (size_t)ntiles + 1, rocprim::maximum<int64_t>(),
-                                   c->stream));
+    if (pos && c->sorted_pos == pos && c->sorted_np == np && c->sorted_ntiles == ntiles && c->rb_buf) {
+        // this stream was written tile by tile (pm_gradient_interp_kick_rebucket): its offsets are on file
+        RbBufs rb;
+        int rc = rebucket_bufs(c, ntiles, np, &rb);
+        if (rc) return rc;
+        start = rb.table[c->rb_cur];
+    } else {
+        hipLaunchKernelGGL(tile_bounds_kernel, dim3(tb), dim3(BLK), 0, c->stream, pos, np, n, ntiles, raw);
+        PM_LAUNCH_CHECK();
+        PM_HIP(rocprim::inclusive_scan(scan_tmp, tmp_bytes, raw, start, (size_t)ntiles + 1, rocprim::maximum<int64_t>(),
+                                       c->stream));
+    }
     hipLaunchKernelGGL(tile_extra_kernel, dim3(tb), dim3(BLK), 0, c->stream, start, ntiles, extra);
     PM_LAUNCH_CHECK();
     PM_HIP(rocprim::exclusive_scan(scan_tmp, tmp_bytes, extra, xstart, (int64_t)0, (size_t)ntiles + 1,
@@ -901,7 +943,9 @@ __global__ __launch_bounds__(BLK) void list_bounds_kernel(const unsigned *__rest
     lstart[t] = lo;
 }
 
-static void tile_lists_drop(pm_ctx *c) { c->lists_pos = nullptr, c->lists_np = 0, c->lists_use = 0, c->lists_sticky = 0; }
+static void tile_lists_drop(pm_ctx *c) {
+    c->lists_pos = nullptr, c->lists_np = 0, c->lists_use = 0, c->lists_sticky = 0, c->stay_valid = 0;
+}
 
 // device buffers of the straggler lists: unsorted and sorted (key, index) pairs, per-tile offsets
 struct ListBufs {
@@ -1155,6 +1199,59 @@ static HaloBuf halo_parts(float *base, int n) {
     return h;
 }
 
+// where cell c of the haloed tile t lives: the tile's own cells in rho, its halo cells in the tile's entries of the
+// halo buffer (every address has exactly one tile that maps to it)
+__device__ __forceinline__ float *halo_cell(int c, const TileId &t, const HaloBuf &halo, const pm_geom &geo, float *rho) {
+    const int n_ = geo.n, T_ = n_ >> PM_LJ;
+    const int lij = c / PM_HK, lk = c - lij * PM_HK, li = lij / PM_HJ, lj = lij - li * PM_HJ;
+    const int64_t col = (int64_t)t.ti * T_ + t.tj;
+    if (lk == 0 || lk == PM_HK - 1) return halo.k + ((((col * PM_HI + li) * 2 + (lk ? 1 : 0)) * T_ + t.tk) * PM_HJ + lj);
+    if (li == 0 || li == PM_HI - 1) return halo.hi + (((col * 2 + (li ? 1 : 0)) * PM_HJ + lj) * n_ + t.tk * PM_TK + lk - 1);
+    if (lj == 0 || lj == PM_HJ - 1)
+        return halo.hj + (((col * 2 + (lj ? 1 : 0)) * PM_TI + (li - 1)) * n_ + t.tk * PM_TK + lk - 1);
+    return rho + pm_cell(geo, t.ti * PM_TI - 1 + li, t.tj * PM_TJ - 1 + lj, t.tk * PM_TK - 1 + lk);
+}
+
+// Destination tile of the incremental re-sort.  A particle is FILED under the tile it is expected to be in after
+// the next drift, x + dtp * v (v: the velocity between the two kicks, which both the fused kick + drift + deposit
+// and the gather see in memory; dtp: the caller's guess of the next step, 0 = file under the current tile).  The
+// displacement is clamped to one cell (the Courant criterion's bound, integration.py:324-326), so the destination
+// is the serving tile or one of its 26 neighbours: code d = 9 (dti + 1) + 3 (dtj + 1) + (dtk + 1), 13 = stays.
+// With the guess within a few per cent, one particle in a thousand ends up outside the tile it is filed under,
+// where an exact sort sees every tile crosser of the step (4 % when the fastest particle moves one cell).
+struct DestCode {
+    int d;
+    unsigned key;  // tile key of the destination
+};
+__device__ __forceinline__ DestCode dest_of(const float x[3], const float v[3], float dtp, float nf, int n, const TileId &t) {
+    const float h = 1.0f / nf;
+    int q[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        float dx = dtp * v[m];
+        dx = fminf(fmaxf(dx, -h), h);
+        q[m] = (int)floorf((x[m] + dx) * nf);  // -1 .. n: not wrapped, so that the tile difference below is signed
+    }
+    const int di = (q[0] >> PM_LI) - t.ti, dj = (q[1] >> PM_LJ) - t.tj, dk = (q[2] >> PM_LK) - t.tk;
+    DestCode r;
+    // (a particle that is not in tile t at all -- only if positions were changed behind the lists -- stays put)
+    const bool ok = di >= -1 && di <= 1 && dj >= -1 && dj <= 1 && dk >= -1 && dk <= 1;
+    r.d = ok ? (di + 1) * 9 + (dj + 1) * 3 + (dk + 1) : 13;
+    const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
+    const int ti = ok ? (t.ti + di + Ti) % Ti : t.ti, tj = ok ? (t.tj + dj + Tj) % Tj : t.tj, tk = ok ? (t.tk + dk + Tk) % Tk : t.tk;
+    r.key = tile_key(ti, tj, tk);
+    return r;
+}
+__device__ __forceinline__ TileId tile_of_cell(int i, int j, int k) { return TileId{i >> PM_LI, j >> PM_LJ, k >> PM_LK}; }
+
+// what the fused kick + drift + deposit records for the re-sort: every tile's new population, and per workgroup
+// how many of the particles it serves go to each of the 27 destinations
+struct DestCount {
+    unsigned *tile_count;  // [ntiles] cleared (NULL: off)
+    unsigned *wg_hist;     // [workgroups][27]
+    float dtp;
+};
+
 // slab decomposition: particles whose new x leaves [x_lo, x_hi) are listed for the migration (idx == NULL: off)
 struct Leavers {
     float x_lo, x_hi;
@@ -1169,27 +1266,15 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
                                                           TileWork work, pm_geom geo, float *__restrict__ rho,
                                                           unsigned *__restrict__ lkeys, unsigned *__restrict__ lidx,
                                                           unsigned subcap, unsigned *__restrict__ counts, Leavers lv,
-                                                          HaloBuf halo) {
+                                                          HaloBuf halo, DestCount dc) {
     unsigned key;
     int64_t s, e;
     // Halo buffer: the first-chunk workgroup of a tile owns the tile's entries of K, Hi, Hj and the tile's own
     // cells of rho, and writes all of them with plain stores, empty tile or not (rho is not cleared first).
     const bool owner = halo.k && (blockIdx.x + work.boff) < work.nlaunch;
-    const int n_ = geo.n, T_ = n_ >> PM_LJ;
     TileId t0{0, 0, 0};
     if (owner) t0 = tile_of_key(tile_key_of_block(blockIdx.x + work.boff, work));
-    auto halo_store = [&](int c, float v) {  // cell c of the haloed tile t0
-        const int lij = c / PM_HK, lk = c - lij * PM_HK, li = lij / PM_HJ, lj = lij - li * PM_HJ;
-        const int64_t col = (int64_t)t0.ti * T_ + t0.tj;
-        if (lk == 0 || lk == PM_HK - 1)
-            halo.k[(((col * PM_HI + li) * 2 + (lk ? 1 : 0)) * T_ + t0.tk) * PM_HJ + lj] = v;
-        else if (li == 0 || li == PM_HI - 1)
-            halo.hi[((col * 2 + (li ? 1 : 0)) * PM_HJ + lj) * n_ + t0.tk * PM_TK + lk - 1] = v;
-        else if (lj == 0 || lj == PM_HJ - 1)
-            halo.hj[((col * 2 + (lj ? 1 : 0)) * PM_TI + (li - 1)) * n_ + t0.tk * PM_TK + lk - 1] = v;
-        else
-            rho[pm_cell(geo, t0.ti * PM_TI - 1 + li, t0.tj * PM_TJ - 1 + lj, t0.tk * PM_TK - 1 + lk)] = v;
-    };
+    auto halo_store = [&](int c, float v) { *halo_cell(c, t0, halo, geo, rho) = v; };
     if (!tile_work_item(work, key, s, e)) {
         if (owner)
             for (int c = threadIdx.x; c < PM_TILE; c += BLK) halo_store(c, 0.f);
@@ -1198,12 +1283,14 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
     __shared__ pm_acc_t tile[PM_TILE];  // 25.9 KB
     __shared__ unsigned s_k[PM_SCAP], s_p[PM_SCAP];
     __shared__ unsigned s_cnt, s_base;
+    __shared__ unsigned s_hist[27];  // served particles per destination (13: counted as the rest)
     const int tid = threadIdx.x;
     const int n = geo.n;
     const float nf = (float)n;
     const TileId t = tile_of_key(key);
     for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0;
     if (tid == 0) s_cnt = 0;
+    if (tid < 27) s_hist[tid] = 0;
     __syncthreads();
     const unsigned seg = (blockIdx.x % PM_NSUB) * subcap;
     auto append = [&](unsigned k, unsigned p) {  // past the staging area: straight to the global list
@@ -1240,6 +1327,10 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
                 const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
                 if (in_tile(i, j, k, t)) {
                     deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
+                    if (dc.tile_count) {
+                        const DestCode dd = dest_of(x[u], v[u], dc.dtp, nf, n, t);
+                        if (dd.d != 13) atomicAdd(&s_hist[dd.d], 1u);
+                    }
                 } else {
                     const unsigned k2 = tile_key(i >> PM_LI, j >> PM_LJ, k >> PM_LK);
                     const unsigned slot = atomicAdd(&s_cnt, 1u);
@@ -1247,6 +1338,8 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
                         s_k[slot] = k2, s_p[slot] = (unsigned)p;
                     else
                         append(k2, (unsigned)p);
+                    // served by the tile it is in now, from that tile's list: counted at its destination one by one
+                    if (dc.tile_count) atomicAdd(dc.tile_count + dest_of(x[u], v[u], dc.dtp, nf, n, tile_of_cell(i, j, k)).key, 1u);
                 }
             }
         }
@@ -1265,6 +1358,22 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
         else if (w != 0)
             unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), weight_of_acc(w));
     }
+    // where the particles this workgroup serves (those of its range that are inside its tile) are filed next:
+    // per workgroup for the slots the re-bucketing gather takes, per tile for the layout of the new stream
+    if (dc.tile_count && tid < 27) {
+        unsigned cnt_d = s_hist[tid];
+        if (tid == 13) {
+            unsigned moved = 0;
+            for (int d = 0; d < 27; ++d) moved += s_hist[d];
+            cnt_d = (unsigned)(e - s) - s_cnt - moved;
+        }
+        dc.wg_hist[(size_t)(blockIdx.x + work.boff) * 27 + tid] = cnt_d;
+        if (cnt_d) {
+            const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
+            const int di = tid / 9 - 1, dj = (tid / 3) % 3 - 1, dk = tid % 3 - 1;
+            atomicAdd(dc.tile_count + tile_key((t.ti + di + Ti) % Ti, (t.tj + dj + Tj) % Tj, (t.tk + dk + Tk) % Tk), cnt_d);
+        }
+    }
     const unsigned cnt = min(s_cnt, (unsigned)PM_SCAP);
     if (cnt == 0) return;
     if (tid == 0) s_base = atomicAdd(sub_counter(counts), cnt);
@@ -1274,10 +1383,15 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
         if (base + i < subcap) lkeys[seg + base + i] = s_k[i], lidx[seg + base + i] = s_p[i];
 }
 
-// deposit of the listed stragglers, one workgroup per tile with a non-empty incoming list
+// deposit of the listed stragglers, one workgroup per tile with a non-empty incoming list.  With a halo buffer
+// the workgroup is the only writer of its tile's own cells and of its tile's buffer entries while this kernel
+// runs (the owners' stores and the surplus workgroups' atomics belong to earlier launches), so it adds with plain
+// loads and stores of the touched cells, rows of 16 contiguous floats; without one, with global atomics --
+// which the memory side executes as a 64-byte read-modify-write per touched sector (the 5 ms the halo buffer took
+// out of the main kernel came back here once most tiles had a list: 5.2 ms at 15 % stragglers, 1024^3).
 template <int SCHEME>
 __global__ __launch_bounds__(BLK) void deposit_list_kernel(const float *__restrict__ pos, TileLists lists, pm_geom geo,
-                                                           float *__restrict__ rho) {
+                                                           float *__restrict__ rho, HaloBuf halo) {
     const unsigned key = blockIdx.x;
     const unsigned ls = lists.lstart[key], le = lists.lstart[key + 1];
     if (ls == le) return;
@@ -1299,9 +1413,30 @@ __global__ __launch_bounds__(BLK) void deposit_list_kernel(const float *__restri
             deposit_global<SCHEME>(x, y, z, geo, rho);
     }
     __syncthreads();
-    for (int c = tid; c < PM_TILE; c += BLK) {
-        const pm_acc_t w = tile[c];
-        if (w != 0) unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), weight_of_acc(w));
+    if (halo.k) {
+        // read-modify-write of the touched cells, all the loads of a thread in flight before its first store (one
+        // dependent load -> store per cell made the kernel latency-bound: 5.4 ms at 4 % stragglers, 1024^3)
+        constexpr int NQ = (PM_TILE + BLK - 1) / BLK;
+        float *dst[NQ];
+        float add[NQ], old[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = q * BLK + tid;
+            const pm_acc_t w = c < PM_TILE ? tile[c] : 0;
+            add[q] = weight_of_acc(w);
+            dst[q] = w != 0 ? halo_cell(c, t, halo, geo, rho) : nullptr;
+        }
+        // (unconditional loads, untouched cells from one cached dummy address: a guarded load is sunk to its use)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) old[q] = *(dst[q] ? dst[q] : rho);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (dst[q]) *dst[q] = old[q] + add[q];
+    } else {
+        for (int c = tid; c < PM_TILE; c += BLK) {
+            const pm_acc_t w = tile[c];
+            if (w != 0) unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), weight_of_acc(w));
+        }
     }
 }
 
@@ -1317,23 +1452,34 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     ListBufs b;
     rc = list_bufs(c, np, ntiles, &b);
     if (rc) return rc;
+    // destination counts for the incremental re-sort: single-GPU layout only (a slab's migration renumbers the
+    // particles)
+    RbBufs rb;
+    const bool count_stay = !lv.idx && work.nlaunch == ntiles;
+    DestCount dcount{nullptr, nullptr, c->dt_pred};
+    if (count_stay) {
+        rc = rebucket_bufs(c, ntiles, np, &rb);
+        if (rc) return rc;
+        PM_HIP(hipMemsetAsync(rb.tile_count, 0, ((size_t)ntiles + 1) * sizeof(unsigned), c->stream));
+        dcount.tile_count = rb.tile_count, dcount.wg_hist = rb.wg_hist;
+    }
     const size_t cells = (size_t)c->slab_nx * c->n * c->n;
     const HaloBuf halo = halo_parts(khalo, c->n);
     if (!khalo) PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));  // owners store every cell otherwise
     PM_HIP(hipMemsetAsync(b.counts, 0, PM_NSUB * PM_SUB_STRIDE * sizeof(unsigned), c->stream));
     if (!khalo) {
         hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, vel, acc, -half_dt, dt,
-                           work, pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv, halo);
+                           work, pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv, halo, dcount);
     } else {
         // owners first (plain stores), then the surplus workgroups of over-full tiles, which add with atomics
         hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME>), dim3(work.nlaunch), dim3(BLK), 0, c->stream, pos, vel, acc, -half_dt,
-                           dt, work, pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv, halo);
+                           dt, work, pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv, halo, dcount);
         if (blocks > work.nlaunch) {
             TileWork extra = work;
             extra.boff = work.nlaunch;
             hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME>), dim3(blocks - work.nlaunch), dim3(BLK), 0, c->stream, pos, vel,
                                acc, -half_dt, dt, extra, pm_ctx_geom(c), rho, b.k_in, b.i_in, (unsigned)b.subcap, b.counts, lv,
-                               halo);
+                               halo, dcount);
         }
     }
     PM_LAUNCH_CHECK();
@@ -1361,10 +1507,11 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     lists.idx = idx, lists.lstart = b.lstart, lists.use = 1;
     if (listed > 0) {
         hipLaunchKernelGGL((deposit_list_kernel<SCHEME>), dim3(ntiles), dim3(BLK), 0, c->stream, pos, lists, pm_ctx_geom(c),
-                           rho);
+                           rho, halo);
         PM_LAUNCH_CHECK();
     }
-    c->lists_pos = pos, c->lists_np = np, c->lists_use = 1, c->lists_sticky = 1;
+    c->lists_pos = pos, c->lists_np = np, c->lists_use = 1, c->lists_sticky = 1, c->stay_valid = count_stay ? 1 : 0;
+    c->stay_dt_pred = c->dt_pred;
     return PM_OK;
 }
 
@@ -1555,14 +1702,29 @@ __device__ __noinline__ Acc3 gather_phi_global(const float *__restrict__ phi, fl
     return Acc3{acc[0], acc[1], acc[2]};
 }
 
+// Incremental re-sort riding on the gather (pm_gradient_interp_kick_rebucket): the kernel reads every particle's
+// position and velocity and writes its velocity and acceleration anyway; written OUT OF PLACE into the range of
+// its destination tile (dest_of: the tile it is expected to be in after the next drift) the stream comes out
+// sorted for 12 more bytes per particle (the position), where a sort by key costs a dozen passes.  The order
+// inside a tile is the order of arrival (nothing depends on it: the tile sums of the deposit are integer sums).
+struct Rebucket {
+    const int64_t *newstart;  // [ntiles + 1] offsets of the re-bucketed stream
+    unsigned *fill;           // [ntiles] cleared: whoever sends particles to a tile takes a slice of its range here
+    const unsigned *wg_hist;  // [workgroups][27] particles the workgroup serves from its range, per destination
+    float dtp;                // the guess of the next dt the destinations were counted with (dest_of)
+    float *pos_out, *vel_out, *acc_out;
+    const unsigned *id;       // optional particle tags carried along (NULL: none)
+    unsigned *id_out;
+};
+
 // One workgroup per tile: gather + second kick + CFL maxima.  ORDER == 0: `src` is the [.,n,n,3] force
 // grid; ORDER in {2,3,5,7}: `src` is the potential and the force tile is differentiated in LDS.
-template <int SCHEME, int ORDER, bool KICK>
+template <int SCHEME, int ORDER, bool KICK, bool REBUCKET = false>
 __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restrict__ src,
                                                             const float *__restrict__ pos, TileWork work,
                                                             TileLists lists, pm_geom geo, float *__restrict__ out,
                                                             float *__restrict__ vel, float mhalf_dt,
-                                                            unsigned *__restrict__ maxbits) {
+                                                            unsigned *__restrict__ maxbits, Rebucket rb) {
     // The tile of a first-chunk workgroup follows from blockIdx alone, so its fill loads are issued
     // together with the range lookup instead of one memory latency after it.
     unsigned key = 0;
@@ -1577,6 +1739,10 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         has_range = true;
     __shared__ __attribute__((aligned(16))) float tile[3 * PM_FSTRIDE];  // 39.2 KB: (x, y) plane + z plane (ORDER > 0: first the potential tile)
     __shared__ unsigned s_max[2][BLK / 64];
+    // REBUCKET: per destination, where the workgroup's slice of that tile's new range starts, its size, and the
+    // next free slot in it
+    __shared__ int64_t s_dest[27];
+    __shared__ unsigned s_mine[27], s_slot[27];
     const int tid = threadIdx.x;
     const int n = geo.n;
     const float nf = (float)n;
@@ -1611,6 +1777,21 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         has_range = s < e;
         if (lists.use) ls = lists.lstart[key], le = lists.lstart[key + 1];
         if (!has_range && ls == le) return;
+    }
+    if constexpr (REBUCKET) {
+        // slices of the destination tiles' new ranges for the particles this workgroup serves from its range, as
+        // the fused kick counted them (made visible to all by the barriers of the tile fill); listed particles
+        // take their slots one by one
+        if (tid < 27) {
+            const unsigned mine = has_range ? rb.wg_hist[(size_t)blockIdx.x * 27 + tid] : 0u;
+            s_mine[tid] = mine, s_slot[tid] = 0;
+            if (mine) {
+                const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
+                const int di = tid / 9 - 1, dj = (tid / 3) % 3 - 1, dk = tid % 3 - 1;
+                const unsigned dkey = tile_key((t.ti + di + Ti) % Ti, (t.tj + dj + Tj) % Tj, (t.tk + dk + Tk) % Tk);
+                s_dest[tid] = rb.newstart[dkey] + (int64_t)atomicAdd(rb.fill + dkey, mine);
+            }
+        }
     }
     PosQueue q;
     VelQueue qv;
@@ -1704,8 +1885,9 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     unsigned ma = 0, mv = 0;  // bit patterns of max|a|, max|v| (integer order == float order, NaN on top)
     // (o, w, p): where the particle's acceleration and velocity go -- the range's own base with a 32-bit
     // relative index, or the arrays' base with the 64-bit index of a listed straggler
+    // `src_index`: the particle's index in the input arrays (only read for the tags of a re-bucketing pass)
     auto serve = [&](float *__restrict__ o, float *__restrict__ w3, auto p, float x, float y, float z, const float v[3],
-                     bool own_range) {
+                     bool own_range, int64_t src_index) {
         const float xp = x * nf, yp = y * nf, zp = z * nf;
         const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
         const bool inside = in_tile(i, j, k, t);
@@ -1725,7 +1907,52 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                 r = gather_phi_global<SCHEME, ORDER>(src, scale, xp, yp, zp, i, j, k, geo);
             a[0] = r.x, a[1] = r.y, a[2] = r.z;
         }
-        if (!skip) {
+        if constexpr (REBUCKET) {
+            const float xs[3] = {x, y, z};
+            int64_t d64 = -1;  // where the particle goes (-1: not written)
+            if (own_range) {
+                // the destination the fused kick counted for it; stayers (nearly all) take consecutive slots of
+                // the own slice with one LDS atomic per wave and iteration, movers one each
+                const DestCode dd = dest_of(xs, v, rb.dtp, nf, n, t);
+                const bool stay = !skip && dd.d == 13;
+                const unsigned long long m = __ballot(stay);
+                const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                unsigned wb = 0;
+                if (stay && before == 0) wb = atomicAdd(&s_slot[13], (unsigned)__popcll(m));  // the first staying lane
+                wb = __shfl((int)wb, m ? __ffsll((long long)m) - 1 : (tid & 63), 64);
+                unsigned slot = wb + before;
+                if (!skip && !stay) slot = atomicAdd(&s_slot[dd.d], 1u);
+                // (slot < s_mine always, unless the positions were changed behind the prepared lists: memory safety)
+                if (!skip && slot < s_mine[dd.d]) d64 = s_dest[dd.d] + slot;
+            } else {
+                // a listed particle (it is inside this tile, or the lists are void): counted one by one by the
+                // fused kick, so it takes its slot from the destination's counter itself -- the lanes of a wave
+                // that stay in this tile (nearly all) with one global atomic between them
+                const DestCode dd = dest_of(xs, v, rb.dtp, nf, n, tile_of_cell(i, j, k));
+                const bool here = dd.key == key;
+                const unsigned long long m = __ballot(here);
+                const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                unsigned wb = 0;
+                if (here && before == 0) wb = atomicAdd(rb.fill + key, (unsigned)__popcll(m));
+                wb = __shfl((int)wb, m ? __ffsll((long long)m) - 1 : (tid & 63), 64);
+                const unsigned slot = here ? wb + before : atomicAdd(rb.fill + dd.key, 1u);
+                d64 = rb.newstart[dd.key] + (int64_t)slot;
+                if (d64 >= rb.newstart[dd.key + 1]) d64 = -1;  // (memory safety, as above)
+            }
+            if (d64 >= 0) {
+                float *op = rb.acc_out + 3 * d64, *wp = rb.vel_out + 3 * d64, *xo = rb.pos_out + 3 * d64;
+                xo[0] = x, xo[1] = y, xo[2] = z;
+                if (rb.id) rb.id_out[d64] = rb.id[src_index];
+#pragma unroll
+                for (int mm = 0; mm < 3; ++mm) {
+                    op[mm] = a[mm];
+                    ma = max(ma, __float_as_uint(a[mm]) & 0x7fffffffu);
+                    const float w = v[mm] + mhalf_dt * a[mm];
+                    wp[mm] = w;
+                    mv = max(mv, __float_as_uint(w) & 0x7fffffffu);
+                }
+            }
+        } else if (!skip) {
             float *op = o + 3 * p, *wp = w3 + 3 * p;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
@@ -1748,7 +1975,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
             q.pop(r, x, y, z);
             float v[3] = {0.f, 0.f, 0.f};
             if (KICK) qv.pop(r, v);
-            serve(o, w3, r, x, y, z, v, true);
+            serve(o, w3, r, x, y, z, v, true, s + r);
         }
     }
 #pragma unroll 1
@@ -1756,7 +1983,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         const int64_t p = lists.idx[l];
         float v[3] = {0.f, 0.f, 0.f};
         if (KICK) v[0] = vel[3 * p], v[1] = vel[3 * p + 1], v[2] = vel[3 * p + 2];
-        serve(out, vel, p, pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], v, false);
+        serve(out, vel, p, pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], v, false, p);
     }
     for (int off = 32; off > 0; off >>= 1) {
         ma = max(ma, (unsigned)__shfl_down((int)ma, off, 64));
@@ -1828,10 +2055,10 @@ static int interp_kick_launch(pm_ctx *c, const float *grid, const float *pos, in
         if (rc) return rc;
         if (vel)
             hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, 0, true>), dim3(nblk), dim3(BLK), 0, c->stream, grid, pos,
-                               work, lists, pm_ctx_geom(c), out, vel, -half_dt, mb);
+                               work, lists, pm_ctx_geom(c), out, vel, -half_dt, mb, Rebucket{});
         else
             hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, 0, false>), dim3(nblk), dim3(BLK), 0, c->stream, grid, pos,
-                               work, lists, pm_ctx_geom(c), out, vel, 0.f, mb);
+                               work, lists, pm_ctx_geom(c), out, vel, 0.f, mb, Rebucket{});
         PM_LAUNCH_CHECK();
         return PM_OK;
     }
@@ -1872,10 +2099,10 @@ static int grad_interp_kick_launch(pm_ctx *c, const float *phi, pm_geom geo, con
     if (rc) return rc;
     if (vel)
         hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, ORDER, true>), dim3(nblk), dim3(BLK), 0, c->stream, phi, pos,
-                           work, lists, geo, out, vel, -half_dt, mb);
+                           work, lists, geo, out, vel, -half_dt, mb, Rebucket{});
     else
         hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, ORDER, false>), dim3(nblk), dim3(BLK), 0, c->stream, phi, pos,
-                           work, lists, geo, out, vel, 0.f, mb);
+                           work, lists, geo, out, vel, 0.f, mb, Rebucket{});
     PM_LAUNCH_CHECK();
     return PM_OK;
 }
@@ -1911,6 +2138,96 @@ extern "C" int pm_gradient_interp_kick(pm_ctx *c, int order, int scheme, const f
     }
     pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme);
     return PM_EINVAL;
+}
+
+// ---- incremental re-sort: the same kernel writing the particle arrays out of place, tile after tile ----------
+
+__global__ __launch_bounds__(BLK) void rebucket_counts_kernel(const unsigned *__restrict__ tile_count, unsigned ntiles,
+                                                              int64_t *__restrict__ cnt) {
+    const unsigned t = blockIdx.x * BLK + threadIdx.x;
+    if (t > ntiles) return;
+    cnt[t] = t < ntiles ? (int64_t)tile_count[t] : 0;
+}
+
+template <int SCHEME, int ORDER>
+static int rebucket_launch(pm_ctx *c, const float *phi, pm_geom geo, const float *pos, float *vel, int64_t np,
+                           float half_dt, const TileWork &work, const TileLists &lists, unsigned nblk, const Rebucket &rb) {
+    hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, ORDER, true, true>), dim3(nblk), dim3(BLK), 0, c->stream, phi, pos, work,
+                       lists, geo, (float *)nullptr, vel, -half_dt, c->d_scratch + 8, rb);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+template <int SCHEME>
+static int rebucket_order(pm_ctx *c, int order, const float *phi, pm_geom geo, const float *pos, float *vel, int64_t np,
+                          float half_dt, const TileWork &work, const TileLists &lists, unsigned nblk, const Rebucket &rb) {
+    switch (order) {
+        case 2: return rebucket_launch<SCHEME, 2>(c, phi, geo, pos, vel, np, half_dt, work, lists, nblk, rb);
+        case 3: return rebucket_launch<SCHEME, 3>(c, phi, geo, pos, vel, np, half_dt, work, lists, nblk, rb);
+        case 5: return rebucket_launch<SCHEME, 5>(c, phi, geo, pos, vel, np, half_dt, work, lists, nblk, rb);
+        case 7: return rebucket_launch<SCHEME, 7>(c, phi, geo, pos, vel, np, half_dt, work, lists, nblk, rb);
+    }
+    pm_set_error("gradient order %d, should be 2, 3, 5 or 7", order);
+    return PM_EINVAL;
+}
+
+// pm_gradient_interp_kick with the kick, writing position, kicked velocity and acceleration (and the optional
+// tags) of every particle to the *_out arrays in tile order (pmstep.h).  Needs the ranges, lists and stay counts
+// pm_kick_drift_wrap_deposit[_khalo] left prepared for exactly d_pos / np.
+extern "C" int pm_gradient_interp_kick_rebucket(pm_ctx *c, int order, int scheme, const float *d_phi, const float *d_pos,
+                                                const float *d_vel, int64_t np, float half_dt, float *d_pos_out,
+                                                float *d_vel_out, float *d_acc_out, const unsigned *d_id,
+                                                unsigned *d_id_out) {
+    PM_REQUIRE(c && d_phi && d_pos && d_vel && d_pos_out && d_vel_out && d_acc_out && np > 0, "bad argument");
+    PM_REQUIRE((!d_id) == (!d_id_out), "d_id / d_id_out must come as a pair");
+    PM_REQUIRE(d_pos_out != d_pos && d_vel_out != d_vel, "the re-bucketed arrays are written out of place");
+    PM_REQUIRE(c->n >= 16 && c->slab_nx == c->n && c->tile_nx == c->n, "pm_gradient_interp_kick_rebucket is the single-GPU form");
+    PM_REQUIRE(((uintptr_t)d_phi & 15u) == 0, "d_phi must be 16-byte aligned (the tile fill reads float4)");
+    PM_REQUIRE(c->lists_pos == d_pos && c->lists_np == np && c->lists_use == 1 && c->stay_valid,
+               "no stay counts prepared for these positions (pm_kick_drift_wrap_deposit[_khalo] on the same d_pos first)");
+    TileWork work;
+    TileLists lists;
+    unsigned nblk = 0;
+    int rc = tile_work_for(c, d_pos, np, &work, &lists, &nblk);
+    if (rc) return rc;
+    const unsigned ntiles = work.ntiles;
+    RbBufs b;
+    rc = rebucket_bufs(c, ntiles, np, &b);
+    if (rc) return rc;
+    int64_t *table = b.table[c->rb_cur ^ 1];  // (work.start may be the other table: this stream's own layout)
+    const unsigned tb = (ntiles + 1 + BLK - 1) / BLK;
+    hipLaunchKernelGGL(rebucket_counts_kernel, dim3(tb), dim3(BLK), 0, c->stream, b.tile_count, ntiles, b.cnt);
+    PM_LAUNCH_CHECK();
+    size_t tmp = b.scan_tmp_bytes;
+    PM_HIP(rocprim::exclusive_scan(b.scan_tmp, tmp, b.cnt, table, (int64_t)0, (size_t)ntiles + 1, rocprim::plus<int64_t>(),
+                                   c->stream));
+    PM_HIP(hipMemsetAsync(b.fill, 0, ((size_t)ntiles + 1) * sizeof(unsigned), c->stream));
+    PM_HIP(hipMemsetAsync(c->d_scratch + 8, 0, 2 * sizeof(unsigned), c->stream));
+    Rebucket rb;
+    rb.newstart = table, rb.fill = b.fill, rb.wg_hist = b.wg_hist, rb.dtp = c->stay_dt_pred;
+    rb.pos_out = d_pos_out, rb.vel_out = d_vel_out, rb.acc_out = d_acc_out, rb.id = d_id, rb.id_out = d_id_out;
+    const pm_geom geo = pm_ctx_geom(c);
+    float *vel = const_cast<float *>(d_vel);  // read only by the re-bucketing instantiation
+    switch (scheme) {
+        case PM_NGP: rc = rebucket_order<PM_NGP>(c, order, d_phi, geo, d_pos, vel, np, half_dt, work, lists, nblk, rb); break;
+        case PM_CIC: rc = rebucket_order<PM_CIC>(c, order, d_phi, geo, d_pos, vel, np, half_dt, work, lists, nblk, rb); break;
+        case PM_TSC: rc = rebucket_order<PM_TSC>(c, order, d_phi, geo, d_pos, vel, np, half_dt, work, lists, nblk, rb); break;
+        default: pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme); rc = PM_EINVAL;
+    }
+    if (rc) return rc;
+    tile_lists_drop(c);  // they describe the old layout
+    c->rb_cur ^= 1;
+    c->sorted_pos = d_pos_out, c->sorted_np = np, c->sorted_ntiles = ntiles;
+    return PM_OK;
+}
+
+// The caller's guess of the NEXT step's dt, used by pm_kick_drift_wrap_deposit[_khalo] to count and by
+// pm_gradient_interp_kick_rebucket to choose the tile every particle is filed under (dest_of).  0 (default): the
+// tile it is in.  Any value gives correct results; a good guess keeps the straggler lists short.
+extern "C" int pm_set_predicted_dt(pm_ctx *c, float dt_next) {
+    PM_REQUIRE(c && dt_next >= 0.f && dt_next == dt_next, "bad argument");
+    c->dt_pred = dt_next;
+    return PM_OK;
 }
 
 extern "C" int pm_last_maxabs(pm_ctx *c, float *h_max_acc, float *h_max_vel) {

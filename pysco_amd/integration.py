@@ -57,6 +57,7 @@ def euler(position, velocity, acceleration, potential, additional_field, dt, tab
     return position, velocity, acceleration, potential, additional_field
 
 
+_PREDICT = True       # incremental re-sort: file particles under the tile they are expected to be in NEXT step
 _FUSE_DEPOSIT = True  # tests flip this to compare with the separate kick-drift-wrap and deposit
 _USE_KHALO = True     # ... and this for the plain flush (every tile cell through global atomics)
 _khalo_buffers = {}
@@ -89,6 +90,13 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
             # the deposit of pm() rides on the streaming update (pmstep.h: pm_kick_drift_wrap_deposit)
             torch = L.require_gpu()
             density = torch.empty((ncells_1d,) * 3, dtype=torch.float32, device=position.device)
+            if param.get("rebucket_straggler_fraction") is not None:
+                # guess of the next step's dt, for the tile the re-bucketing gather files every particle under:
+                # this step's, scaled by how it changed from the last one (pmstep.h: pm_set_predicted_dt)
+                dt_last = param.get("_dt_last")
+                ratio = min(1.5, max(0.5, float(dt) / dt_last)) if (dt_last and dt_last > 0) else 1.0
+                param["_dt_last"] = float(dt)
+                L.context(ncells_1d).call("pm_set_predicted_dt", float(np.float32(dt * ratio)) if _PREDICT and dt > 0 else 0.0)
             if _USE_KHALO:
                 # the tiles' halo cells go to a side buffer and the own cells to the density, all with plain
                 # stores instead of memory-side atomics; solver.pm hands the buffer to the FFT solve (or has
@@ -113,12 +121,34 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
         utils.periodic_wrap(position)
     logging.info(f"{param['t']=} {param['aexp']=}")
     if fused:  # second kick fused into the interpolation kernel
+        rebucket = _rebucket_request(density, param, position)
         acceleration, potential, additional_field = solver.pm(position, param, potential, additional_field, tables,
-                                                              _kick=(velocity, half_dt), _density=density)
+                                                              _kick=(velocity, half_dt), _density=density,
+                                                              _rebucket=rebucket)
+        if rebucket is not None and "position" in rebucket:
+            # the gather wrote the arrays out of place, tile after tile (pmstep.h: pm_gradient_interp_kick_rebucket)
+            position, velocity = rebucket["position"], rebucket["velocity"]
+            if rebucket["ids"] is not None:
+                param["particle_id"] = rebucket["ids"]
     else:
         acceleration, potential, additional_field = solver.pm(position, param, potential, additional_field, tables)
         utils.add_vector_scalar_inplace(velocity, acceleration, -half_dt)
     return position, velocity, acceleration, potential, additional_field
+
+
+def _rebucket_request(density, param, position):
+    """Incremental re-sort policy (no reference counterpart; the reference re-sorts every n_reorder steps,
+    main.py:146-150).  With param["rebucket_straggler_fraction"] = f set (main.run_nbody sets it), a step whose
+    fused kick + drift + deposit found more than f of the particles outside the tile they are filed under has its
+    gather write position, velocity and acceleration out of place in tile order: integrate() then returns NEW
+    tensors (same particles, permuted; param["particle_id"], an optional int32 tensor, follows them)."""
+    thr = param.get("rebucket_straggler_fraction")
+    if thr is None or density is None or param["theory"].casefold() == "fr":
+        return None
+    frac, complete = utils.straggler_fraction(2 ** int(param["ncoarse"]))
+    if frac is None or not complete or frac <= float(thr):
+        return None
+    return {"ids": param.get("particle_id")}
 
 
 def dt_CFL_maxacc(acceleration, param) -> np.float32:

@@ -199,3 +199,28 @@ def add_prolongation(y, x) -> None:
         yd = L.to_device(y, torch.float32)
         ctx.call("pm_prolongation", L.ptr(yd), L.ptr(xd), xd.shape[0], 1)
         y[...] = yd.cpu().numpy()
+
+
+def derivative_interp_vec_kick_rebucket(scheme_name: str, potential, order: int, position, velocity, half_dt, ids=None):
+    """derivative_interp_vec_kick with the kick, writing the particle arrays out of place in tile order
+    (pmstep.h: pm_gradient_interp_kick_rebucket): returns (acceleration, position, velocity, ids) as NEW
+    tensors holding the same particles tile after tile -- the incremental form of utils.reorder_particles
+    (utils.py:1019), for 12 bytes per particle on top of the gather.  Needs the tile lists the fused kick +
+    drift + deposit left prepared for `position`.  `ids`: optional int32 tags carried along."""
+    from . import utils
+
+    torch = L.require_gpu()
+    n = potential.shape[1]
+    scheme = {"cic": L.CIC, "tsc": L.TSC, "ngp": L.NGP}[scheme_name]
+    if order not in (2, 3, 5, 7):
+        raise ValueError(f"{order=}, should be 2, 3, 5 or 7")
+    ctx = L.context(n)
+    acc, pos_out, vel_out = torch.empty_like(position), torch.empty_like(position), torch.empty_like(velocity)
+    ids_out = None if ids is None else torch.empty_like(ids)
+    if ids is not None and (ids.dtype != torch.int32 or not ids.is_contiguous() or ids.shape[0] != position.shape[0]):
+        raise ValueError("ids must be a contiguous int32 tensor with one entry per particle")
+    ctx.call("pm_gradient_interp_kick_rebucket", int(order), scheme, L.ptr(potential), L.ptr(position), L.ptr(velocity),
+             position.shape[0], float(np.float32(half_dt)), L.ptr(pos_out), L.ptr(vel_out), L.ptr(acc), L.ptr(ids),
+             L.ptr(ids_out))
+    utils.register_fused_maxabs(ctx, acc, vel_out)
+    return acc, pos_out, vel_out, ids_out

@@ -28,7 +28,8 @@ def _empty(template):
     return np.empty(0, dtype=np.float32)
 
 
-def pm(position, param, potential=None, additional_field=None, tables: List = (), *, _kick=None, _density=None):
+def pm(position, param, potential=None, additional_field=None, tables: List = (), *, _kick=None, _density=None,
+       _rebucket=None):
     """Acceleration at the particles, potential and (for f(R)/MOND) the extra field.
 
     Mirrors solver.py:30-215: deposit -> density scaling -> [P(k)] -> extra field -> rhs ->
@@ -37,6 +38,9 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     `_kick=(velocity, half_dt)` is the private hook integration.leapfrog uses to fuse its second
     kick (integration.py:262) into the interpolation kernel, and `_density` the density it already
     deposited together with its first kick and drift; neither is part of the reference API.
+    `_rebucket` (a dict, private): ask the gather to write the particle arrays out of place in tile order
+    (mesh.derivative_interp_vec_kick_rebucket); when it did, the dict holds the new "position", "velocity" (and
+    "ids" if it came with some) and the returned acceleration is in the new order.
     """
     from . import slab
 
@@ -84,8 +88,13 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
 
         if fuse_gradient:
             vel, half_dt = (None, 0.0) if _kick is None else _kick
-            acceleration = mesh.derivative_interp_vec_kick(MASS_SCHEME, potential_d,
-                                                           param["gradient_stencil_order"], pos_d, vel, half_dt)
+            if _rebucket is not None and vel is not None and L.is_device_array(position):
+                acceleration, _rebucket["position"], _rebucket["velocity"], _rebucket["ids"] = (
+                    mesh.derivative_interp_vec_kick_rebucket(MASS_SCHEME, potential_d, param["gradient_stencil_order"],
+                                                             pos_d, vel, half_dt, _rebucket.get("ids")))
+            else:
+                acceleration = mesh.derivative_interp_vec_kick(MASS_SCHEME, potential_d,
+                                                               param["gradient_stencil_order"], pos_d, vel, half_dt)
         elif _kick is not None and ncells_1d >= 16:
             if not lists_complete:
                 ctx.call("pm_set_gather_mode", 2)  # chunk / anchor kernel: any particle order through LDS

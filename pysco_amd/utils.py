@@ -155,9 +155,10 @@ def straggler_fraction(ncells_1d: int):
     return s.value / npart.value, bool(complete.value)
 
 
-def reorder_particles(position, velocity=None, acceleration=None):
+def reorder_particles(position, velocity=None, acceleration=None, _order_out=None):
     """Sort particles by Morton key (utils.py:1019).  Unlike the reference's per-thread partial
-    argsort (utils.py:1080-1116) this is always a full, stable sort."""
+    argsort (utils.py:1080-1116) this is always a full, stable sort.  `_order_out` (private): a list that
+    receives the permutation (int64 device tensor: new[i] = old[order[i]])."""
     torch = L.require_gpu()
     pos = L.to_device(position, torch.float32)
     vel = L.to_device(velocity, torch.float32) if velocity is not None else None
@@ -166,8 +167,12 @@ def reorder_particles(position, velocity=None, acceleration=None):
     po = torch.empty_like(pos)
     vo = torch.empty_like(vel) if vel is not None else None
     ao = torch.empty_like(acc) if acc is not None else None
+    order = None
+    if _order_out is not None:
+        order = torch.empty((pos.shape[0],), dtype=torch.int64, device=pos.device)
+        _order_out.append(order)
     ctx.call("pm_reorder_particles", pos.shape[0], L.ptr(pos), L.ptr(vel), L.ptr(acc), L.ptr(po),
-                                         L.ptr(vo), L.ptr(ao), None)
+                                         L.ptr(vo), L.ptr(ao), L.ptr(order))
     if acceleration is not None:
         return L.like_input(po, position), L.like_input(vo, velocity), L.like_input(ao, acceleration)
     if velocity is not None:

@@ -720,7 +720,8 @@ def test_run_nbody_loop_vs_oracle(amd):
             "Om_lambda": 0.742589237, "H0": 72.0, "boxlen": 100.0, "aexp": 0.5, "aexp_old": 0.49,
             "linear_newton_solver": "fft", "gradient_stencil_order": 5, "save_power_spectrum": "no", "nthreads": 1,
             "Courant_factor": 1.0, "max_aexp_stepping": 10, "integrator": "leapfrog", "write_snapshot": False,
-            "n_reorder": 2, "reorder_straggler_fraction": 1.0}  # fixed cadence only, as in the oracle loop below
+            "n_reorder": 2, "reorder_straggler_fraction": 1.0,  # fixed cadence only, as in the oracle loop below
+            "rebucket_straggler_fraction": None}
     base["t"] = float(tables[1](np.log(base["aexp"])))
     z_out = [0.45, 0.6]
 

@@ -1,0 +1,146 @@
+"""GPU tests of the incremental re-sort (pm_gradient_interp_kick_rebucket): the gather writing the particle arrays
+out of place in tile order.  The values must be those of the in-place step (pinned against the oracle and the
+goldens in test_gpu_newton.py); only the particle order may differ, and int32 tags follow it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pysco_oracle as orc  # noqa: E402  (checker only)
+from tests.helpers import zeldovich_particles  # noqa: E402
+
+
+def _tile_keys(pos, n):
+    """Tile of every particle in stream order: 8 x 16 x 16 cells, Morton order of the cells with x most significant
+     == cell-level Morton code >> 11."""
+    c = np.minimum((pos.astype(np.float32) * np.float32(n)).astype(np.int64), n - 1)
+
+    def spread(v):
+        out = np.zeros_like(v)
+        for b in range(11):
+            out |= ((v >> b) & 1) << (3 * b)
+        return out
+
+    return (spread(c[:, 0]) << 2 | spread(c[:, 1]) << 1 | spread(c[:, 2])) >> 11
+
+
+def _run(n, pos_h, vel_h, steps, rebucket, sort_first=True, scheme="TSC", order=5, predict=False):
+    import torch
+
+    import bench
+    from pysco_amd import _lib as L
+    from pysco_amd import integration, solver, utils
+
+    L._ctxs.clear()
+    integration._PREDICT = predict
+    param, tables = bench.make_param(n, pos_h.shape[0])
+    param["mass_scheme"], param["gradient_stencil_order"] = scheme, order
+    if rebucket is not None:
+        param["rebucket_straggler_fraction"] = rebucket
+    pos, vel = torch.from_numpy(pos_h).cuda(), torch.from_numpy(vel_h).cuda()
+    ids = torch.arange(pos.shape[0], dtype=torch.int32, device="cuda")
+    if sort_first:
+        order_out = []
+        pos, vel = utils.reorder_particles(pos, vel, _order_out=order_out)
+        ids = ids[order_out[0]].contiguous()
+    param["particle_id"] = ids
+    acc, pot, extra = solver.pm(pos, param, tables=tables)
+    fracs = []
+    for _ in range(steps):
+        pos, vel, acc, pot, extra = integration.integrate(pos, vel, acc, pot, extra, tables, param, np.float32(3e38))
+        fracs.append(utils.straggler_fraction(n)[0])
+    integration._PREDICT = True
+    ids = param["particle_id"].cpu().numpy()
+    assert np.array_equal(np.sort(ids), np.arange(pos.shape[0]))  # a permutation: nobody lost, nobody twice
+    inv = np.argsort(ids)
+    return pos.cpu().numpy(), vel.cpu().numpy(), acc.cpu().numpy(), inv, fracs, param
+
+
+@pytest.mark.parametrize("n,npart_1d,scheme,order", [(64, 64, "TSC", 5), (64, 48, "CIC", 3), (32, 64, "TSC", 7),
+                                                     (128, 96, "TSC", 2)])
+def test_rebucket_steps_match_inplace_steps(n, npart_1d, scheme, order):
+    """Four leapfrog steps re-bucketing in every one of them vs the same steps in place: same particles (by tag),
+    same positions / velocities / accelerations; the stream comes out tile-sorted; (32, 64): 8 particles per
+    cell, every tile range is split over several workgroups."""
+    pos_h, vel_h = zeldovich_particles(npart_1d, seed=3, rms_cells=0.7 * npart_1d / n, vel_factor=0.3)
+    ref = _run(n, pos_h, vel_h, 4, None, scheme=scheme, order=order)
+    new = _run(n, pos_h, vel_h, 4, 0.0, scheme=scheme, order=order)
+    assert ref[5]["t"] == pytest.approx(new[5]["t"], rel=1e-6)
+    for k, tol in ((0, 2e-6), (1, None), (2, None)):
+        a, b = ref[k][ref[3]], new[k][new[3]]
+        if k == 0:
+            d = np.abs(a - b)
+            assert np.minimum(d, 1 - d).max() <= tol
+        else:
+            assert np.abs(a - b).max() <= 2e-4 * np.abs(a).max()
+    keys = _tile_keys(new[0], n)
+    assert np.all(np.diff(keys) >= 0), "re-bucketed stream is not in tile order"
+    assert max(ref[4]) > 0  # (the in-place stream has stragglers)
+
+
+def test_rebucket_sorts_an_unsorted_stream_and_keeps_oracle_parity():
+    """An unsorted (lattice-order) stream: every particle is a straggler, the lists hold them all, and one
+    re-bucketing step is a full tile sort.  Values against the CPU oracle's leapfrog step, particle by tag."""
+    n = 32
+    pos_h, vel_h = zeldovich_particles(n, seed=9, rms_cells=0.5, vel_factor=0.3)
+    pos, vel, acc, inv, fracs, param = _run(n, pos_h, vel_h, 2, 0.0, sort_first=False)
+    assert fracs[0] > 0.2 and fracs[1] < 0.5 * fracs[0]  # second step: only that step's crossers
+    import bench
+
+    par, tables = bench.make_param(n, n**3)
+    p, v = pos_h.copy(), vel_h.copy()
+    a, phi, extra = orc.pm(p, par, tables=tables)
+    for _ in range(2):
+        p, v, a, phi, extra = orc.integrate(p, v, a, phi, extra, tables, par, np.float32(3e38))
+    d = np.abs(pos[inv] - p)
+    assert np.minimum(d, 1 - d).max() < 1e-5
+    assert np.abs(vel[inv] - v).max() <= 2e-5 * np.abs(v).max()
+    assert np.abs(acc[inv] - a).max() <= 2e-4 * np.abs(a).max()
+    assert np.all(np.diff(_tile_keys(pos, n)) >= 0)
+
+
+def test_rebucket_threshold_policy_and_table_reuse():
+    """With a threshold the steps alternate between in-place and re-bucketing ones; a re-bucketed stream enters the
+    next fused kick with its tile offsets on file (no range search) and shows only that step's crossers."""
+    n = 64
+    pos_h, vel_h = zeldovich_particles(n, seed=4, rms_cells=0.6, vel_factor=0.3)
+    ref = _run(n, pos_h, vel_h, 6, None)
+    new = _run(n, pos_h, vel_h, 6, 0.005)
+    assert sum(new[4]) < sum(ref[4])  # the stragglers no longer pile up
+    d = np.abs(ref[0][ref[3]] - new[0][new[3]])
+    assert np.minimum(d, 1 - d).max() <= 3e-6
+
+
+@pytest.mark.parametrize("n,npart_1d", [(64, 64), (32, 64), (16, 32)])
+def test_rebucket_with_predicted_destinations(n, npart_1d):
+    """Filing every particle under the tile it is expected to be in after the NEXT drift (pm_set_predicted_dt):
+    same values as the in-place steps, and far fewer stragglers per step than filing under the current tile.
+    (16, 32): two tiles along x, where the -1 and +1 neighbours are the same tile."""
+    pos_h, vel_h = zeldovich_particles(npart_1d, seed=6, rms_cells=0.7 * npart_1d / n, vel_factor=0.5)
+    ref = _run(n, pos_h, vel_h, 6, None)
+    exact = _run(n, pos_h, vel_h, 6, 0.0)
+    pred = _run(n, pos_h, vel_h, 6, 0.0, predict=True)
+    for k in range(3):
+        a, b = ref[k][ref[3]], pred[k][pred[3]]
+        if k == 0:
+            d = np.abs(a - b)
+            assert np.minimum(d, 1 - d).max() <= 3e-6
+        else:
+            assert np.abs(a - b).max() <= 2e-4 * np.abs(a).max()
+    if n >= 32:
+        assert sum(pred[4][2:]) < 0.5 * sum(exact[4][2:]), (pred[4], exact[4])
+
+
+def test_rebucket_requires_prepared_lists():
+    import torch
+
+    from pysco_amd import _lib as L
+    from pysco_amd import mesh
+
+    n = 32
+    pos = torch.rand((1000, 3), device="cuda")
+    vel = torch.zeros_like(pos)
+    phi = torch.zeros((n, n, n), device="cuda")
+    L._ctxs.clear()
+    with pytest.raises(L.PMStepError, match="no stay counts prepared"):
+        mesh.derivative_interp_vec_kick_rebucket("tsc", phi, 5, pos, vel, 0.1)
