@@ -1707,6 +1707,10 @@ __device__ __noinline__ Acc3 gather_phi_global(const float *__restrict__ phi, fl
 // its destination tile (dest_of: the tile it is expected to be in after the next drift) the stream comes out
 // sorted for 12 more bytes per particle (the position), where a sort by key costs a dozen passes.  The order
 // inside a tile is the order of arrival (nothing depends on it: the tile sums of the deposit are integer sums).
+struct __attribute__((packed, aligned(4))) Packed3 {
+    float a, b, c;
+};
+
 struct Rebucket {
     const int64_t *newstart;  // [ntiles + 1] offsets of the re-bucketed stream
     unsigned *fill;           // [ntiles] cleared: whoever sends particles to a tile takes a slice of its range here
@@ -1940,17 +1944,19 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                 if (d64 >= rb.newstart[dd.key + 1]) d64 = -1;  // (memory safety, as above)
             }
             if (d64 >= 0) {
-                float *op = rb.acc_out + 3 * d64, *wp = rb.vel_out + 3 * d64, *xo = rb.pos_out + 3 * d64;
-                xo[0] = x, xo[1] = y, xo[2] = z;
-                if (rb.id) rb.id_out[d64] = rb.id[src_index];
+                // three 12-byte stores (written field by field through the three output pointers the compiler
+                // keeps them apart as nine dword stores, each touching every line of the wave's span)
+                float w[3];
 #pragma unroll
                 for (int mm = 0; mm < 3; ++mm) {
-                    op[mm] = a[mm];
                     ma = max(ma, __float_as_uint(a[mm]) & 0x7fffffffu);
-                    const float w = v[mm] + mhalf_dt * a[mm];
-                    wp[mm] = w;
-                    mv = max(mv, __float_as_uint(w) & 0x7fffffffu);
+                    w[mm] = v[mm] + mhalf_dt * a[mm];
+                    mv = max(mv, __float_as_uint(w[mm]) & 0x7fffffffu);
                 }
+                *reinterpret_cast<Packed3 *>(rb.pos_out + 3 * d64) = Packed3{x, y, z};
+                *reinterpret_cast<Packed3 *>(rb.acc_out + 3 * d64) = Packed3{a[0], a[1], a[2]};
+                *reinterpret_cast<Packed3 *>(rb.vel_out + 3 * d64) = Packed3{w[0], w[1], w[2]};
+                if (rb.id) rb.id_out[d64] = rb.id[src_index];
             }
         } else if (!skip) {
             float *op = o + 3 * p, *wp = w3 + 3 * p;

@@ -17,6 +17,8 @@ import numpy as np
 from . import _lib as L
 from . import integration, solver, utils
 
+__version__ = "1.0.9"  # of the reference release whose main.run this mirrors
+
 
 REBUCKET_FRACTION = 0.0    # default of param["rebucket_straggler_fraction"] in this loop (device arrays): every step
                            # that found a straggler re-buckets (measured at 1024^3: 47.7 ms per step sustained against
@@ -89,7 +91,9 @@ def run_nbody(position, velocity, param, tables: List, z_out: Sequence[float],
         param["i_snap"] = 1
     else:
         param["i_snap"] += 1
-    while param["aexp"] < aexp_out[-1]:
+    # (second condition: the last snapshot's time is hit exactly, but exp(lna(t(ln a)))) may come back one ulp
+    # below a; the reference then indexes t_out out of bounds, main.py:135)
+    while param["aexp"] < aexp_out[-1] and param["i_snap"] <= len(t_out):
         param["nsteps"] += 1
         position, velocity, acceleration, potential, additional_field = integration.integrate(
             position, velocity, acceleration, potential, additional_field, tables, param,
@@ -103,3 +107,85 @@ def run_nbody(position, velocity, param, tables: List, z_out: Sequence[float],
             on_step(param)
         logging.info(f"{param['nsteps']=} {param['aexp']=} z = {1.0 / param['aexp'] - 1}")
     return position, velocity, acceleration, potential, additional_field
+
+
+def run(param) -> None:
+    """Drop-in for the reference's main.run (main.py:30-156): logging level, output directories, background tables
+    (pysco_amd.cosmotable, astropy-free), initial conditions (pysco_amd.initial_conditions: snapshot restart or LPT),
+    then run_nbody with snapshots written by pysco_amd.iostream.  `param`: dict or pandas Series (the reference's
+    container); it is updated in place like the reference's Series.  The particle state lives on the GPU for the
+    whole run: no CPU fallback."""
+    import ast
+    import os
+
+    from . import cosmotable, initial_conditions, iostream
+
+    levels = {0: logging.ERROR, 1: logging.WARNING, 2: logging.INFO}
+    if param["verbose"] not in levels:
+        raise ValueError(f"{param['verbose']=}, should be 0, 1 or 2")
+    logging.basicConfig(level=levels[param["verbose"]], format="%(message)s", force=True)
+    if not (isinstance(param, dict) or type(param).__name__ == "Series"):
+        raise ValueError(f"{type(param)=}, should be a dictionnary or a Pandas Series")
+    target, param = param, dict(param.items())
+    param["write_snapshot"] = False
+    if not param["nthreads"] > 0:
+        param["nthreads"] = os.cpu_count() or 1  # host threads are irrelevant here; the key keeps its meaning
+    logging.warning("FFT module: fused LDS FFT / rocFFT (MI355X)")
+
+    extra = param["theory"].casefold()
+    if extra == "fr":
+        extra += f"{param['fR_logfR0']}_n{param['fR_n']}"
+    elif extra == "mond":
+        mond_function = param["mond_function"].casefold()
+        extra += f"_g0_{param['mond_g0']}_exponent_{param['mond_scale_factor_exponent']}_{mond_function}"
+        if mond_function != "simple":
+            extra += f"_{param['mond_alpha']}"
+    elif extra == "parametrized":
+        extra += f"_mu0_{param['parametrized_mu0']}"
+    extra += f"_{param['linear_newton_solver']}_ncoarse{param['ncoarse']}"
+    param["extra"] = extra
+    z_out = ast.literal_eval(param["z_out"]) if isinstance(param["z_out"], str) else list(param["z_out"])
+    os.makedirs(f"{param['base']}/power", exist_ok=True)
+    for i in range(len(z_out) + 1):
+        os.makedirs(f"{param['base']}/output_{i:05d}", exist_ok=True)
+
+    logging.warning("----- Compute background cosmology -----")
+    tables = cosmotable.generate(param)
+    param["aexp"] = 1.0 / (1 + param["z_start"])  # (aexp and t are overwritten when a snapshot is read)
+    utils.set_units(param)
+    if "nsteps" not in param:
+        param["nsteps"] = 0
+    logging.warning("----- Initial conditions -----")
+    position, velocity = initial_conditions.generate(param, tables)
+    utils.set_units(param)
+    param["t"] = float(tables[1](np.log(param["aexp"])))
+    logging.warning(f"{param['aexp']=} {param['t']=}")
+    logging.warning("----- Run N-body -----")
+    torch = L.require_gpu()
+    position = L.to_device(position, torch.float32)
+    velocity = L.to_device(velocity, torch.float32)
+    try:
+        return_state = run_nbody(position, velocity, param, tables, z_out, on_snapshot=iostream.write_snapshot_particles)
+    finally:
+        for k, v in param.items():  # the caller's container sees what the reference's Series would hold
+            if not k.startswith("_") and not type(v).__module__.startswith("torch"):
+                target[k] = v
+    return return_state
+
+
+def main() -> None:
+    """python -m pysco_amd.main -c param.ini   (main.py:159-176)"""
+    import argparse
+
+    from . import iostream
+
+    parser = argparse.ArgumentParser(description="Run a PM N-body simulation on an MI355X (PySCo-compatible parameter file).")
+    parser.add_argument("-c", "--config_file", help="Configuration file", required=True)
+    args = parser.parse_args()
+    print(f"pysco_amd (drop-in for PySCo {__version__})\nrun parameters {args.config_file}")
+    run(iostream.read_param_file(args.config_file))
+    print("Run Completed!")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+"""GPU tests of the run driver (pysco_amd.main.run: parameter container -> tables -> initial conditions -> step loop
+-> snapshots), SURVEY.md section 8 rows f1 / f2: the example configuration end to end against the same loop written
+with the CPU oracle, and a restart from a snapshot against the uninterrupted run."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pysco_oracle as orc  # noqa: E402  (checker only)
+from tests.helpers import zeldovich_particles  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _example_param(tmp_path, **over):
+    from pysco_amd import iostream
+
+    param = dict(iostream.read_param_file(os.path.join(ROOT, "examples", "param.ini")).items())
+    param.update(base=str(tmp_path), verbose=0, save_power_spectrum="no")
+    param.update(over)
+    return param
+
+
+def _write_initial_snapshot(param, pos, vel, aexp):
+    """Initial conditions as snapshot 0 of the run (the restart path of initial_conditions.generate)."""
+    from pysco_amd import iostream
+
+    extra = f"{param['theory'].casefold()}_{param['linear_newton_solver']}_ncoarse{param['ncoarse']}"
+    snap = {"base": param["base"], "extra": extra, "i_snap": 0, "aexp": aexp, "nsteps": 0,
+            "output_snapshot_format": param["output_snapshot_format"]}
+    iostream.write_snapshot_particles(pos, vel, snap)
+
+
+def test_example_run_end_to_end_vs_oracle_loop(tmp_path):
+    """examples/param.ini (Newton, 128^3 mesh and particles, TSC, multigrid solver, order-5 gradient, leapfrog): ten
+    steps from z = 49 through main.run on the device, snapshots at two redshifts, against the oracle's loop on the
+    same tables.  (Initial conditions: a Zel'dovich-like particle set handed in as snapshot 0.)"""
+    import copy
+
+    from pysco_amd import cosmotable, iostream
+    from pysco_amd import main as amd_main
+
+    n = 128
+    pos, vel = zeldovich_particles(n, seed=12, rms_cells=0.3, vel_factor=0.02)
+    pos, vel = orc.reorder_particles(pos, vel)  # Morton order: the run then has no reason to permute the particles
+    z_out = "[30, 18]"
+    param = _example_param(tmp_path, z_out=z_out, initial_conditions=0, output_snapshot_format="parquet",
+                           rebucket_straggler_fraction=None, n_reorder=1000, reorder_straggler_fraction=1.0)
+    _write_initial_snapshot(param, pos, vel, 1.0 / 50)
+    ref_param = copy.deepcopy(param)
+    amd_main.run(param)
+    assert param["nsteps"] >= 8 and param["i_snap"] == 3
+
+    # the same loop with the oracle (main.py:97-156), same tables
+    par = ref_param
+    par["extra"] = param["extra"]
+    tables = cosmotable.generate(par)
+    par["aexp"] = 1.0 / 50
+    par["write_snapshot"] = False
+    orc.set_units(par)
+    par["nsteps"] = 0
+    par["t"] = float(tables[1](np.log(par["aexp"])))
+    p, v = pos.copy(), vel.copy()
+    acc, phi, extra = orc.pm(p, par, tables=tables)
+    aexp_out = np.sort(1.0 / (np.array([30, 18]) + 1.0))
+    t_out = tables[1](np.log(aexp_out))
+    par["i_snap"] = 1
+    snaps = []
+    while par["aexp"] < aexp_out[-1] and par["i_snap"] <= len(t_out):  # (as run_nbody: see its comment)
+        par["nsteps"] += 1
+        p, v, acc, phi, extra = orc.integrate(p, v, acc, phi, extra, tables, par, t_out[par["i_snap"] - 1])
+        if par["write_snapshot"]:
+            snaps.append((par["aexp"], p.copy(), v.copy()))
+            par["i_snap"] += 1
+    assert par["nsteps"] == param["nsteps"]
+    assert abs(par["aexp"] - param["aexp"]) < 1e-6
+    for i, (a_ref, p_ref, v_ref) in enumerate(snaps, start=1):
+        d = f"{tmp_path}/output_{i:05d}"
+        p_dev, v_dev = iostream.read_snapshot_particles_parquet(f"{d}/particles_{param['extra']}.parquet")
+        side = iostream.read_param_file(f"{d}/param_{param['extra']}_{i:05d}.txt")
+        assert abs(float(side["aexp"]) - a_ref) < 1e-6 and int(side["i_snap"]) == i
+        dd = np.abs(p_dev - p_ref)
+        assert np.minimum(dd, 1 - dd).max() < 1e-5  # positions after ten steps
+        assert np.abs(v_dev - v_ref).max() < 2e-3 * np.abs(v_ref).max()
+
+
+@pytest.mark.parametrize("fmt", ["hdf5", "parquet"])
+def test_restart_reproduces_the_uninterrupted_run(tmp_path, fmt):
+    """Run A: z = 49 -> 30 -> 22 in one go.  Run B: the same parameter file restarted from A's snapshot 1
+    (initial_conditions = 1, initial_conditions.py:79-107).  Same final particles to 1e-5."""
+    from pysco_amd import iostream
+    from pysco_amd import main as amd_main
+
+    n = 64
+    pos, vel = zeldovich_particles(n, seed=2, rms_cells=0.4, vel_factor=0.02)
+    pos, vel = orc.reorder_particles(pos, vel)
+    common = dict(ncoarse=6, npart=n**3, linear_newton_solver="fft", output_snapshot_format=fmt,
+                  rebucket_straggler_fraction=None, n_reorder=1000, reorder_straggler_fraction=1.0)
+    a_dir = tmp_path / "a"
+    pa = _example_param(a_dir, z_out="[30, 22]", initial_conditions=0, **common)
+    _write_initial_snapshot(pa, pos, vel, 1.0 / 50)
+    amd_main.run(pa)
+    ext = "h5" if fmt == "hdf5" else "parquet"
+    read = iostream.read_snapshot_particles_hdf5 if fmt == "hdf5" else iostream.read_snapshot_particles_parquet
+    final_a = read(f"{a_dir}/output_00002/particles_{pa['extra']}.{ext}")
+
+    # (a restart takes every parameter of the snapshot, `base` included: it continues in the directory of run A)
+    os.rename(f"{a_dir}/output_00002", f"{a_dir}/output_00002_run_a")
+    pb = _example_param(a_dir, z_out="[30, 22]", initial_conditions=1, **common)
+    amd_main.run(pb)
+    assert pb["nsteps"] == pa["nsteps"] and pb["i_snap"] == pa["i_snap"]
+    final_b = read(f"{a_dir}/output_00002/particles_{pb['extra']}.{ext}")
+    d = np.abs(final_a[0] - final_b[0])
+    assert np.minimum(d, 1 - d).max() < 1e-5
+    assert np.abs(final_a[1] - final_b[1]).max() < 1e-4 * np.abs(final_a[1]).max()
