@@ -94,6 +94,15 @@ int pm_greens(pm_ctx *ctx, int kind, int p, void *d_xk, const float *h_k2, const
 /* fourier_grid_to_Pk :22-100: bins |k| into int(|k|+0.5), deconvolves sinc^p, also zeroes
  * d_xk[0,0,0].  Outputs are host arrays of length n: per-bin sums of |k|, |delta_k|^2, counts
  * (the caller slices [1:kmax] and divides, as :94-99). */
+/* fourier.gradient_inverse_laplacian (fourier.py:606, p = 0) / gradient_inverse_laplacian_compensated (:660,
+ * p = MAS order): the force of the `full_fft` solver in k-space, out_m = -i k_m / (2 pi k^2) W^(-2p) x with the
+ * k = 0 mode zeroed.  d_out3 receives three half-spectra [3][n, n, n/2+1] complex64 (planar: each goes through
+ * pm_fft_c2r on its own; the reference's [n, n, n/2+1, 3] layout is a host-side view).  h_kfreq: signed
+ * frequencies i or i - n as fp32; h_sinc: sinc(k h) per axis as for pm_pk. */
+int pm_grad_inverse_laplacian(pm_ctx *ctx, int p, const void *d_xk, void *d_out3, const float *h_kfreq,
+                              const float *h_sinc);
+/* three planar arrays of m floats -> [m, 3] (the force grid's layout; the tail of fourier.ifft_3D_real_grad, :343) */
+int pm_interleave3(pm_ctx *ctx, const float *d_planar, int64_t m, float *d_out);
 int pm_pk(pm_ctx *ctx, int p, void *d_xk, const float *h_sinc, double *h_ksum, double *h_pksum,
           double *h_nmodes);
 

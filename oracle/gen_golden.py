@@ -147,6 +147,42 @@ def g_kspace():
         save(f"kspace_n{n}", **out)
 
 
+def g_kspace_grad():
+    """G3 (force form): gradient_inverse_laplacian(_compensated) (fourier.py:606-719), ifft_3D_real_grad (:343-396)
+    and solver.fft_force (solver.py:524-566) -- the pieces of the `full_fft` solver, which pm() itself cannot
+    reach in the reference (solver.py:181, 200 call the two-argument fft_force with three)."""
+    for n in (16, 32):
+        rng = np.random.default_rng(20 + n)  # the same field as kspace_n{n}
+        x = rng.normal(size=(n, n, n)).astype(np.float32)
+        xk = fourier.fft_3D_real(x, 1)
+        out = {"x": x, "xk": xk}
+        with np.errstate(all="ignore"):
+            out["grad_plain"] = fourier.gradient_inverse_laplacian(xk.copy())
+            out["grad_comp2"] = fourier.gradient_inverse_laplacian_compensated(xk.copy(), 2)
+            out["grad_comp3"] = fourier.gradient_inverse_laplacian_compensated(xk.copy(), 3)
+        out["ifft_grad_comp3"] = fourier.ifft_3D_real_grad(out["grad_comp3"].copy(), 1)
+        if n == 32:  # keep the fixture small: the larger size pins the force itself
+            for k in ("grad_plain", "grad_comp2", "grad_comp3", "xk"):
+                del out[k]
+        for mas in (0, 3):
+            param = base_param(int(np.log2(n)), n**3, MAS_index=mas, save_pk=False, parametrized_mu_z=f32(1))
+            with np.errstate(all="ignore"):
+                out[f"fft_force_mas{mas}"] = solver.fft_force(x.copy(), param)
+        save(f"kspace_grad_n{n}", **out)
+
+
+def g_pm_parametrized():
+    """f4: solver.pm with theory = parametrized (mu(z) of solver.py:95-112), FFT and multigrid solvers."""
+    n, nc = 32, 5
+    pos, _ = particles_lattice(50, n, 0.8)
+    for tag, kw in (("fft", dict(theory="parametrized", parametrized_mu0=-0.1, Om_r=8.07417e-05)),
+                    ("multigrid", dict(theory="parametrized", parametrized_mu0=0.2, Om_r=8.07417e-05, w0=-0.9, wa=0.1,
+                                       linear_newton_solver="multigrid"))):
+        param, acc, pot, extra = _pm_case(tag, n, nc, pos, **kw)
+        save(f"pm_parametrized_{tag}", pos=pos, acc=acc, pot=pot, extra=extra, param_json=np.array(param_to_json(param)))
+        print("   mu(z) =", param["parametrized_mu_z"])
+
+
 def g_gradient():
     """G5: finite-difference gradients (mesh.py:639-850) and the f(R) fused variants (:860-2069)."""
     n = 16
@@ -500,7 +536,7 @@ GROUPS = {
     "deposit": g_deposit, "kspace": g_kspace, "gradient": g_gradient, "utils": g_utils,
     "pm_newton": g_pm_newton, "pk_pm": g_pk_pm, "integrate": g_integrate,
     "multigrid": g_multigrid, "cubic": g_cubic, "mond": g_mond, "pm_mg": g_pm_mg,
-    "quartic": g_quartic, "pm_fr2": g_pm_fr2,
+    "quartic": g_quartic, "pm_fr2": g_pm_fr2, "kspace_grad": g_kspace_grad, "pm_parametrized": g_pm_parametrized,
 }
 
 if __name__ == "__main__":

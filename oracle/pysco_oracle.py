@@ -283,6 +283,57 @@ def inverse_laplacian_7pt(x) -> None:  # fourier.py:555-595
     _apply_greens(x, 2, 0, np.zeros(n, np.float32), f, minus_h2_inv4)
 
 
+def _grad_inverse_laplacian(x, p: int) -> np.ndarray:
+    """-i k_j / (2 pi k^2) [W(k)^(-2p)] x, fp32 arithmetic in the reference's order (fourier.py:606-719); p = 0: no
+    compensation.  (0 - i c)(a + i b) = c b - i c a exactly, then each component times k_j."""
+    assert x.dtype == np.complex64
+    n = x.shape[0]
+    nh = n // 2 + 1
+    k = _kfreq(n)
+    kz = np.arange(nh, dtype=np.float32)
+    invtwopi = np.float32(0.5 / np.pi)
+    with np.errstate(all="ignore"):
+        k2 = ((k**2)[:, None] + (k**2)[None, :])[:, :, None] + (kz**2)[None, None, :]
+        c = invtwopi / k2
+        if p:
+            h = np.float32(1.0 / n)
+            w = (np.sinc(k * h)[:, None] * np.sinc(k * h)[None, :])[:, :, None] * np.sinc(kz * h)[None, None, :]
+            c = (w.astype(np.float32) ** (-2 * p)).astype(np.float32) * c
+        re, im = c * x.imag, -(c * x.real)
+        out = np.empty((n, n, nh, 3), dtype=np.complex64)
+        for m, km in enumerate((k[:, None, None], k[None, :, None], kz[None, None, :])):
+            out[..., m] = (re * km) + 1j * (im * km)
+    out[0, 0, 0, :] = 0
+    return out
+
+
+def gradient_inverse_laplacian(x) -> np.ndarray:  # fourier.py:606-657
+    return _grad_inverse_laplacian(x, 0)
+
+
+def gradient_inverse_laplacian_compensated(x, p: int) -> np.ndarray:  # fourier.py:660-719
+    return _grad_inverse_laplacian(x, int(p))
+
+
+def ifft_3D_real_grad(x, threads: int = 1) -> np.ndarray:  # fourier.py:343-396 (NumPy fallback :370-371)
+    return np.ascontiguousarray(np.fft.irfftn(x, axes=(0, 1, 2)).astype(np.float32))
+
+
+def fft_force(rhs, param, pk_out: list | None = None) -> np.ndarray:  # solver.py:524-566
+    MAS_index = param["MAS_index"]
+    rhs_fourier = fft_3D_real(rhs)
+    force = gradient_inverse_laplacian(rhs_fourier) if MAS_index == 0 else gradient_inverse_laplacian_compensated(
+        rhs_fourier, MAS_index)
+    if param.get("save_pk", False):
+        k, Pk, Nmodes = fourier_grid_to_Pk(rhs_fourier, MAS_index)
+        Pk = Pk * np.float32((param["boxlen"] / len(rhs) ** 2) ** 3 / (1.5 * param["aexp"] * param["Om_m"]) ** 2
+                             / param["parametrized_mu_z"] ** 2)
+        k = k * np.float32(2 * np.pi / param["boxlen"])
+        if pk_out is not None:
+            pk_out.append((k, Pk, Nmodes))
+    return ifft_3D_real_grad(force)
+
+
 def fourier_grid_to_Pk(density_k, p: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:  # fourier.py:22-100
     assert density_k.dtype == np.complex64 and density_k.flags.c_contiguous
     n = density_k.shape[0]
@@ -395,14 +446,24 @@ def pm(position, param, potential=None, additional_field=None, tables=(), pk_out
     elif solver in ("fft", "fft_7pt"):
         potential = fft(rhs, param, pk_out)
     elif solver == "full_fft":
-        # the reference's full_fft branch calls fft_force with 3 args (solver.py:181,200) -> TypeError
-        raise TypeError("fft_force() takes 2 positional arguments but 3 were given")
+        # The reference's full_fft branch calls the two-argument fft_force with three (solver.py:181, 200) and dies
+        # with TypeError; with param["full_fft_reference_bug"] set the restatement does the same.  Otherwise it does
+        # what the branch spells out: the potential is left alone and the force comes from fft_force (solver.py:524).
+        if param.get("full_fft_reference_bug", False):
+            raise TypeError("fft_force() takes 2 positional arguments but 3 were given")
     else:
         raise NotImplementedError(f"{param['linear_newton_solver']=}, should be multigrid, fft, fft_7pt or full_fft")
 
     if theory == "fr":
         half_c2 = fr_half_c2(param)
-        force = derivative_fR(potential, additional_field, half_c2, param["fR_n"], param["gradient_stencil_order"])
+        if solver == "full_fft":  # solver.py:181-189: force += half_c2 grad(u^(n+1)) (mesh.add_derivative_fR)
+            force = fft_force(rhs, param, pk_out)
+            force = force + derivative_fR(np.zeros_like(additional_field), additional_field, half_c2, param["fR_n"],
+                                          param["gradient_stencil_order"])
+        else:
+            force = derivative_fR(potential, additional_field, half_c2, param["fR_n"], param["gradient_stencil_order"])
+    elif solver == "full_fft":
+        force = fft_force(rhs, param, pk_out)
     else:
         force = derivative(potential, param["gradient_stencil_order"])
 

@@ -47,6 +47,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_fft_r2c": (_vp, _vp, _vp),
     "pm_fft_c2r": (_vp, _vp, _vp),
     "pm_greens": (_vp, _i, _i, _vp, _vp, _vp, _f),
+    "pm_grad_inverse_laplacian": (_vp, _i, _vp, _vp, _vp, _vp),
+    "pm_interleave3": (_vp, _vp, _i64, _vp),
     "pm_pk": (_vp, _i, _vp, _vp, _vp, _vp, _vp),
     "pm_poisson_fft": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),
     "pm_poisson_fft_fused": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),

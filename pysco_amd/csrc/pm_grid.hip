@@ -529,6 +529,69 @@ extern "C" int pm_greens_slab(pm_ctx *c, int kind, int p, void *d_xk, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// Force in k-space (fourier.py:606-719): out_m = -i k_m / (2 pi k^2) [W^(-2p)] x, the `full_fft` solver's
+// gradient of the inverse Laplacian.  Planar output (three half-spectra), each inverse-transformed on its own.
+// (0 - i c)(a + i b) = c b - i c a exactly, then each component times k_m: the reference's rounding.
+
+template <bool COMP>
+__global__ __launch_bounds__(BLK) void grad_greens_kernel(const float2 *__restrict__ x, int n, int p,
+                                                          const float *__restrict__ kf, const float *__restrict__ s,
+                                                          float2 *__restrict__ out) {
+    const int nh = (n >> 1) + 1;
+    const int64_t total = (int64_t)n * n * nh;
+    const float invtwopi = (float)(0.5 / 3.14159265358979323846);
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t % nh);
+        const int64_t ij = t / nh;
+        const int j = (int)(ij % n), i = (int)(ij / n);
+        const float kx = kf[i], ky = kf[j], kz = (float)k;
+        float c = invtwopi / ((kx * kx + ky * ky) + kz * kz);
+        if (COMP) {
+            const float w = (s[i] * s[j]) * s[k];
+            c = powf(w, (float)(-2 * p)) * c;
+        }
+        const float2 v = x[t];
+        float re = c * v.y, im = -(c * v.x);
+        if (t == 0) re = 0.f, im = 0.f;  // result[0, 0, 0, :] = 0 (fourier.py:656, 718)
+        out[t] = make_float2(re * kx, im * kx);
+        out[total + t] = make_float2(re * ky, im * ky);
+        out[2 * total + t] = make_float2(re * kz, im * kz);
+    }
+}
+
+extern "C" int pm_grad_inverse_laplacian(pm_ctx *c, int p, const void *d_xk, void *d_out3, const float *h_kfreq,
+                                         const float *h_sinc) {
+    PM_REQUIRE(c && d_xk && d_out3 && h_kfreq && h_sinc && p >= 0, "bad argument");
+    const int n = c->n;
+    PM_HIP(hipMemcpyAsync(c->d_tab, h_kfreq, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    PM_HIP(hipMemcpyAsync(c->d_tab + n, h_sinc, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const int64_t total = (int64_t)n * n * (n / 2 + 1);
+    const int blocks = pm_stream_blocks(total, BLK * 2);
+    const float2 *x = reinterpret_cast<const float2 *>(d_xk);
+    float2 *out = reinterpret_cast<float2 *>(d_out3);
+    if (p > 0)
+        hipLaunchKernelGGL((grad_greens_kernel<true>), dim3(blocks), dim3(BLK), 0, c->stream, x, n, p, c->d_tab, c->d_tab + n, out);
+    else
+        hipLaunchKernelGGL((grad_greens_kernel<false>), dim3(blocks), dim3(BLK), 0, c->stream, x, n, p, c->d_tab, c->d_tab + n, out);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// three planar arrays of m elements -> one [m, 3] array (the force grid's layout)
+__global__ __launch_bounds__(BLK) void interleave3_kernel(const float *__restrict__ a, int64_t m, float *__restrict__ out) {
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < m; t += (int64_t)gridDim.x * BLK) {
+        out[3 * t] = a[t], out[3 * t + 1] = a[m + t], out[3 * t + 2] = a[2 * m + t];
+    }
+}
+
+extern "C" int pm_interleave3(pm_ctx *c, const float *d_planar, int64_t m, float *d_out) {
+    PM_REQUIRE(c && d_planar && d_out && m > 0, "bad argument");
+    hipLaunchKernelGGL(interleave3_kernel, dim3(pm_stream_blocks(m, BLK)), dim3(BLK), 0, c->stream, d_planar, m, d_out);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // P(k) estimator (fourier.py:22-100).  Per-block LDS histograms in fp32 (the reference keeps one
 // private fp32 histogram per i-plane), flushed to fp64 global bins.
 

@@ -88,6 +88,51 @@ def inverse_laplacian_7pt(x) -> None:  # fourier.py:555
     _greens_inplace(x, L.GREEN_7PT, 0)
 
 
+def _grad_planar(xk, p: int):
+    """Three planar half-spectra [3, n, n, n/2+1] of the k-space force (device tensors)."""
+    torch = L.require_gpu()
+    n = xk.shape[0]
+    out = torch.empty((3, n, n, n // 2 + 1), dtype=torch.complex64, device=xk.device)
+    k = _kfreq(n)
+    sincs = np.sinc(k * np.float32(1.0 / n)).astype(np.float32)
+    L.context(n).call("pm_grad_inverse_laplacian", int(p), L.ptr(xk), L.ptr(out), L.hptr(k), L.hptr(sincs))
+    return out
+
+
+def gradient_inverse_laplacian(x):
+    """-i k / (2 pi k^2) x as [n, n, n/2+1, 3] complex64 (fourier.py:606)."""
+    torch = L.require_gpu()
+    out = _grad_planar(L.to_device(x, torch.complex64), 0).permute(1, 2, 3, 0).contiguous()
+    return L.like_input(out, x)
+
+
+def gradient_inverse_laplacian_compensated(x, p: int):
+    """The same with the mass-assignment window deconvolved, W^(-2p) (fourier.py:660)."""
+    torch = L.require_gpu()
+    out = _grad_planar(L.to_device(x, torch.complex64), int(p)).permute(1, 2, 3, 0).contiguous()
+    return L.like_input(out, x)
+
+
+def _ifft_grad_planar(planar):
+    """[3, n, n, n/2+1] complex64 (destroyed) -> force grid [n, n, n, 3] float32."""
+    torch = L.require_gpu()
+    n = planar.shape[1]
+    ctx = L.context(n)
+    real = torch.empty((3, n, n, n), dtype=torch.float32, device=planar.device)
+    for m in range(3):
+        ctx.call("pm_fft_c2r", L.ptr(planar[m]), L.ptr(real[m]))
+    out = torch.empty((n, n, n, 3), dtype=torch.float32, device=planar.device)
+    ctx.call("pm_interleave3", L.ptr(real), n**3, L.ptr(out))
+    return out
+
+
+def ifft_3D_real_grad(x, threads: int = 1):
+    """c2r transform of a [n, n, n/2+1, 3] spectrum over its first three axes -> [n, n, n, 3] (fourier.py:343)."""
+    torch = L.require_gpu()
+    xk = L.to_device(x, torch.complex64)
+    return L.like_input(_ifft_grad_planar(xk.permute(3, 0, 1, 2).contiguous()), x)
+
+
 def fourier_grid_to_Pk(density_k, p: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """(k, P(k), Nmodes) in grid units; also zeroes density_k[0,0,0] like the reference."""
     torch = L.require_gpu()

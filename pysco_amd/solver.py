@@ -76,7 +76,8 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
         # Without an f(R) term the force grid is only ever read by the gather: the gather kernel then takes
         # the potential and differentiates its own LDS tile (mesh.derivative_interp_vec_kick), and the
         # [n,n,n,3] array is never built.
-        fuse_gradient = _FUSE_GRADIENT and ncells_1d >= 16 and THEORY != "fr"
+        fuse_gradient = (_FUSE_GRADIENT and ncells_1d >= 16 and THEORY != "fr"
+                         and param["linear_newton_solver"].casefold() != "full_fft")  # (its force is not a gradient)
         # More stragglers than the lists hold (an unsorted or long-unsorted stream): the gather from the
         # potential would serve each of them with 324 loads; the force grid + order-independent gather it is.
         frac, lists_complete = utils.straggler_fraction(ncells_1d)
@@ -192,13 +193,22 @@ def _solve_grid(density, param, potential_d, additional_field_d, tables, want_fo
         else:
             potential_d = fft(rhs, param)
     elif LINEAR_NEWTON_SOLVER == "full_fft":
-        # The reference passes three arguments to the two-argument fft_force here
-        # (solver.py:181,200 vs :526-529) and therefore raises TypeError; same behaviour.
-        raise TypeError("fft_force() takes 2 positional arguments but 3 were given")
+        # The reference passes three arguments to the two-argument fft_force (solver.py:181, 200 vs :526-529) and
+        # raises TypeError; param["full_fft_reference_bug"] = True keeps that.  Otherwise the branch does what it
+        # spells out: the potential is left alone, the force comes from fft_force (below).
+        if param.get("full_fft_reference_bug", False):
+            raise TypeError("fft_force() takes 2 positional arguments but 3 were given")
     else:
         raise NotImplementedError(
             f"{param['linear_newton_solver']=}, should be multigrid, fft, fft_7pt or full_fft"
         )
+    if LINEAR_NEWTON_SOLVER == "full_fft":
+        force = fft_force(rhs, param)
+        if THEORY == "fr":  # solver.py:181-189 (mesh.add_derivative_fR): force += half_c2 grad(u^(n+1))
+            torch = L.require_gpu()
+            force += mesh.derivative_fR(torch.zeros_like(additional_field_d), additional_field_d, fr_half_c2(param),
+                                        param["fR_n"], param["gradient_stencil_order"])
+        return potential_d, additional_field_d, force
     del rhs
 
     if THEORY == "fr":
@@ -322,6 +332,27 @@ def rhs_poisson(density, additional_field, param) -> None:
     else:
         f1 = np.float32(1.5 * param["aexp"] * param["Om_m"] * param["parametrized_mu_z"])
         utils.linear_operator_inplace(density, f1, -f1)
+
+
+def fft_force(rhs, param):
+    """Force grid [n, n, n, 3] of the `full_fft` solver (solver.py:524-566): r2c -> [P(k)] ->
+    gradient_inverse_laplacian(_compensated) -> three c2r transforms."""
+    torch = L.require_gpu()
+    MAS_index = param["MAS_index"]
+    rhs_d = _dev(rhs)
+    n = rhs_d.shape[0]
+    rhs_fourier = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64, device=rhs_d.device)
+    L.context(n).call("pm_fft_r2c", L.ptr(rhs_d), L.ptr(rhs_fourier))
+    planar = fourier._grad_planar(rhs_fourier, 0 if MAS_index == 0 else int(MAS_index))
+    if param.get("save_pk", False):
+        k, Pk, Nmodes = fourier.fourier_grid_to_Pk(rhs_fourier, MAS_index)
+        Pk *= np.float32((param["boxlen"] / n**2) ** 3 / (1.5 * param["aexp"] * param["Om_m"]) ** 2
+                         / param["parametrized_mu_z"] ** 2)
+        k *= np.float32(2 * np.pi / param["boxlen"])
+        if _WRITE_PK:
+            iostream.write_power_spectrum_to_ascii_file(k, Pk, Nmodes, param)
+    del rhs_fourier
+    return L.like_input(fourier._ifft_grad_planar(planar), rhs)
 
 
 def fft(rhs, param, _source_scale=None, _khalo=None):

@@ -444,6 +444,8 @@ def test_pm_errors(amd, golden):
     for key, val, exc in (("mass_scheme", "NGP", NotImplementedError), ("save_power_spectrum", "maybe", NotImplementedError),
                           ("linear_newton_solver", "cg", NotImplementedError), ("theory", "brans-dicke", NotImplementedError),
                           ("linear_newton_solver", "full_fft", TypeError), ("gradient_stencil_order", 4, ValueError)):
+        if val == "full_fft":
+            base["full_fft_reference_bug"] = True  # the reference's arity bug, kept behind a flag (solver.py:181)
         p = dict(base)
         p[key] = val
         with pytest.raises(exc):
@@ -794,3 +796,68 @@ def test_tile_window_restricts_workgroups_not_results(amd):
     np.testing.assert_array_equal(out[True][1], out[False][1])
     np.testing.assert_array_equal(out[True][1], orc.invTSC_vec(orc.derivative(phi, 5), pos))
 
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_full_fft_pieces_vs_golden(amd, golden, n):
+    """fourier.gradient_inverse_laplacian(_compensated), ifft_3D_real_grad and solver.fft_force (the `full_fft`
+    solver, fourier.py:343-396, 606-719, solver.py:524-566) against the reference's outputs."""
+    g = golden(f"kspace_grad_n{n}")
+    if n == 16:
+        for name, fn in (("grad_plain", lambda a: amd.fourier.gradient_inverse_laplacian(a)),
+                         ("grad_comp2", lambda a: amd.fourier.gradient_inverse_laplacian_compensated(a, 2)),
+                         ("grad_comp3", lambda a: amd.fourier.gradient_inverse_laplacian_compensated(a, 3))):
+            got = fn(g["xk"].copy())
+            assert got.shape == (n, n, n // 2 + 1, 3) and got.dtype == np.complex64
+            assert np.abs(got - g[name]).max() <= 4e-6 * np.abs(g[name]).max(), name
+            assert np.all(got[0, 0, 0] == 0)
+        got = amd.fourier.ifft_3D_real_grad(g["grad_comp3"].copy())
+        np.testing.assert_allclose(got, g["ifft_grad_comp3"], rtol=0, atol=3e-6 * _scale(g["ifft_grad_comp3"]))
+    for mas in (0, 3):
+        f = amd.solver.fft_force(g["x"].copy(), {"MAS_index": mas, "save_pk": False})
+        ref = g[f"fft_force_mas{mas}"]
+        assert f.shape == (n, n, n, 3) and f.dtype == np.float32
+        np.testing.assert_allclose(f, ref, rtol=0, atol=5e-6 * _scale(ref))
+
+
+@pytest.mark.parametrize("theory,scheme", [("newton", "TSC"), ("newton", "CIC"), ("fr", "TSC")])
+def test_pm_full_fft_works_and_matches_the_oracle(amd, theory, scheme):
+    """solver.pm with linear_newton_solver = full_fft: a WORKING force path (the reference's dies on an arity bug,
+    solver.py:181, 200): accelerations = inv<scheme>_vec of fft_force, the potential handed in comes back untouched;
+    against the oracle's composition of the same reference functions, and close to the fft solver's result."""
+    import bench
+
+    n = 32
+    pos, _ = zeldovich_particles(n, seed=8, rms_cells=0.6)
+    tables = bench.synth_tables()
+    param, _ = bench.make_param(n, n**3)
+    param.update(linear_newton_solver="full_fft", mass_scheme=scheme, theory=theory, fR_n=1, fR_logfR0=5, boxlen=1000.0,
+                 Npre=2, Npost=1, epsrel=1e-2)
+    amd.utils.set_units(param)
+    par_o = dict(param)
+    acc_o, pot_o, extra_o = orc.pm(pos, par_o, tables=tables)
+    acc, pot, extra = amd.solver.pm(pos, param, tables=tables)
+    assert pot.size == 0 and pot_o.size == 0  # full_fft leaves the (empty) potential alone (solver.py:160-161)
+    s = _scale(acc_o)
+    assert np.abs(acc - acc_o).max() <= (2e-5 if theory == "newton" else 2e-3) * s
+    if theory == "newton":  # spectral vs 5-point gradient of the same potential: the same force to a few per cent
+        p2, _ = bench.make_param(n, n**3)
+        p2.update(mass_scheme=scheme)
+        acc_fft, _, _ = amd.solver.pm(pos, p2, tables=tables)
+        assert np.abs(acc - acc_fft).max() < 0.2 * s
+
+
+@pytest.mark.parametrize("tag", ["fft", "multigrid"])
+def test_pm_parametrized_vs_golden(amd, golden, tag):
+    """theory = parametrized: mu(z) = 1 + mu0 Omega_Lambda(z) / Omega_Lambda scales the Poisson source
+    (solver.py:95-112); against the reference's pm() for the FFT and the multigrid solver."""
+    g = golden("pm_parametrized_" + tag)
+    param = param_from_json(g["param_json"])
+    ref = param_from_json(g["param_json"])
+    acc, pot, extra = amd.solver.pm(g["pos"], param, tables=synth_tables())
+    assert extra.size == 0
+    assert float(param["parametrized_mu_z"]) == pytest.approx(ref["parametrized_mu_z"], rel=1e-6)
+    assert ref["parametrized_mu_z"] != 1
+    tol = 5e-6 if tag == "fft" else 1e-3
+    np.testing.assert_allclose(pot, g["pot"], rtol=0, atol=tol * _scale(g["pot"]))
+    np.testing.assert_allclose(acc, g["acc"], rtol=0, atol=4 * tol * _scale(g["acc"]))

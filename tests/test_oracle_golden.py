@@ -302,3 +302,43 @@ def test_quartic(golden):
 
 def test_pm_fr_n2(golden):
     test_pm_multigrid_theories(golden, "fr2_multigrid")
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_oracle_full_fft_pieces(golden, n):
+    """gradient_inverse_laplacian(_compensated), ifft_3D_real_grad and fft_force (fourier.py:343-396, 606-719,
+    solver.py:524-566) against the reference's outputs (the pieces of the `full_fft` solver)."""
+    g = golden(f"kspace_grad_n{n}")
+    if n == 16:
+        xk = g["xk"]
+        for name, fn in (("grad_plain", lambda a: orc.gradient_inverse_laplacian(a)),
+                         ("grad_comp2", lambda a: orc.gradient_inverse_laplacian_compensated(a, 2)),
+                         ("grad_comp3", lambda a: orc.gradient_inverse_laplacian_compensated(a, 3))):
+            got = fn(xk.copy())
+            assert got.shape == (n, n, n // 2 + 1, 3) and got.dtype == np.complex64
+            s = np.abs(g[name]).max()
+            assert np.abs(got - g[name]).max() <= 4e-6 * s, name
+            assert np.all(got[0, 0, 0] == 0)
+        np.testing.assert_allclose(orc.ifft_3D_real_grad(g["grad_comp3"].copy()), g["ifft_grad_comp3"], rtol=0,
+                                   atol=2e-6 * np.abs(g["ifft_grad_comp3"]).max())
+    for mas in (0, 3):
+        param = {"MAS_index": mas, "save_pk": False}
+        f = orc.fft_force(g["x"].copy(), param)
+        ref = g[f"fft_force_mas{mas}"]
+        assert f.shape == (n, n, n, 3) and f.dtype == np.float32
+        np.testing.assert_allclose(f, ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("tag", ["fft", "multigrid"])
+def test_oracle_pm_parametrized(golden, tag):
+    """solver.pm with theory = parametrized (solver.py:95-112)."""
+    from tests.helpers import param_from_json, synth_tables
+
+    g = golden("pm_parametrized_" + tag)
+    param = param_from_json(g["param_json"])
+    ref = param_from_json(g["param_json"])
+    acc, pot, extra = orc.pm(g["pos"], param, tables=synth_tables())
+    assert param["parametrized_mu_z"] == pytest.approx(ref["parametrized_mu_z"], rel=1e-6) and ref["parametrized_mu_z"] != 1
+    tol = 5e-6 if tag == "fft" else 1e-3
+    np.testing.assert_allclose(pot, g["pot"], rtol=0, atol=tol * np.abs(g["pot"]).max())
+    np.testing.assert_allclose(acc, g["acc"], rtol=0, atol=4 * tol * np.abs(g["acc"]).max())
