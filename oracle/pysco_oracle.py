@@ -349,6 +349,48 @@ def fourier_grid_to_Pk(density_k, p: int) -> Tuple[np.ndarray, np.ndarray, np.nd
         return ks[1:kmax] / nm[1:kmax], ps[1:kmax] / nm[1:kmax], nm[1:kmax]
 
 
+def pk_fp64(position, ncells_1d: int, p: int = 3):
+    """The P(k) pipeline -- TSC deposit (mesh.py:2468), r2c, binned and window-deconvolved spectrum
+    (fourier.py:22-100) -- evaluated in float64 from the same fp32 positions: the "truth" the fp32 paths are held
+    against at benchmark sizes (<= 1e-4 per bin).  Same formulas, same truncations to cell
+    indices, every product and sum in fp64."""
+    n = int(ncells_1d)
+    x = np.float32(np.asarray(position, dtype=np.float32) * np.float32(n)).astype(np.float64)  # as the kernels form it
+    i = np.minimum(x.astype(np.int64), n - 1)
+    d = x - 0.5 - i
+    w = np.stack([0.5 * (0.5 - d) ** 2, 0.75 - d * d, 0.5 * (0.5 + d) ** 2], axis=0)  # [3, Np, 3]: cells i-1, i, i+1
+    rho = np.zeros(n**3, dtype=np.float64)
+    for a in range(3):
+        ia = (i[:, 0] + a - 1) % n
+        for b in range(3):
+            ib = (i[:, 1] + b - 1) % n
+            wab = w[a, :, 0] * w[b, :, 1]
+            for c in range(3):
+                ic = (i[:, 2] + c - 1) % n
+                rho += np.bincount((ia * n + ib) * n + ic, weights=wab * w[c, :, 2], minlength=n**3)
+    import scipy.fft
+
+    dk = scipy.fft.rfftn(rho.reshape(n, n, n), workers=num_threads())
+    del rho
+    kf = np.where(np.arange(n) >= n // 2, np.arange(n) - n, np.arange(n)).astype(np.float64)
+    kz = np.arange(n // 2 + 1, dtype=np.float64)
+    sx, sz = np.sinc(kf / n), np.sinc(kz / n)
+    wk = (sx[:, None] * sx[None, :])[:, :, None] * sz[None, None, :]
+    power = (dk.real**2 + dk.imag**2) * wk ** (-2.0 * p)
+    del dk, wk
+    knorm = np.sqrt(((kf**2)[:, None] + (kf**2)[None, :])[:, :, None] + (kz**2)[None, None, :])
+    kidx = (knorm + 0.5).astype(np.int64).ravel()
+    knorm, power = knorm.ravel(), power.ravel()
+    knorm[0], power[0] = 0.0, 0.0
+    nm = np.bincount(kidx, minlength=n).astype(np.float64)
+    nm[0] -= 1  # the k = 0 mode is skipped (fourier.py:80-82)
+    ks = np.bincount(kidx, weights=knorm, minlength=n)
+    ps = np.bincount(kidx, weights=power, minlength=n)
+    kmax = int(2 * (n // 2) / 3)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return ks[1:kmax] / nm[1:kmax], ps[1:kmax] / nm[1:kmax], nm[1:kmax]
+
+
 # ------------------------------------------------------------------ solver.py (Newtonian FFT path)
 
 

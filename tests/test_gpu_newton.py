@@ -861,3 +861,16 @@ def test_pm_parametrized_vs_golden(amd, golden, tag):
     tol = 5e-6 if tag == "fft" else 1e-3
     np.testing.assert_allclose(pot, g["pot"], rtol=0, atol=tol * _scale(g["pot"]))
     np.testing.assert_allclose(acc, g["acc"], rtol=0, atol=4 * tol * _scale(g["acc"]))
+
+
+def test_pk_vs_float64_restatement(amd):
+    """P(k) per bin within 1e-4 of a float64 evaluation of the same pipeline (TSC deposit,
+    r2c, binned window-deconvolved spectrum) on the same particles, at a size the goldens do not reach (256^3)."""
+    n = 256
+    pos, _ = zeldovich_particles(n, seed=21, rms_cells=1.5)
+    k64, pk64, nm64 = orc.pk_fp64(pos, n, 3)
+    rho = amd.mesh.TSC(amd.torch.from_numpy(pos).cuda(), n)
+    k, pk, nm = amd.fourier.fourier_grid_to_Pk(amd.fourier.fft_3D_real(rho), 3)
+    assert np.array_equal(nm, nm64.astype(np.float32))
+    assert np.max(np.abs(pk.astype(np.float64) - pk64) / pk64) <= 1e-4
+    np.testing.assert_allclose(k, k64, rtol=1e-5)
