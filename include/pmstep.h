@@ -207,8 +207,10 @@ int pm_gradient_interp_kick(pm_ctx *ctx, int order, int scheme, const float *d_p
  * reference counterpart for doing it inside the step).  The gather reads every particle's position and velocity
  * and writes its velocity and acceleration anyway; here it writes position, kicked velocity and acceleration OUT
  * OF PLACE, tile after tile (8 x 16 x 16 cells, the unit of the tile-range kernels), every particle into the
- * range of the tile it is expected to be in after the next drift (x + dt_next * v clamped to one cell, the
- * Courant bound of integration.py:324-326; dt_next from pm_set_predicted_dt, 0 = the tile it is in now).  The
+ * range of the tile it is expected to be in after the next drift (x + dt_next * (v - (dt + dt_next) / 2 * a_old),
+ * clamped to one cell, the Courant bound of integration.py:324-326; decided and recorded per particle by the
+ * preceding pm_kick_drift_wrap_deposit[_khalo], which has a_old; dt_next from pm_set_predicted_dt, 0 = the tile it
+ * is in now).  The
  * *_out stream enters the next step with (nearly) no stragglers, for 12 more bytes per particle than the
  * in-place gather.  Values are those pm_gradient_interp_kick computes (same
  * bits); only the particle order changes -- inside a tile it is the order of arrival, which no kernel result

@@ -792,6 +792,7 @@ extern "C" int pm_set_tile_window(pm_ctx *c, int x_lo, int nx) {
 // destination histogram of every workgroup, the fill counters, the widened counts and the two tile-offset tables.
 struct RbBufs {
     unsigned *tile_count, *wg_hist, *fill;
+    unsigned char *dcode;
     int64_t *cnt, *table[2];
     void *scan_tmp;
     size_t scan_tmp_bytes;
@@ -806,7 +807,8 @@ static int rebucket_bufs(pm_ctx *c, unsigned ntiles, int64_t np, RbBufs *b) {
     int64_t *nullp = nullptr;
     PM_HIP(rocprim::exclusive_scan(nullptr, tmp, nullp, nullp, (int64_t)0, (size_t)ntiles + 1, rocprim::plus<int64_t>(),
                                    c->stream));
-    const size_t need = 2 * t32 + w32 + 3 * t64 + tmp;
+    const size_t dbytes = up((size_t)np);
+    const size_t need = 2 * t32 + w32 + 3 * t64 + up(tmp) + dbytes;
     if (c->rb_buf_bytes < need) {
         if (c->rb_buf) PM_HIP(hipFree(c->rb_buf));
         c->rb_buf = nullptr, c->rb_buf_bytes = 0, c->sorted_pos = nullptr, c->stay_valid = 0;
@@ -819,6 +821,7 @@ static int rebucket_bufs(pm_ctx *c, unsigned ntiles, int64_t np, RbBufs *b) {
     b->cnt = (int64_t *)(p + 2 * t32 + w32);
     b->table[0] = (int64_t *)(p + 2 * t32 + w32 + t64), b->table[1] = (int64_t *)(p + 2 * t32 + w32 + 2 * t64);
     b->scan_tmp = p + 2 * t32 + w32 + 3 * t64, b->scan_tmp_bytes = tmp;
+    b->dcode = (unsigned char *)(p + 2 * t32 + w32 + 3 * t64 + up(tmp));
     return PM_OK;
 }
 
@@ -1213,12 +1216,15 @@ __device__ __forceinline__ float *halo_cell(int c, const TileId &t, const HaloBu
 }
 
 // Destination tile of the incremental re-sort.  A particle is FILED under the tile it is expected to be in after
-// the next drift, x + dtp * v (v: the velocity between the two kicks, which both the fused kick + drift + deposit
-// and the gather see in memory; dtp: the caller's guess of the next step, 0 = file under the current tile).  The
-// displacement is clamped to one cell (the Courant criterion's bound, integration.py:324-326), so the destination
-// is the serving tile or one of its 26 neighbours: code d = 9 (dti + 1) + 3 (dtj + 1) + (dtk + 1), 13 = stays.
-// With the guess within a few per cent, one particle in a thousand ends up outside the tile it is filed under,
-// where an exact sort sees every tile crosser of the step (4 % when the fastest particle moves one cell).
+// the next drift, x + dtp * v with v = v_half - (dt + dtp) / 2 * a_old: the velocity the next drift will use, with
+// the acceleration of this step's first kick standing in for the one the gather is about to compute (dtp: the
+// caller's guess of the next step, 0 = file under the current tile).  The fused kick + drift + deposit has all of
+// that in registers; it records the decision as one byte per particle, which the gather obeys.  The displacement
+// is clamped to one cell (the Courant criterion's bound, integration.py:324-326), so the destination is the tile
+// the particle is in or one of its 26 neighbours: code d = 9 (dti + 1) + 3 (dtj + 1) + (dtk + 1), 13 = stays.
+// Measured (512^3, tools/exp_predict_tiles.py): 0.05-0.3 % of the particles end up outside the tile they are
+// filed under, where an exact sort sees every tile crosser of the step (4 % when the fastest particle moves one
+// cell) and the velocity alone predicts 0.25-1.1 %.
 struct DestCode {
     int d;
     unsigned key;  // tile key of the destination
@@ -1249,7 +1255,10 @@ __device__ __forceinline__ TileId tile_of_cell(int i, int j, int k) { return Til
 struct DestCount {
     unsigned *tile_count;  // [ntiles] cleared (NULL: off)
     unsigned *wg_hist;     // [workgroups][27]
-    float dtp;
+    unsigned char *dcode;  // [np] destination code of every particle, relative to the tile it is in
+    float dtp;             // guess of the next dt
+    float kick;            // -(dt + dtp) / 2: the velocity of the next drift is about v + kick * a (a: the
+                           // acceleration this step's first kick used -- the new one is not known yet)
 };
 
 // slab decomposition: particles whose new x leaves [x_lo, x_hi) are listed for the migration (idx == NULL: off)
@@ -1325,10 +1334,14 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
                 }
                 const float xp = x[u][0] * nf, yp = x[u][1] * nf, zp = x[u][2] * nf;
                 const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+                float veff[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) veff[m] = v[u][m] + dc.kick * a[u][m];
                 if (in_tile(i, j, k, t)) {
                     deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
                     if (dc.tile_count) {
-                        const DestCode dd = dest_of(x[u], v[u], dc.dtp, nf, n, t);
+                        const DestCode dd = dest_of(x[u], veff, dc.dtp, nf, n, t);
+                        dc.dcode[p] = (unsigned char)dd.d;
                         if (dd.d != 13) atomicAdd(&s_hist[dd.d], 1u);
                     }
                 } else {
@@ -1339,7 +1352,11 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
                     else
                         append(k2, (unsigned)p);
                     // served by the tile it is in now, from that tile's list: counted at its destination one by one
-                    if (dc.tile_count) atomicAdd(dc.tile_count + dest_of(x[u], v[u], dc.dtp, nf, n, tile_of_cell(i, j, k)).key, 1u);
+                    if (dc.tile_count) {
+                        const DestCode dd = dest_of(x[u], veff, dc.dtp, nf, n, tile_of_cell(i, j, k));
+                        dc.dcode[p] = (unsigned char)dd.d;
+                        atomicAdd(dc.tile_count + dd.key, 1u);
+                    }
                 }
             }
         }
@@ -1402,6 +1419,9 @@ __global__ __launch_bounds__(BLK) void deposit_list_kernel(const float *__restri
     const TileId t = tile_of_key(key);
     for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0;
     __syncthreads();
+#if defined(PM_EXP_LISTFLUSH) && PM_EXP_LISTFLUSH == 4
+    if (false)
+#endif
     for (unsigned l = ls + tid; l < le; l += BLK) {
         const int64_t p = lists.idx[l];
         const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
@@ -1413,7 +1433,27 @@ __global__ __launch_bounds__(BLK) void deposit_list_kernel(const float *__restri
             deposit_global<SCHEME>(x, y, z, geo, rho);
     }
     __syncthreads();
-    if (halo.k) {
+#ifdef PM_EXP_LISTFLUSH  /* development: 0 = atomics on rho, 1 = atomics on the tile's own addresses, 2 = read-modify-write */
+    if (PM_EXP_LISTFLUSH == 3) return;  // no flush at all (timing experiment)
+    if (PM_EXP_LISTFLUSH == 0) {
+        for (int c = tid; c < PM_TILE; c += BLK) {
+            const pm_acc_t w = tile[c];
+            if (w != 0) unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), weight_of_acc(w));
+        }
+        return;
+    }
+    if (halo.k && PM_EXP_LISTFLUSH == 1) {
+#else
+    if (halo.k && le - ls < 128) {
+#endif
+        // a short list (the usual case once the stream is re-bucketed every step: ~10 particles per tile) touches a
+        // few hundred cells: fire-and-forget atomics on the tile's own addresses, no load to wait for (the
+        // read-modify-write form below cost 2.6 ms at 0.5 % stragglers, the atomics 0.4 ms)
+        for (int c = tid; c < PM_TILE; c += BLK) {
+            const pm_acc_t w = tile[c];
+            if (w != 0) unsafeAtomicAdd(halo_cell(c, t, halo, geo, rho), weight_of_acc(w));
+        }
+    } else if (halo.k) {
         // read-modify-write of the touched cells, all the loads of a thread in flight before its first store (one
         // dependent load -> store per cell made the kernel latency-bound: 5.4 ms at 4 % stragglers, 1024^3)
         constexpr int NQ = (PM_TILE + BLK - 1) / BLK;
@@ -1440,6 +1480,94 @@ __global__ __launch_bounds__(BLK) void deposit_list_kernel(const float *__restri
     }
 }
 
+// f(di, dj, dk, w) for every cell of the particle's assignment footprint (offsets from its cell, fp32 weight in the
+// reference's operation order) -- the weights of deposit_lds / deposit_global, for the flat list deposit below
+template <int SCHEME, class F>
+__device__ __forceinline__ void deposit_each(float xp, float yp, float zp, int i, int j, int k, F f) {
+    if (SCHEME == PM_NGP) {
+        f(0, 0, 0, 1.0f);
+    } else if (SCHEME == PM_CIC) {
+        float wx[2], wy[2], wz[2];
+        int sx, sy, sz;
+        cic_weights(xp, i, wx[0], wx[1], sx);
+        cic_weights(yp, j, wy[0], wy[1], sy);
+        cic_weights(zp, k, wz[0], wz[1], sz);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) f(a * sx, b * sy, c * sz, wx[a] * wy[b] * wz[c]);
+    } else {
+        float wx[3], wy[3], wz[3];
+        tsc_weights(xp, i, wx);
+        tsc_weights(yp, j, wy);
+        tsc_weights(zp, k, wz);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float wxy = wx[a] * wy[b];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) f(a - 1, b - 1, c - 1, wxy * wz[c]);
+            }
+    }
+}
+
+// The same deposit for SHORT lists (a stream that is re-bucketed every step leaves about one listed particle per
+// tile): one WAVE per listed particle, a lane per cell of its footprint, added straight to the addresses the tile it
+// is in owns (own cells in rho, halo cells in the tile's halo-buffer entries) with fire-and-forget atomics: 9 rows
+// of 3 adjacent cells per wave instruction.  (One particle per lane -- 64 scattered sectors per instruction --
+// was 4x slower than the per-tile kernel above, which spends 0.8 ms at 1024^3 on clearing and scanning half a
+// million LDS tiles whatever the lists hold.)
+template <int SCHEME>
+__global__ __launch_bounds__(BLK) void deposit_list_flat_kernel(const float *__restrict__ pos,
+                                                                const unsigned *__restrict__ idx, unsigned count,
+                                                                pm_geom geo, float *__restrict__ rho, HaloBuf halo) {
+    const int n = geo.n;
+    const float nf = (float)n;
+    const unsigned lane = threadIdx.x & 63u, nwaves = gridDim.x * (BLK / 64);
+    for (unsigned l = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6); l < count; l += nwaves) {
+        const int64_t p = idx[l];
+        const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+        const float xp = x * nf, yp = y * nf, zp = z * nf;
+        const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+        const TileId t = tile_of_cell(i, j, k);
+        const int c0 = ((i - t.ti * PM_TI + 1) * PM_HJ + (j - t.tj * PM_TJ + 1)) * PM_HK + (k - t.tk * PM_TK + 1);
+        // the lane's cell of the footprint (offsets from the particle's cell) and its weight, products in the
+        // reference's order; ONE atomic instruction per particle
+        int di = 0, dj = 0, dk = 0;
+        float w = 1.0f;
+        bool on = lane == 0;
+        auto pick = [](const float *v, int q) { return q == 0 ? v[0] : (q == 1 ? v[1] : v[2]); };
+        if (SCHEME == PM_CIC) {
+            float wx[3], wy[3], wz[3];
+            int sx, sy, sz;
+            cic_weights(xp, i, wx[0], wx[1], sx);
+            cic_weights(yp, j, wy[0], wy[1], sy);
+            cic_weights(zp, k, wz[0], wz[1], sz);
+            wx[2] = wy[2] = wz[2] = 0.f;
+            const int a = (lane >> 2) & 1, b = (lane >> 1) & 1, c = lane & 1;
+            on = lane < 8, di = a * sx, dj = b * sy, dk = c * sz;
+            w = pick(wx, a) * pick(wy, b) * pick(wz, c);
+        } else if (SCHEME == PM_TSC) {
+            float wx[3], wy[3], wz[3];
+            tsc_weights(xp, i, wx);
+            tsc_weights(yp, j, wy);
+            tsc_weights(zp, k, wz);
+            const int a = (int)lane / 9, b = ((int)lane / 3) % 3, c = (int)lane % 3;
+            on = lane < 27, di = a - 1, dj = b - 1, dk = c - 1;
+            w = (pick(wx, a) * pick(wy, b)) * pick(wz, c);
+        }
+        if (on) {
+            if (halo.k)
+                unsafeAtomicAdd(halo_cell(c0 + (di * PM_HJ + dj) * PM_HK + dk, t, halo, geo, rho), w);
+            else
+                unsafeAtomicAdd(rho + pm_cell(geo, i + di, j + dj, k + dk), w);
+        }
+    }
+}
+
 template <int SCHEME>
 static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *acc, float half_dt, float dt, int64_t np,
                               float *rho, Leavers lv, float *khalo) {
@@ -1456,12 +1584,12 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     // particles)
     RbBufs rb;
     const bool count_stay = !lv.idx && work.nlaunch == ntiles;
-    DestCount dcount{nullptr, nullptr, c->dt_pred};
+    DestCount dcount{nullptr, nullptr, nullptr, c->dt_pred, -0.5f * (dt + c->dt_pred)};
     if (count_stay) {
         rc = rebucket_bufs(c, ntiles, np, &rb);
         if (rc) return rc;
         PM_HIP(hipMemsetAsync(rb.tile_count, 0, ((size_t)ntiles + 1) * sizeof(unsigned), c->stream));
-        dcount.tile_count = rb.tile_count, dcount.wg_hist = rb.wg_hist;
+        dcount.tile_count = rb.tile_count, dcount.wg_hist = rb.wg_hist, dcount.dcode = rb.dcode;
     }
     const size_t cells = (size_t)c->slab_nx * c->n * c->n;
     const HaloBuf halo = halo_parts(khalo, c->n);
@@ -1505,7 +1633,11 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     }
     TileLists lists;
     lists.idx = idx, lists.lstart = b.lstart, lists.use = 1;
-    if (listed > 0) {
+    if (listed > 0 && (int64_t)listed * 400 < np) {  // under 0.25 % (measured break-even at 1024^3: 0.3 %)
+        hipLaunchKernelGGL((deposit_list_flat_kernel<SCHEME>), dim3(pm_stream_blocks((int64_t)listed * 64, BLK)), dim3(BLK), 0,
+                           c->stream, pos, idx, listed, pm_ctx_geom(c), rho, halo);
+        PM_LAUNCH_CHECK();
+    } else if (listed > 0) {
         hipLaunchKernelGGL((deposit_list_kernel<SCHEME>), dim3(ntiles), dim3(BLK), 0, c->stream, pos, lists, pm_ctx_geom(c),
                            rho, halo);
         PM_LAUNCH_CHECK();
@@ -1715,7 +1847,7 @@ struct Rebucket {
     const int64_t *newstart;  // [ntiles + 1] offsets of the re-bucketed stream
     unsigned *fill;           // [ntiles] cleared: whoever sends particles to a tile takes a slice of its range here
     const unsigned *wg_hist;  // [workgroups][27] particles the workgroup serves from its range, per destination
-    float dtp;                // the guess of the next dt the destinations were counted with (dest_of)
+    const unsigned char *dcode;  // [np] destination code of every particle (dest_of, recorded by the fused kick)
     float *pos_out, *vel_out, *acc_out;
     const unsigned *id;       // optional particle tags carried along (NULL: none)
     unsigned *id_out;
@@ -1912,27 +2044,31 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
             a[0] = r.x, a[1] = r.y, a[2] = r.z;
         }
         if constexpr (REBUCKET) {
-            const float xs[3] = {x, y, z};
             int64_t d64 = -1;  // where the particle goes (-1: not written)
             if (own_range) {
                 // the destination the fused kick counted for it; stayers (nearly all) take consecutive slots of
                 // the own slice with one LDS atomic per wave and iteration, movers one each
-                const DestCode dd = dest_of(xs, v, rb.dtp, nf, n, t);
-                const bool stay = !skip && dd.d == 13;
+                const int dd_d = min((int)rb.dcode[src_index], 26);
+                const bool stay = !skip && dd_d == 13;
                 const unsigned long long m = __ballot(stay);
                 const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 unsigned wb = 0;
                 if (stay && before == 0) wb = atomicAdd(&s_slot[13], (unsigned)__popcll(m));  // the first staying lane
                 wb = __shfl((int)wb, m ? __ffsll((long long)m) - 1 : (tid & 63), 64);
                 unsigned slot = wb + before;
-                if (!skip && !stay) slot = atomicAdd(&s_slot[dd.d], 1u);
+                if (!skip && !stay) slot = atomicAdd(&s_slot[dd_d], 1u);
                 // (slot < s_mine always, unless the positions were changed behind the prepared lists: memory safety)
-                if (!skip && slot < s_mine[dd.d]) d64 = s_dest[dd.d] + slot;
+                if (!skip && slot < s_mine[dd_d]) d64 = s_dest[dd_d] + slot;
             } else {
                 // a listed particle (it is inside this tile, or the lists are void): counted one by one by the
                 // fused kick, so it takes its slot from the destination's counter itself -- the lanes of a wave
                 // that stay in this tile (nearly all) with one global atomic between them
-                const DestCode dd = dest_of(xs, v, rb.dtp, nf, n, tile_of_cell(i, j, k));
+                const int dd_d = min((int)rb.dcode[src_index], 26);
+                const TileId ta = tile_of_cell(i, j, k);
+                const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
+                struct { unsigned key; } dd;
+                dd.key = tile_key((ta.ti + dd_d / 9 - 1 + Ti) % Ti, (ta.tj + (dd_d / 3) % 3 - 1 + Tj) % Tj,
+                                  (ta.tk + dd_d % 3 - 1 + Tk) % Tk);
                 const bool here = dd.key == key;
                 const unsigned long long m = __ballot(here);
                 const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -2210,7 +2346,7 @@ extern "C" int pm_gradient_interp_kick_rebucket(pm_ctx *c, int order, int scheme
     PM_HIP(hipMemsetAsync(b.fill, 0, ((size_t)ntiles + 1) * sizeof(unsigned), c->stream));
     PM_HIP(hipMemsetAsync(c->d_scratch + 8, 0, 2 * sizeof(unsigned), c->stream));
     Rebucket rb;
-    rb.newstart = table, rb.fill = b.fill, rb.wg_hist = b.wg_hist, rb.dtp = c->stay_dt_pred;
+    rb.newstart = table, rb.fill = b.fill, rb.wg_hist = b.wg_hist, rb.dcode = b.dcode;
     rb.pos_out = d_pos_out, rb.vel_out = d_vel_out, rb.acc_out = d_acc_out, rb.id = d_id, rb.id_out = d_id_out;
     const pm_geom geo = pm_ctx_geom(c);
     float *vel = const_cast<float *>(d_vel);  // read only by the re-bucketing instantiation

@@ -35,8 +35,9 @@ def main():
         c = (x * n).to(torch.int32).clamp_(0, n - 1)
         return ((c[:, 0] >> 3) * (n >> 4) + (c[:, 1] >> 4)) * (n >> 4) + (c[:, 2] >> 4)
 
-    pred_v = pred_va = None
+    pred_v = pred_va = pred_vb = None
     t_prev = param["t"]
+    dt_last = None
     for s in range(args.steps):
         x0, v0, a0 = pos.clone(), vel.clone(), acc.clone()
         pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, np.float32(3e38))
@@ -46,13 +47,19 @@ def main():
         cross = float((tl != tile(x0)).float().mean())
         msg = f"step {s + 1:3d} dt {dt:.4e} crossers {cross:.4f}"
         if pred_v is not None:
-            msg += f"  wrong: v {float((pred_v != tl).float().mean()):.4f}  va {float((pred_va != tl).float().mean()):.4f}"
+            msg += (f"  wrong: v {float((pred_v != tl).float().mean()):.4f}  va {float((pred_va != tl).float().mean()):.4f}"
+                    f"  va(new acc) {float((pred_vb != tl).float().mean()):.4f}")
         # predictions for the NEXT step, from what the fused kick + drift of this step knows: new x, v_half, old a, dt
         v_half = v0 - np.float32(0.5 * dt) * a0
-        d = (np.float32(dt) * v_half).clamp_(-1.0 / n, 1.0 / n)
+        ratio = min(1.5, max(0.5, dt / dt_last)) if dt_last else 1.0
+        dt_last = dt
+        dtp = np.float32(dt * ratio)  # guess of the next dt
+        d = (dtp * v_half).clamp_(-1.0 / n, 1.0 / n)
         pred_v = tile((pos + d) % 1.0)
-        d = (np.float32(dt) * (v_half - np.float32(dt) * a0)).clamp_(-1.0 / n, 1.0 / n)
+        d = (dtp * (v_half - np.float32(0.5 * (dt + float(dtp))) * a0)).clamp_(-1.0 / n, 1.0 / n)
         pred_va = tile((pos + d) % 1.0)
+        d = (dtp * (v_half - np.float32(0.5 * (dt + float(dtp))) * acc)).clamp_(-1.0 / n, 1.0 / n)
+        pred_vb = tile((pos + d) % 1.0)
         # the same with the NEW acceleration (what the gather could do if it knew the counts beforehand)
         print(msg, flush=True)
         del x0, v0, a0, v_half, d
