@@ -2024,6 +2024,9 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     // `src_index`: the particle's index in the input arrays (only read for the tags of a re-bucketing pass)
     auto serve = [&](float *__restrict__ o, float *__restrict__ w3, auto p, float x, float y, float z, const float v[3],
                      bool own_range, int64_t src_index) {
+        // (the particle's destination code: loaded here so that its latency hides behind the gather)
+        int dcode_p = 13;
+        if constexpr (REBUCKET) dcode_p = rb.dcode[src_index];
         const float xp = x * nf, yp = y * nf, zp = z * nf;
         const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
         const bool inside = in_tile(i, j, k, t);
@@ -2048,7 +2051,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
             if (own_range) {
                 // the destination the fused kick counted for it; stayers (nearly all) take consecutive slots of
                 // the own slice with one LDS atomic per wave and iteration, movers one each
-                const int dd_d = min((int)rb.dcode[src_index], 26);
+                const int dd_d = min(dcode_p, 26);
                 const bool stay = !skip && dd_d == 13;
                 const unsigned long long m = __ballot(stay);
                 const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -2063,7 +2066,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                 // a listed particle (it is inside this tile, or the lists are void): counted one by one by the
                 // fused kick, so it takes its slot from the destination's counter itself -- the lanes of a wave
                 // that stay in this tile (nearly all) with one global atomic between them
-                const int dd_d = min((int)rb.dcode[src_index], 26);
+                const int dd_d = min(dcode_p, 26);
                 const TileId ta = tile_of_cell(i, j, k);
                 const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
                 struct { unsigned key; } dd;
