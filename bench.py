@@ -39,15 +39,33 @@ def synth_tables():
             interp1d(lna, a, fill_value="extrapolate")] + [None] * 9
 
 
-def make_param(n, npart):
+CONFIGS = {
+    # name: (default mesh size, param overrides) -- BASELINE.json configs; newton_fft is the headline (configs 2 / 3)
+    "newton_fft": (1024, {}),
+    "newton_mg": (128, {"linear_newton_solver": "multigrid"}),  # config 1: examples/param.ini semantics
+    "fr": (512, {"theory": "fr", "fR_n": 1, "fR_logfR0": 5, "linear_newton_solver": "multigrid"}),  # config 4
+    "mond": (512, {"theory": "mond", "mond_function": "simple", "mond_g0": 1.2, "mond_alpha": 1,
+                   "mond_scale_factor_exponent": 0, "linear_newton_solver": "multigrid"}),  # config 5 (on one GPU)
+}
+
+
+def make_param(n, npart, config="newton_fft"):
     ncoarse = int(np.log2(n))
     p = {"theory": "newton", "mass_scheme": "TSC", "npart": npart, "ncoarse": ncoarse, "Om_m": 0.25733,
          "Om_lambda": 0.742589237, "H0": 72.0, "boxlen": 100.0 * (n / 128), "aexp": 0.5, "aexp_old": 0.49,
          "linear_newton_solver": "fft", "gradient_stencil_order": 5, "save_power_spectrum": "no", "nthreads": 1,
          "Courant_factor": 1.0, "max_aexp_stepping": 10, "integrator": "leapfrog", "write_snapshot": False,
          "nsteps": 0, "n_reorder": 50}
+    p.update({"w0": -1.0, "wa": 0.0, "Npre": 2, "Npost": 1, "epsrel": 1e-2})
+    p.update(CONFIGS[config][1])
+    if config == "fr":
+        p["boxlen"] = 1000.0 * (n / 32)  # 31 Mpc/h cells: below that the reference's cubic root itself returns NaN
     tables = synth_tables()
     p["t"] = float(tables[1](np.log(p["aexp"])))
+    if config != "newton_fft":  # (the oracle and the f(R) / MOND prefactors need the unit system)
+        from pysco_amd import utils as _u
+
+        _u.set_units(p)
     return p, tables
 
 
@@ -114,7 +132,25 @@ def alg_bytes(n, npart):
     }
 
 
-def cpu_baseline(cpu_n, budget_s=15.0):
+def alg_bytes_level(stage):
+    """Algorithmic bytes of one call of a per-level multigrid stage "name@n" (every logical
+    array read once and written once): None if the stage is not one."""
+    name, _, size = stage.partition("@")
+    if not size:
+        return None
+    c = float(int(size)) ** 3
+    per_cell = {"pm_lap_gauss_seidel": 12.0, "pm_cubic_gauss_seidel": 12.0, "pm_quartic_gauss_seidel": 12.0,  # x, b -> x
+                "pm_lap_restrict_residual": 8.5, "pm_lap_operator": 8.0, "pm_lap_residual_error": 8.0,
+                "pm_cubic_operator": 12.0, "pm_quartic_operator": 12.0, "pm_cubic_residual_error": 8.0,
+                "pm_quartic_residual_error": 8.0, "pm_restriction": 4.5, "pm_mond_rhs": 8.0,
+                "pm_prolongation": 8.0 * 8 + 4.0,  # (size = the coarse grid's: 8 fine cells read + written, 1 coarse read)
+                # one V-cycle: (Npre + Npost) sweeps of 12 B + restricted residual 16 B + prolongation 12 B per cell,
+                # summed over the levels (x 8/7), Npre + Npost = 3
+                "pm_lap_vcycle": (3 * 12.0 + 16.0 + 12.0) * 8.0 / 7.0}.get(name)
+    return None if per_cell is None else per_cell * c
+
+
+def cpu_baseline(cpu_n, budget_s=15.0, config="newton_fft"):
     """CPU oracle (C restatement + FFT) timed on leapfrog steps of the same workload at cpu_n^3: first on one
     core (the parity checker's serial build, numpy.fft), then on all the cores this process may use (OpenMP
     build: atomic-add deposit as the reference's parallel TSC, scipy.fft with workers).  The reported value is
@@ -132,7 +168,7 @@ def cpu_baseline(cpu_n, budget_s=15.0):
     def leg(omp):
         orc.use_openmp(omp)
         pos, vel = pos0.copy(), vel0.copy()
-        param, tables = make_param(cpu_n, cpu_n**3)
+        param, tables = make_param(cpu_n, cpu_n**3, config)
         acc, phi, extra = orc.pm(pos, param, tables=tables)
         steps, t0 = 0, time.perf_counter()
         while True:
@@ -154,7 +190,7 @@ def cpu_baseline(cpu_n, budget_s=15.0):
     orc.use_openmp(True)
     try:
         pos_c, vel_c = pos0.copy(), vel0.copy()
-        par_c, tables = make_param(cpu_n, cpu_n**3)
+        par_c, tables = make_param(cpu_n, cpu_n**3, config)
         acc_c, phi_c, ex_c = orc.pm(pos_c, par_c, tables=tables)
         for _ in range(K):
             pos_c, vel_c, acc_c, phi_c, ex_c = orc.integrate(pos_c, vel_c, acc_c, phi_c, ex_c, tables, par_c, np.float32(3e38))
@@ -162,7 +198,7 @@ def cpu_baseline(cpu_n, budget_s=15.0):
     finally:
         orc.use_openmp(False)
     pos_g, vel_g = torch.from_numpy(pos0).cuda(), torch.from_numpy(vel0).cuda()
-    par_g, tables = make_param(cpu_n, cpu_n**3)
+    par_g, tables = make_param(cpu_n, cpu_n**3, config)
     acc_g, phi_g, ex_g = solver.pm(pos_g, par_g, tables=tables)
     for _ in range(K):
         pos_g, vel_g, acc_g, phi_g, ex_g = integration.integrate(pos_g, vel_g, acc_g, phi_g, ex_g, tables, par_g,
@@ -192,7 +228,7 @@ def cpu_baseline(cpu_n, budget_s=15.0):
                                    "p = 3); vs_fp64: the HIP estimator against a float64 evaluation of the same "
                                    "pipeline on the device-evolved particles; max_dx: largest position difference "
                                    "between the two sides (box units)"},
-            "sample": f"leapfrog steps at {cpu_n}^3 particles / {cpu_n}^3 mesh (TSC, FFT, order 5) with the CPU "
+            "sample": f"leapfrog steps at {cpu_n}^3 particles / {cpu_n}^3 mesh ({config}: TSC, order 5) with the CPU "
                       f"restatement of PySCo's Numba path (oracle/pm_oracle.c): {sn} steps in {tn:.1f} s on {threads} "
                       f"threads (OpenMP, atomic deposit, scipy.fft workers), {s1} steps in {t1:.1f} s on 1 core "
                       "(serial build, numpy.fft)"}
@@ -203,7 +239,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--ncells", type=int, default=1024)
+    ap.add_argument("--config", default="newton_fft", choices=sorted(CONFIGS),
+                    help="BASELINE.json workload: newton_fft (headline, default), newton_mg (config 1), fr (4), mond (5)")
+    ap.add_argument("--ncells", type=int, default=0, help="mesh cells per side (default: the config's)")
     ap.add_argument("--rms-cells", type=float, default=0.5)
     ap.add_argument("--cpu-ncells", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -235,7 +273,7 @@ def main():
     from pysco_amd import integration, solver, utils
     from pysco_amd import main as pm_main
 
-    n = args.ncells
+    n = args.ncells or CONFIGS[args.config][0]
     npart = n**3
     pos, vel = zeldovich_device(n, rms_cells=args.rms_cells)
     utils.periodic_wrap(pos)
@@ -252,7 +290,7 @@ def main():
     if world > 1:
         slab._slabs.clear()
     torch.cuda.empty_cache()
-    param, tables = make_param(n, npart)
+    param, tables = make_param(n, npart, args.config)
     # the product's own loop body (pysco_amd.main.run_nbody): integrate() + the particle-order policy, with its
     # incremental re-sorts and any full re-sort INSIDE the timed region
     rebucket = pm_main.REBUCKET_FRACTION if args.rebucket_fraction is None else args.rebucket_fraction
@@ -333,7 +371,8 @@ def main():
     table = []
     for name, (calls, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):
         avg = ms / calls
-        gbs = ab.get(name, 0.0) / (avg * 1e-3) / 1e9 if name in ab else None
+        per_call = ab.get(name, alg_bytes_level(name))
+        gbs = per_call / (avg * 1e-3) / 1e9 if per_call else None
         table.append({"stage": name, "calls_per_step": calls / args.steps, "avg_ms": round(avg, 4),
                       "alg_GBps": None if gbs is None else round(gbs, 1)})
     dom = table[0]
@@ -352,21 +391,27 @@ def main():
             traffic = pmc.get("stages", {}).get(dom["stage"], {}).get("hbm_bytes_per_call")
     roofline = {"bound": "hbm", "kernel": dom["stage"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved / (HBM_PEAK / 1e9), 4), "traffic": traffic,
-                "alg_bytes_per_launch": ab.get(dom["stage"]),
+                "alg_bytes_per_launch": ab.get(dom["stage"], alg_bytes_level(dom["stage"])),
                 "step_frac": round(B_ALG_PER_PARTICLE * npart / (wall / args.steps) / (HBM_PEAK * world), 4),
                 "step_alg_bytes_per_particle": B_ALG_PER_PARTICLE, "stages": table}
 
-    out = {"metric": "particles pushed/sec (one PM step), Newtonian TSC+FFT, fp32", "value": value,
+    solver_name = {"newton_fft": "Newtonian TSC+FFT", "newton_mg": "Newtonian TSC + multigrid", "fr": "f(R) n=1 FAS multigrid",
+                   "mond": "QUMOND simple, multigrid"}[args.config]
+    cycles = {k[len("_vcycles_"):]: round(param.get(k, 0) / max(1, args.steps + args.warmup + 1), 2)
+              for k in ("_vcycles_linear", "_vcycles_fas") if k in param}
+    out = {"metric": f"particles pushed/sec (one PM step), {solver_name}, fp32", "value": value,
            "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"Newton {n}^3 mesh / {n}^3 particles, TSC, FFT Poisson (compensated), "
-                                  f"order-5 gradient, leapfrog KDK, Zel'dovich ICs rms {args.rms_cells} cell, "
+           "config": {"workload": f"{args.config}: {n}^3 mesh / {n}^3 particles, TSC, "
+                                  + ("FFT Poisson (compensated), " if args.config == "newton_fft" else
+                                     f"multigrid Npre 2 Npost 1 epsrel 1e-2 (V-cycles per solve-step: {cycles}), ")
+                                  + f"order-5 gradient, leapfrog KDK, Zel'dovich ICs rms {args.rms_cells} cell, "
                                   "Morton-sorted once, then the product loop's order policy inside the timed steps ("
                                   + (f"incremental tile re-sort above {param['rebucket_straggler_fraction']:g} stragglers"
                                      if "rebucket_straggler_fraction" in param else "in-place steps")
                                   + f", full sort above {pm_main.REORDER_FRACTION:g})",
-                      "ncells_1d": n, "npart": npart,
+                      "ncells_1d": n, "npart": npart, "vcycles_per_step": cycles,
                       "parallelism": "1 GPU" if world == 1 else f"{world} x-slabs, RCCL all-to-all FFT transposes + ring halos"},
            "roofline": roofline}
     # the first and last five timed steps: straggler fraction (particles outside the tile the sort filed them
@@ -380,7 +425,8 @@ def main():
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         del pos, vel, acc, phi, extra
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(args.cpu_ncells)
+        out["cpu_baseline"] = cpu_baseline(min(args.cpu_ncells, n) if args.config == "newton_fft" else min(128, n),
+                                           config=args.config)
         # the P(k) half of the metric as top-level keys (BASELINE.json: "... + P(k) rel-err")
         pk = out["cpu_baseline"]["pk_rel_err"]
         out["pk_rel_err"], out["pk_rel_err_fp64"], out["pk_steps"] = pk["value"], pk["vs_fp64"], pk["steps"]

@@ -246,6 +246,18 @@ int pm_lap_restrict_residual(pm_ctx *ctx, const float *d_x, const float *d_b, in
 int pm_lap_residual_error(pm_ctx *ctx, const float *d_x, const float *d_b, int n, float *h_out);
 /* sqrt(sum (f*a - b)^2): tail of laplacian.truncation_error :529 (f = 1) and cubic.truncation_error :1057 (f = 4) */
 int pm_diff_norm(pm_ctx *ctx, const float *d_a, const float *d_b, float f, int64_t count, float *h_out);
+/* laplacian.smoothing (laplacian.py:1026): n_smoothing red-black sweeps with omega = 1.25 on x in place.  For
+ * n >= 256 each sweep is ONE pass over the grid (red and black updated by a workgroup marching through LDS planes,
+ * out of place into a scratch grid of the context, copied back after an odd count): x and b read once, x written once
+ * per sweep instead of twice.  Same bits as pm_lap_gauss_seidel called n_smoothing times.  pm_set_fused_sweep(ctx, 0)
+ * makes every sweep the two half-sweep launches again (comparison / fallback). */
+int pm_lap_smoothing(pm_ctx *ctx, float *d_x, const float *d_b, int n, int n_smoothing);
+int pm_set_fused_sweep(pm_ctx *ctx, int on);
+/* multigrid.V_cycle (multigrid.py:474-517) on x in place, the whole recursion down to the 4^3 grid issued from C:
+ * Npre smoothing sweeps, restricted residual, first guess -h^2/6 res (laplacian.py:765), coarse cycle (below 8^3 cells
+ * only Npre sweeps), added prolongation, Npost sweeps; omega = 1.25.  Same kernels, same bits as the per-operator
+ * entry points called in that order.  n >= 8. */
+int pm_lap_vcycle(pm_ctx *ctx, float *d_x, const float *d_b, int n, int npre, int npost);
 /* laplacian.gauss_seidel :844: one red + one black sweep with over-relaxation f_relax, in place */
 int pm_lap_gauss_seidel(pm_ctx *ctx, float *d_x, const float *d_b, int n, float f_relax);
 /* cubic.operator :23 (d_rhs NULL) / cubic.residual_with_rhs :90 */

@@ -168,6 +168,9 @@ struct pm_ctx {
     int64_t sorted_np;         // partitions [0, np) gives correct results, an exact one saves the bisection)
     unsigned sorted_ntiles;
     int rb_cur;
+    int mg_fused_sweep;  // 1 (default): single-pass red + black sweep for n >= 256 (pm_set_fused_sweep; tests compare)
+    void *mg_buf;        // scratch grids of pm_lap_vcycle (grown on demand)
+    size_t mg_buf_bytes;
     // sort workspace (grown on demand)
     void *sort_tmp;
     size_t sort_tmp_bytes;

@@ -57,6 +57,7 @@ extern "C" int pm_ctx_create(pm_ctx **out, int n, void *stream) {
     c->slab_nx = n;
     c->slab_x0 = 0;
     c->gather_mode = 1;
+    c->mg_fused_sweep = 1;
     c->tile_x_lo = 0, c->tile_nx = n;
     c->last_stragglers = -1, c->last_np = 0, c->last_complete = 1;
     c->stream = (hipStream_t)stream;
@@ -92,6 +93,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *c) {
     if (c->tile_tmp) hipFree(c->tile_tmp);
     if (c->list_buf) hipFree(c->list_buf);
     if (c->rb_buf) hipFree(c->rb_buf);
+    if (c->mg_buf) hipFree(c->mg_buf);
     hipFree(c->d_scratch);
     hipFree(c->d_tab);
     hipFree(c->d_hist);

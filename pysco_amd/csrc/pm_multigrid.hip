@@ -87,7 +87,7 @@ __global__ __launch_bounds__(BLK) void prolongation_kernel(float *__restrict__ y
 
 // four fine k-cells per thread (nc >= 8): the four coarse rows are read as one aligned float2 + two scalars each,
 // the fine row is one float4 read-modify-write; same expression per fine cell
-__global__ __launch_bounds__(BLK) void prolongation_rows_kernel(float *__restrict__ y, const float *__restrict__ xc,
+__global__ __launch_bounds__(BLK) void prolongation_rows_kernel(float *y, const float *ysrc, const float *__restrict__ xc,
                                                                 int log2nc, int add, XRange xf, XRange xcr) {
     const int log2nf = log2nc + 1, nf = 1 << log2nf, nc = 1 << log2nc, mc = nc - 1, lq = log2nf - 2;
     const float f0 = (float)(27.0 / 64), f1 = (float)(9.0 / 64), f2 = (float)(3.0 / 64), f3 = (float)(1.0 / 64);
@@ -103,8 +103,9 @@ __global__ __launch_bounds__(BLK) void prolongation_rows_kernel(float *__restric
         };
         float c00[4], cX[4], cY[4], cXY[4];
         ld(i, j, c00), ld(ia, j, cX), ld(i, jb, cY), ld(ia, jb, cXY);
-        float *dst = y + cidx(xf.i0 + fi, jf, 4 * q, log2nf);
-        float4 o = add ? *reinterpret_cast<const float4 *>(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t at = cidx(xf.i0 + fi, jf, 4 * q, log2nf);
+        float *dst = y + at;  // (add: y = ysrc + prolongation; ysrc == y for the in-place form)
+        float4 o = add ? *reinterpret_cast<const float4 *>(ysrc + at) : make_float4(0.f, 0.f, 0.f, 0.f);
         float ov[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
         for (int c2 = 0; c2 < 4; ++c2) {
@@ -117,13 +118,19 @@ __global__ __launch_bounds__(BLK) void prolongation_rows_kernel(float *__restric
     }
 }
 
-static int prolongation_launch(pm_ctx *c, float *d_y, const float *d_xc, int nc, int add, XRange xf, XRange xcr) {
+static int prolongation_launch(pm_ctx *c, float *d_y, const float *d_xc, int nc, int add, XRange xf, XRange xcr,
+                               const float *d_ysrc = nullptr) {
     const int64_t total = (int64_t)xf.ni * (2 * nc) * (2 * nc);
-    if (nc >= 8 && pm_aligned16(d_y) && pm_aligned16(d_xc)) {
+    if (!d_ysrc) d_ysrc = d_y;
+    if (nc >= 8 && pm_aligned16(d_y) && pm_aligned16(d_xc) && pm_aligned16(d_ysrc)) {
         hipLaunchKernelGGL(prolongation_rows_kernel, dim3(pm_stream_blocks(total / 4, BLK)), dim3(BLK), 0, c->stream, d_y,
-                           d_xc, ilog2(nc), add, xf, xcr);
+                           d_ysrc, d_xc, ilog2(nc), add, xf, xcr);
         PM_LAUNCH_CHECK();
         return PM_OK;
+    }
+    if (d_ysrc != d_y) {
+        pm_set_error("out-of-place prolongation needs nc >= 8 and 16-byte aligned arrays");
+        return PM_EINVAL;
     }
     hipLaunchKernelGGL(prolongation_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_y, d_xc,
                        ilog2(nc), add, xf, xcr);
@@ -548,6 +555,260 @@ extern "C" int pm_lap_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, int 
                        invsix, f_relax);
     PM_LAUNCH_CHECK();
     return PM_OK;
+}
+
+static int mg_arena(pm_ctx *c, size_t bytes, float **out) {
+    if (c->mg_buf_bytes < bytes) {
+        if (c->mg_buf) PM_HIP(hipFree(c->mg_buf));
+        c->mg_buf = nullptr, c->mg_buf_bytes = 0;
+        PM_HIP(hipMalloc(&c->mg_buf, bytes));
+        c->mg_buf_bytes = bytes;
+    }
+    *out = (float *)c->mg_buf;
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Red + black sweep in ONE pass over the grid (n >= 256), out of place: x_in, b read once, x_out written once --
+// 12 B per cell plus the halos, where the two half-sweep launches above move 24 (each reads x and b and writes x
+// whole).  A workgroup owns a column of 16 x 64 cells (j, k) and marches 32 planes along x with five planes of x in
+// LDS (each with a 2-cell rim, rows of 72 floats = 18 aligned float4): at step i it turns the red cells of plane
+// i + 1 to their new values in LDS (they only read black cells: the old ones of planes i, i + 1, i + 2), then computes
+// the black cells of plane i from the new reds of planes i - 1, i, i + 1 and stores plane i.  The next plane and the
+// right-hand sides travel one step ahead in registers.  Every cell is updated by gs_update with the summation order
+// of its parity class: the same bits as the two launches.  (Round 1's version of this -- no register prefetch,
+// whole-x columns, three barriers per plane -- was latency-bound and slower than the half-sweeps.)
+constexpr int GF_TJ = 16, GF_TK = 64, GF_LX = 32, GF_ROW = GF_TK + 8, GF_ROWS = GF_TJ + 4, GF_PLANE = GF_ROW * GF_ROWS;
+constexpr int GF_SLOTS = 5, GF_Q4 = GF_ROWS * (GF_ROW / 4);  // 360 float4 per plane
+constexpr int GF_RING = 2 * (GF_TK + 2) + 2 * GF_TJ;         // 164 cells around the own region
+
+__device__ __forceinline__ float gs_update_cls(int cls, float xm, float xp, float ym, float yp, float zm, float zp,
+                                               float mh2b, float xc, float invsix, float f_relax) {
+    switch (cls) {  // (i & 1, j & 1, k & 1): the orders of gs_cell / GS_ROW
+        case 7: return gs_update<5, 3, 1, 0, 2, 4, 6>(xm, xp, ym, yp, zm, zp, mh2b, xc, invsix, f_relax);
+        case 4: return gs_update<2, 4, 1, 0, 6, 5, 3>(xm, xp, ym, yp, zm, zp, mh2b, xc, invsix, f_relax);
+        case 2: return gs_update<0, 3, 4, 1, 2, 5, 6>(xm, xp, ym, yp, zm, zp, mh2b, xc, invsix, f_relax);
+        case 1: return gs_update<0, 2, 5, 4, 6, 3, 1>(xm, xp, ym, yp, zm, zp, mh2b, xc, invsix, f_relax);
+        case 6: return gs_update<4, 3, 1, 0, 2, 6, 5>(xm, xp, ym, yp, zm, zp, mh2b, xc, invsix, f_relax);
+        case 5: return gs_update<2, 5, 1, 0, 4, 6, 3>(xm, xp, ym, yp, zm, zp, mh2b, xc, invsix, f_relax);
+        case 3: return gs_update<0, 5, 3, 2, 4, 6, 1>(xm, xp, ym, yp, zm, zp, mh2b, xc, invsix, f_relax);
+        default: return gs_update<0, 2, 4, 6, 5, 3, 1>(xm, xp, ym, yp, zm, zp, mh2b, xc, invsix, f_relax);
+    }
+}
+
+__global__ __launch_bounds__(BLK) void lap_gs_fused_kernel(const float *__restrict__ xin, const float *__restrict__ b,
+                                                           float *__restrict__ xout, int log2n, float h2, float invsix,
+                                                           float f_relax) {
+    __shared__ __attribute__((aligned(16))) float pl[GF_SLOTS][GF_PLANE];  // 28.8 KB
+    const int n = 1 << log2n, m = n - 1, tid = threadIdx.x;
+    const int ncol_k = n / GF_TK, ncol_j = n / GF_TJ;
+    const int col = blockIdx.x % (ncol_k * ncol_j), seg = blockIdx.x / (ncol_k * ncol_j);
+    const int k0 = (col % ncol_k) * GF_TK, j0 = (col / ncol_k) * GF_TJ, i0 = seg * GF_LX;
+    auto slot = [&](int p) -> float * { return pl[((p % GF_SLOTS) + GF_SLOTS) % GF_SLOTS]; };  // p relative to i0, >= -2
+
+    // global -> registers -> LDS of one raw plane (relative index p): float4 number f of the plane, 2 per thread
+    const int f0 = tid, f1 = tid + BLK;
+    auto q_src = [&](int p, int f) -> const float4 * {
+        const int rr = f / (GF_ROW / 4), c4 = f - rr * (GF_ROW / 4);
+        return reinterpret_cast<const float4 *>(xin + cidx((i0 + p) & m, (j0 - 2 + rr) & m, (k0 - 4 + 4 * c4) & m, log2n));
+    };
+    auto q_put = [&](int p, int f, float4 v) {
+        const int rr = f / (GF_ROW / 4), c4 = f - rr * (GF_ROW / 4);
+        *reinterpret_cast<float4 *>(slot(p) + rr * GF_ROW + 4 * c4) = v;
+    };
+    // the thread's own quad: row rq (0..15), k 4 kq .. 4 kq + 3 of the own region
+    const int rq = tid >> 4, kq = tid & 15;
+    const int jq = j0 + rq, lrow = (rq + 2) * GF_ROW, lcol = 4 + 4 * kq;
+    auto b_quad = [&](int p) -> float4 {
+        return *reinterpret_cast<const float4 *>(b + cidx((i0 + p) & m, jq, k0 + 4 * kq, log2n));
+    };
+    // the thread's cell of the ring around the own region (tid < GF_RING): LDS row / column and global j, k
+    int ring_r = 0, ring_c = 0;
+    if (tid < GF_TK + 2) ring_r = 1, ring_c = 3 + tid;
+    else if (tid < 2 * (GF_TK + 2)) ring_r = GF_TJ + 2, ring_c = 3 + tid - (GF_TK + 2);
+    else if (tid < 2 * (GF_TK + 2) + GF_TJ) ring_r = 2 + tid - 2 * (GF_TK + 2), ring_c = 3;
+    else ring_r = 2 + tid - 2 * (GF_TK + 2) - GF_TJ, ring_c = GF_TK + 4;
+    const int ring_j = (j0 - 2 + ring_r) & m, ring_k = (k0 - 4 + ring_c) & m;
+    auto b_ring = [&](int p) -> float {
+        return tid < GF_RING ? b[cidx((i0 + p) & m, ring_j, ring_k, log2n)] : 0.f;
+    };
+    // new value of the cell at LDS (row offset ro, column c) of plane p (relative), parities from the global indices
+    auto update = [&](int p, int ro, int c, int gj, int gk, float bval) -> float {
+        const float *vm = slot(p - 1), *v0 = slot(p), *vp = slot(p + 1);
+        const int o = ro + c;
+        const int cls = ((((i0 + p) & 1) << 2) | ((gj & 1) << 1) | (gk & 1));
+        return gs_update_cls(cls, vm[o], vp[o], v0[o - GF_ROW], v0[o + GF_ROW], v0[o - 1], v0[o + 1], -(h2 * bval), v0[o],
+                             invsix, f_relax);
+    };
+    // red cells (i + j + k odd) of plane p, in place in LDS: the two of the own quad + the ring cell if it is red
+    auto red_phase = [&](int p, float4 bq, float br) {
+        const int e0 = ((i0 + p) + jq + 1) & 1;  // k offsets e0, e0 + 2 of the quad are red
+        const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+        float *v0 = slot(p);
+        const float r0 = update(p, lrow, lcol + e0, jq, e0, bb[e0]);
+        const float r1 = update(p, lrow, lcol + e0 + 2, jq, e0, bb[e0 + 2]);
+        float rr = 0.f;
+        const bool ring_red = tid < GF_RING && (((i0 + p) + ring_j + ring_k) & 1);
+        if (ring_red) rr = update(p, ring_r * GF_ROW, ring_c, ring_j, ring_k, br);
+        v0[lrow + lcol + e0] = r0, v0[lrow + lcol + e0 + 2] = r1;
+        if (ring_red) v0[ring_r * GF_ROW + ring_c] = rr;
+    };
+
+    // prologue: planes -2, -1, 0 -> R(-1); plane 1 -> R(0)
+    float4 pf0, pf1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = -2; p <= 0; ++p) {
+        q_put(p, f0, *q_src(p, f0));
+        if (f1 < GF_Q4) q_put(p, f1, *q_src(p, f1));
+    }
+    float4 bq_m1 = b_quad(-1), bq_0 = b_quad(0);
+    float br_m1 = b_ring(-1), br_0 = b_ring(0);
+    pf0 = *q_src(1, f0);
+    if (f1 < GF_Q4) pf1 = *q_src(1, f1);
+    __syncthreads();
+    red_phase(-1, bq_m1, br_m1);
+    q_put(1, f0, pf0);
+    if (f1 < GF_Q4) q_put(1, f1, pf1);
+    pf0 = *q_src(2, f0);
+    if (f1 < GF_Q4) pf1 = *q_src(2, f1);
+    float4 bq_next = b_quad(1);  // b of plane i + 1 (red phase of step i), then of plane i (black phase of step i + 1)
+    float br_next = b_ring(1);
+    __syncthreads();
+    red_phase(0, bq_0, br_0);
+    float4 bq_cur = bq_0;  // b of plane i for the black phase
+
+#pragma unroll 1
+    for (int i = 0; i < GF_LX; ++i) {
+        // a. the prefetched plane i + 2 goes to LDS; plane i + 3 and the next right-hand sides start their way
+        q_put(i + 2, f0, pf0);
+        if (f1 < GF_Q4) q_put(i + 2, f1, pf1);
+        if (i + 1 < GF_LX) {
+            pf0 = *q_src(i + 3, f0);
+            if (f1 < GF_Q4) pf1 = *q_src(i + 3, f1);
+        }
+        const float4 bq_r = bq_next;
+        const float br_r = br_next;
+        if (i + 1 < GF_LX) bq_next = b_quad(i + 2), br_next = b_ring(i + 2);
+        __syncthreads();
+        // c. red cells of plane i + 1
+        red_phase(i + 1, bq_r, br_r);
+        __syncthreads();
+        // e. black cells of plane i (own quad), then the whole quad of plane i leaves
+        {
+            const int e0 = ((i0 + i) + jq + 1) & 1;  // reds at e0, e0 + 2; blacks at 1 - e0, 3 - e0
+            const float bb[4] = {bq_cur.x, bq_cur.y, bq_cur.z, bq_cur.w};
+            const float *v0 = slot(i);
+            float q[4];
+            q[e0] = v0[lrow + lcol + e0], q[e0 + 2] = v0[lrow + lcol + e0 + 2];
+            q[1 - e0] = update(i, lrow, lcol + 1 - e0, jq, 1 - e0, bb[1 - e0]);
+            q[3 - e0] = update(i, lrow, lcol + 3 - e0, jq, 1 - e0, bb[3 - e0]);
+            *reinterpret_cast<float4 *>(xout + cidx((i0 + i) & m, jq, k0 + 4 * kq, log2n)) = make_float4(q[0], q[1], q[2], q[3]);
+        }
+        bq_cur = bq_r;
+    }
+}
+
+// n_sweeps red-black sweeps starting from `cur`: the single-pass kernel ping-ponging between `cur` and `other` where it
+// applies (n >= 256), the two half-sweep launches in place otherwise.  *where = the array that holds the result.
+static bool lap_fused_applies(const pm_ctx *c, int n, const float *x, const float *b, const float *tmp) {
+    return c->mg_fused_sweep && tmp && n >= 256 && pm_aligned16(x) && pm_aligned16(b) && pm_aligned16(tmp);
+}
+
+static int lap_smooth_pp(pm_ctx *c, float *cur, float *other, const float *b, int n, int n_sweeps, float f_relax,
+                         float **where) {
+    int rc;
+    *where = cur;
+    if (!lap_fused_applies(c, n, cur, b, other)) {
+        for (int s = 0; s < n_sweeps; ++s)
+            if ((rc = pm_lap_gauss_seidel(c, cur, b, n, f_relax))) return rc;
+        return PM_OK;
+    }
+    const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
+    const unsigned blocks = (unsigned)((n / GF_TJ) * (n / GF_TK) * (n / GF_LX));
+    float *src = cur, *dst = other;
+    for (int s = 0; s < n_sweeps; ++s) {
+        hipLaunchKernelGGL(lap_gs_fused_kernel, dim3(blocks), dim3(BLK), 0, c->stream, src, b, dst, ilog2(n), h2, invsix, f_relax);
+        PM_LAUNCH_CHECK();
+        float *t = src;
+        src = dst, dst = t;
+    }
+    *where = src;
+    return PM_OK;
+}
+
+// ... with the result in x (an odd count of single-pass sweeps ends with a copy back)
+static int lap_smooth(pm_ctx *c, float *x, const float *b, int n, int n_sweeps, float f_relax, float *tmp) {
+    float *where = x;
+    int rc = lap_smooth_pp(c, x, tmp, b, n, n_sweeps, f_relax, &where);
+    if (rc) return rc;
+    if (where != x) PM_HIP(hipMemcpyAsync(x, where, (size_t)n * n * n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return PM_OK;
+}
+
+extern "C" int pm_set_fused_sweep(pm_ctx *c, int on) {
+    PM_REQUIRE(c != nullptr, "ctx is NULL");
+    c->mg_fused_sweep = on ? 1 : 0;
+    return PM_OK;
+}
+
+// laplacian.smoothing (laplacian.py:1026) on device arrays: n_smoothing sweeps with omega = 1.25, in place
+extern "C" int pm_lap_smoothing(pm_ctx *c, float *d_x, const float *d_b, int n, int n_smoothing) {
+    PM_REQUIRE(c && d_x && d_b && n_smoothing >= 0, "bad argument");
+    PM_CHECK_GRID(n);
+    float *tmp = nullptr;
+    if (n >= 256) {
+        int rc = mg_arena(c, ((size_t)n * n * n * 9 / 7 + 1024) * sizeof(float), &tmp);
+        if (rc) return rc;
+    }
+    return lap_smooth(c, d_x, d_b, n, n_smoothing, 1.25f, tmp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One whole linear V-cycle (multigrid.py:474-517) issued from C: the recursion over levels with its scratch grids
+// taken from one arena of the context, every level operation the kernel the stand-alone entry points launch (same
+// bits).  Issued one by one from Python the ~20 calls per level cost more than the kernels below 128^3.
+
+static int lap_vcycle_level(pm_ctx *c, float *x, const float *b, int n, int npre, int npost, float *scratch) {
+    const float f_relax = 1.25f;  // laplacian.py:1051
+    int rc;
+    // (the level's ping-pong grid for the single-pass sweep sits first in its share of the arena)
+    float *tmp = n >= 256 ? scratch : nullptr;
+    if (tmp) scratch += (int64_t)n * n * n;
+    float *cur = x;  // the array that holds the level's solution at the moment
+    if ((rc = lap_smooth_pp(c, x, tmp, b, n, npre, f_relax, &cur))) return rc;
+    const int nc = n / 2;
+    const int64_t cells = (int64_t)nc * nc * nc;
+    float *res_c = scratch, *x_corr_c = scratch + cells;
+    if ((rc = pm_lap_restrict_residual(c, cur, b, n, res_c))) return rc;
+    // laplacian.initialise_potential (laplacian.py:765): -h^2/6 * b with h = 1/nc in fp32, the quotient in fp64
+    const float h = 1.0f / (float)nc;
+    const float minus_h2_over_six = (float)(-(double)(h * h) / 6.0);
+    if ((rc = pm_linear_operator(c, x_corr_c, res_c, minus_h2_over_six, 0.0f, cells))) return rc;
+    if (n <= 8) {  // nlevel >= ncoarse - 3 (multigrid.py:510): the coarsest correction is only smoothed
+        for (int s = 0; s < npre; ++s)
+            if ((rc = pm_lap_gauss_seidel(c, x_corr_c, res_c, nc, f_relax))) return rc;
+    } else if ((rc = lap_vcycle_level(c, x_corr_c, res_c, nc, npre, npost, scratch + 2 * cells))) {
+        return rc;
+    }
+    // the corrected solution goes where an odd / even number of ping-pong sweeps will leave the result in x
+    float *target = x;
+    if (lap_fused_applies(c, n, x, b, tmp) && (npost & 1)) target = tmp;
+    if ((rc = prolongation_launch(c, target, x_corr_c, nc, 1, xr_cube(n), xr_cube(nc), cur))) return rc;
+    float *where = target;
+    if ((rc = lap_smooth_pp(c, target, target == x ? tmp : x, b, n, npost, f_relax, &where))) return rc;
+    if (where != x) PM_HIP(hipMemcpyAsync(x, where, (size_t)n * n * n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return PM_OK;
+}
+
+extern "C" int pm_lap_vcycle(pm_ctx *c, float *d_x, const float *d_b, int n, int npre, int npost) {
+    PM_REQUIRE(c && d_x && d_b && npre >= 0 && npost >= 0, "bad argument");
+    PM_CHECK_GRID(n);
+    PM_REQUIRE(n >= 8, "pm_lap_vcycle needs n >= 8 (ncoarse >= 3)");
+    // two grids per coarse level: 2 (n/2)^3 (1 + 1/8 + ...) < 2 n^3 / 7 floats, and a ping-pong grid per level of 256^3
+    // and more: n^3 (1 + 1/8 + ...) < 8 n^3 / 7
+    float *scratch = nullptr;
+    int rc = mg_arena(c, ((size_t)n * n * n * (n >= 256 ? 11 : 2) / 7 + 1024) * sizeof(float), &scratch);
+    if (rc) return rc;
+    return lap_vcycle_level(c, d_x, d_b, n, npre, npost, scratch);
 }
 
 // One colour half-sweep on a slab [nx + 2, n, n] (owned planes 1..nx, ghosts filled by the caller, who

@@ -97,7 +97,13 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
                 ratio = min(1.5, max(0.5, float(dt) / dt_last)) if (dt_last and dt_last > 0) else 1.0
                 param["_dt_last"] = float(dt)
                 L.context(ncells_1d).call("pm_set_predicted_dt", float(np.float32(dt * ratio)) if _PREDICT and dt > 0 else 0.0)
-            if _USE_KHALO:
+            # the halo side buffer pays off when the fused FFT solve consumes it (its z pass adds it while loading
+            # the density); every other solver needs the completed density: for those, the plain flush
+            khalo_consumer = (param["theory"].casefold() in ("newton", "parametrized")
+                              and param["linear_newton_solver"].casefold() in ("fft", "fft_7pt")
+                              and 32 <= ncells_1d <= 1024 and solver._USE_FUSED_FFT
+                              and param["save_power_spectrum"].casefold() == "no")
+            if _USE_KHALO and (khalo_consumer or _USE_KHALO == "always"):
                 # the tiles' halo cells go to a side buffer and the own cells to the density, all with plain
                 # stores instead of memory-side atomics; solver.pm hands the buffer to the FFT solve (or has
                 # it added to the density)

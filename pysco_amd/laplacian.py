@@ -89,8 +89,7 @@ def gauss_seidel(x, b, f_relax) -> None:
 def smoothing(x, b, n_smoothing: int) -> None:
     """n_smoothing sweeps with omega = 1.25 (laplacian.py:1026)."""
     if L.is_device_array(x):
-        for _ in range(int(n_smoothing)):
-            gauss_seidel(x, b, np.float32(1.25))
+        L.context(4).call("pm_lap_smoothing", L.ptr(x), L.ptr(_dev(b)), x.shape[0], int(n_smoothing))
     else:
         xd = _dev(x)
         for _ in range(int(n_smoothing)):

@@ -38,6 +38,7 @@ def linear(x, b, param):
     residual_err = 1e30
     while residual_err > tolerance:
         V_cycle(x, b, param)
+        param["_vcycles_linear"] = param.get("_vcycles_linear", 0) + 1  # (bookkeeping for bench.py, not a parameter)
         residual_error_tmp = laplacian.residual_error(x, b)
         logging.info(f"{residual_error_tmp=} {tolerance=}")
         if residual_error_tmp < tolerance or residual_err / residual_error_tmp < 2:
@@ -46,8 +47,21 @@ def linear(x, b, param):
     return x
 
 
+_NATIVE_VCYCLE = True  # tests flip this to compare with the recursion written out below
+
+
 def V_cycle(x, b, param, nlevel: int = 0) -> None:
     """One linear V-cycle, in place on x (multigrid.py:474)."""
+    n = x.shape[0]
+    if (_NATIVE_VCYCLE and n >= 8 and (n & (n - 1)) == 0 and (param["ncoarse"] - nlevel) == int(np.log2(n))
+            and x.dtype == (np.float32 if not L.is_device_array(x) else L.require_gpu().float32)):
+        # the same sequence of kernels issued from C in one call (pmstep.h: pm_lap_vcycle)
+        torch = L.require_gpu()
+        xd, bd = L.to_device(x, torch.float32), L.to_device(b, torch.float32)
+        L.context(4).call("pm_lap_vcycle", L.ptr(xd), L.ptr(bd), n, int(param["Npre"]), int(param["Npost"]))
+        if not L.is_device_array(x):
+            x[...] = xd.cpu().numpy()
+        return
     laplacian.smoothing(x, b, param["Npre"])
     res_c = laplacian.restrict_residual(x, b)
     x_corr_c = laplacian.initialise_potential(res_c)
@@ -120,6 +134,7 @@ def FAS(x, b, param):
     residual_err = 1e30
     while residual_err > tolerance:
         V_cycle_FAS(x, b, param)
+        param["_vcycles_fas"] = param.get("_vcycles_fas", 0) + 1
         residual_error_tmp = residual_error(x, b, param)
         logging.info(f"{residual_error_tmp=} {tolerance=}")
         if residual_error_tmp < tolerance or residual_err / residual_error_tmp < 2:

@@ -261,3 +261,66 @@ def test_multigrid_solves_the_7pt_problem_at_scale(amd):
     lap = amd.laplacian.operator(phi_f)
     assert float((lap - src).abs().max()) < 2e-3 * float(src.abs().max())
 
+
+
+@pytest.mark.parametrize("n", [8, 16, 64, 128])
+def test_native_vcycle_is_the_python_recursion(amd, n):
+    """pm_lap_vcycle (the whole V-cycle issued from C) against multigrid.V_cycle's recursion written out in Python
+    over the per-operator entry points: same kernels in the same order, so the same bits."""
+    rng = np.random.default_rng(n)
+    t = amd.torch
+    b = t.from_numpy(rng.normal(size=(n, n, n)).astype(np.float32)).cuda()
+    b -= b.mean()
+    x0 = t.from_numpy(rng.normal(size=(n, n, n)).astype(np.float32)).cuda() * 1e-3
+    param = {"Npre": 2, "Npost": 1, "ncoarse": int(np.log2(n))}
+    out = {}
+    for native in (True, False):
+        amd.multigrid._NATIVE_VCYCLE = native
+        try:
+            x = x0.clone()
+            amd.multigrid.V_cycle(x, b, param)
+            amd.multigrid.V_cycle(x, b, param)
+            out[native] = x.cpu().numpy()
+        finally:
+            amd.multigrid._NATIVE_VCYCLE = True
+    np.testing.assert_array_equal(out[True], out[False])
+    assert np.isfinite(out[True]).all()
+
+
+@pytest.mark.parametrize("n,sweeps", [(256, 1), (256, 2), (256, 3), (512, 2)])
+def test_single_pass_sweep_is_the_two_half_sweeps(amd, n, sweeps):
+    """The single-pass red + black sweep (pm_lap_smoothing, n >= 256: one workgroup marching a column through LDS
+    planes, out of place) against the two half-sweep launches per sweep: the same bits, whole grid."""
+    from pysco_amd import _lib as L
+
+    t = amd.torch
+    g = t.Generator(device="cuda")
+    g.manual_seed(n + sweeps)
+    b = t.randn((n, n, n), generator=g, device="cuda")
+    b -= b.mean()
+    x0 = t.randn((n, n, n), generator=g, device="cuda") * 1e-4
+    out = {}
+    ctx = L.context(4)
+    for fused in (1, 0):
+        ctx.call("pm_set_fused_sweep", fused)
+        try:
+            x = x0.clone()
+            amd.laplacian.smoothing(x, b, sweeps)
+            out[fused] = x
+        finally:
+            ctx.call("pm_set_fused_sweep", 1)
+    assert bool(t.isfinite(out[1]).all())
+    assert bool((out[1] == out[0]).all()), float((out[1] - out[0]).abs().max())
+    # and a whole V-cycle through both
+    if sweeps == 2:
+        param = {"Npre": 2, "Npost": 1, "ncoarse": int(np.log2(n))}
+        vc = {}
+        for fused in (1, 0):
+            ctx.call("pm_set_fused_sweep", fused)
+            try:
+                x = x0.clone()
+                amd.multigrid.V_cycle(x, b, param)
+                vc[fused] = x
+            finally:
+                ctx.call("pm_set_fused_sweep", 1)
+        assert bool((vc[1] == vc[0]).all())

@@ -506,7 +506,7 @@ def test_leapfrog_halo_buffer_vs_plain_flush(amd, theory_solver):
     tables = bench.synth_tables()
     out = {}
     for use in (True, False):
-        amd.integration._USE_KHALO = use
+        amd.integration._USE_KHALO = "always" if use else False  # ("always": also where the solver is not its consumer)
         try:
             param, _ = bench.make_param(n, npart_1d**3)
             param["theory"], param["linear_newton_solver"] = theory_solver
