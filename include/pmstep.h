@@ -218,7 +218,8 @@ int pm_gradient_interp_kick(pm_ctx *ctx, int order, int scheme, const float *d_p
  * permutation.  Needs the ranges, lists and stay counts pm_kick_drift_wrap_deposit[_khalo] left prepared for
  * exactly d_pos / np (fails otherwise; check pm_tile_lists_info's `complete` first).  The context remembers the
  * tile offsets of d_pos_out: the next pm_kick_drift_wrap_deposit on it skips the range search.
- * Single-GPU layout, n >= 16, max|acc| / max|vel| left for pm_last_maxabs as usual. */
+ * order = 0: d_phi is the force grid [n, n, n, 3] (pm_interp_kick's input: the f(R) path, whose force is not the
+ * gradient of one potential).  Single-GPU layout, n >= 16, max|acc| / max|vel| left for pm_last_maxabs as usual. */
 int pm_gradient_interp_kick_rebucket(pm_ctx *ctx, int order, int scheme, const float *d_phi, const float *d_pos,
                                      const float *d_vel, int64_t np, float half_dt, float *d_pos_out, float *d_vel_out,
                                      float *d_acc_out, const unsigned *d_id, unsigned *d_id_out);

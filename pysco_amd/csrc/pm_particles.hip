@@ -2307,12 +2307,13 @@ template <int SCHEME>
 static int rebucket_order(pm_ctx *c, int order, const float *phi, pm_geom geo, const float *pos, float *vel, int64_t np,
                           float half_dt, const TileWork &work, const TileLists &lists, unsigned nblk, const Rebucket &rb) {
     switch (order) {
+        case 0: return rebucket_launch<SCHEME, 0>(c, phi, geo, pos, vel, np, half_dt, work, lists, nblk, rb);  // force grid
         case 2: return rebucket_launch<SCHEME, 2>(c, phi, geo, pos, vel, np, half_dt, work, lists, nblk, rb);
         case 3: return rebucket_launch<SCHEME, 3>(c, phi, geo, pos, vel, np, half_dt, work, lists, nblk, rb);
         case 5: return rebucket_launch<SCHEME, 5>(c, phi, geo, pos, vel, np, half_dt, work, lists, nblk, rb);
         case 7: return rebucket_launch<SCHEME, 7>(c, phi, geo, pos, vel, np, half_dt, work, lists, nblk, rb);
     }
-    pm_set_error("gradient order %d, should be 2, 3, 5 or 7", order);
+    pm_set_error("gradient order %d, should be 0 (force grid), 2, 3, 5 or 7", order);
     return PM_EINVAL;
 }
 

@@ -149,7 +149,7 @@ def _rebucket_request(density, param, position):
     gather write position, velocity and acceleration out of place in tile order: integrate() then returns NEW
     tensors (same particles, permuted; param["particle_id"], an optional int32 tensor, follows them)."""
     thr = param.get("rebucket_straggler_fraction")
-    if thr is None or density is None or param["theory"].casefold() == "fr":
+    if thr is None or density is None:
         return None
     frac, complete = utils.straggler_fraction(2 ** int(param["ncoarse"]))
     if frac is None or not complete or frac <= float(thr):

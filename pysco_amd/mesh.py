@@ -212,7 +212,7 @@ def derivative_interp_vec_kick_rebucket(scheme_name: str, potential, order: int,
     torch = L.require_gpu()
     n = potential.shape[1]
     scheme = {"cic": L.CIC, "tsc": L.TSC, "ngp": L.NGP}[scheme_name]
-    if order not in (2, 3, 5, 7):
+    if order not in (0, 2, 3, 5, 7):  # 0: `potential` is the force grid [n, n, n, 3] (interp_vec_kick's input)
         raise ValueError(f"{order=}, should be 2, 3, 5 or 7")
     ctx = L.context(n)
     acc, pos_out, vel_out = torch.empty_like(position), torch.empty_like(position), torch.empty_like(velocity)

@@ -100,7 +100,12 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
             if not lists_complete:
                 ctx.call("pm_set_gather_mode", 2)  # chunk / anchor kernel: any particle order through LDS
             try:
-                acceleration = mesh.interp_vec_kick(MASS_SCHEME, force, pos_d, _kick[0], _kick[1])
+                if _rebucket is not None and lists_complete and L.is_device_array(position):
+                    acceleration, _rebucket["position"], _rebucket["velocity"], _rebucket["ids"] = (
+                        mesh.derivative_interp_vec_kick_rebucket(MASS_SCHEME, force, 0, pos_d, _kick[0], _kick[1],
+                                                                 _rebucket.get("ids")))
+                else:
+                    acceleration = mesh.interp_vec_kick(MASS_SCHEME, force, pos_d, _kick[0], _kick[1])
             finally:
                 ctx.call("pm_set_gather_mode", 1)
         else:

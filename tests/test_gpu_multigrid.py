@@ -324,3 +324,46 @@ def test_single_pass_sweep_is_the_two_half_sweeps(amd, n, sweeps):
             finally:
                 ctx.call("pm_set_fused_sweep", 1)
         assert bool((vc[1] == vc[0]).all())
+
+
+def test_mond_and_fR_at_benchmark_size(amd):
+    """BASELINE configs 4 and 5 at their full 512^3, where the oracle cannot follow: size-independent properties.
+    QUMOND: the multigrid and the fft_7pt solver solve the same two discrete Poisson problems (Newtonian potential,
+    then the MOND source), so accelerations agree to the multigrid's stopping tolerance, and the Newtonian potential
+    satisfies its 7-point equation.  f(R): the FAS solve leaves a scalaron whose residual is below its tolerance, the
+    field is finite and positive, and the force responds (differs from the Newtonian one by the fifth force)."""
+    import bench
+
+    t = amd.torch
+    n = 512
+    pos, vel = bench.zeldovich_device(n, rms_cells=1.0)
+    amd.utils.periodic_wrap(pos)
+    pos, vel = amd.utils.reorder_particles(pos, vel)
+    del vel
+    # ---- QUMOND
+    p_mg, tables = bench.make_param(n, n**3, "mond")
+    p_mg["epsrel"] = 1e-3
+    p_ff = dict(p_mg, linear_newton_solver="fft_7pt")
+    acc_m, phi_m, newt_m = amd.solver.pm(pos, p_mg, tables=tables)
+    acc_f, phi_f, newt_f = amd.solver.pm(pos, p_ff, tables=tables)
+    for a, b_ in ((newt_m, newt_f), (phi_m, phi_f)):
+        a, b_ = a - a.mean(), b_ - b_.mean()
+        assert float((a - b_).abs().max()) < 3e-3 * float(b_.abs().max())
+    assert float((acc_m - acc_f).abs().max()) < 3e-2 * float(acc_f.abs().max())
+    assert bool(t.isfinite(acc_m).all())
+    rho = amd.mesh.TSC(pos, n)
+    src = np.float32(1.5 * p_mg["aexp"] * p_mg["Om_m"]) * (rho - 1.0)
+    lap = amd.laplacian.operator(newt_f)
+    assert float((lap - src).abs().max()) < 3e-3 * float(src.abs().max())
+    res = float(amd.laplacian.residual_error(newt_m, src))
+    assert res <= 1.05 * float(p_mg["tolerance"]), (res, p_mg["tolerance"])
+    del acc_f, phi_f, newt_f, lap, src, rho, phi_m, newt_m
+    # ---- f(R)
+    p_fr, tables = bench.make_param(n, n**3, "fr")
+    acc_r, phi_r, u = amd.solver.pm(pos, p_fr, tables=tables)
+    assert bool(t.isfinite(u).all()) and float(u.min()) > 0 and bool(t.isfinite(acc_r).all())
+    assert p_fr["_vcycles_fas"] >= 1 and p_fr["tolerance_FAS"] > 0
+    p_nw = dict(p_fr, theory="newton")
+    acc_n, _, _ = amd.solver.pm(pos, p_nw, tables=tables)
+    rel = float((acc_r - acc_n).abs().max()) / float(acc_n.abs().max())
+    assert 1e-4 < rel < 0.5, rel  # the fifth force is there, and it is a correction

@@ -24,7 +24,7 @@ def _tile_keys(pos, n):
     return (spread(c[:, 0]) << 2 | spread(c[:, 1]) << 1 | spread(c[:, 2])) >> 11
 
 
-def _run(n, pos_h, vel_h, steps, rebucket, sort_first=True, scheme="TSC", order=5, predict=False):
+def _run(n, pos_h, vel_h, steps, rebucket, sort_first=True, scheme="TSC", order=5, predict=False, config="newton_fft"):
     import torch
 
     import bench
@@ -33,7 +33,7 @@ def _run(n, pos_h, vel_h, steps, rebucket, sort_first=True, scheme="TSC", order=
 
     L._ctxs.clear()
     integration._PREDICT = predict
-    param, tables = bench.make_param(n, pos_h.shape[0])
+    param, tables = bench.make_param(n, pos_h.shape[0], config)
     param["mass_scheme"], param["gradient_stencil_order"] = scheme, order
     if rebucket is not None:
         param["rebucket_straggler_fraction"] = rebucket
@@ -144,3 +144,16 @@ def test_rebucket_requires_prepared_lists():
     L._ctxs.clear()
     with pytest.raises(L.PMStepError, match="no stay counts prepared"):
         mesh.derivative_interp_vec_kick_rebucket("tsc", phi, 5, pos, vel, 0.1)
+
+
+def test_rebucket_on_the_force_grid_path_of_fR():
+    """f(R): the force is not the gradient of one potential, the gather reads the [n, n, n, 3] force grid
+    (order 0 of pm_gradient_interp_kick_rebucket).  Same trajectories as the in-place steps."""
+    n = 32
+    pos_h, vel_h = zeldovich_particles(n, seed=5, rms_cells=0.5, vel_factor=0.3)
+    ref = _run(n, pos_h, vel_h, 3, None, config="fr")
+    new = _run(n, pos_h, vel_h, 3, 0.0, predict=True, config="fr")
+    assert np.isfinite(new[0]).all()
+    d = np.abs(ref[0][ref[3]] - new[0][new[3]])
+    assert np.minimum(d, 1 - d).max() <= 5e-6
+    assert np.abs(ref[2][ref[3]] - new[2][new[3]]).max() <= 2e-3 * np.abs(ref[2]).max()
