@@ -101,6 +101,16 @@ int pm_greens(pm_ctx *ctx, int kind, int p, void *d_xk, const float *h_k2, const
  * frequencies i or i - n as fp32; h_sinc: sinc(k h) per axis as for pm_pk. */
 int pm_grad_inverse_laplacian(pm_ctx *ctx, int p, const void *d_xk, void *d_out3, const float *h_kfreq,
                               const float *h_sinc);
+/* ---- initial conditions (initial_conditions.py:108-158, fourier.py:730-905) -------- */
+/* fourier.gradient (fourier.py:730): out_m = i 2 pi k_m x, three planar half-spectra [3][n, n, n/2+1] */
+int pm_kspace_gradient(pm_ctx *ctx, const void *d_xk, void *d_out3, const float *h_kfreq);
+/* fourier.hessian (:784; a2 = b2 = -1): -k_a1 k_b1 4 pi^2 x;  fourier.sum_of_hessian (:842): -(k_a1 k_b1 + k_a2 k_b2) 4 pi^2 x */
+int pm_kspace_hessian(pm_ctx *ctx, const void *d_xk, void *d_out, const float *h_kfreq, int a1, int b1, int a2, int b2);
+/* y = f a b (accumulate 0: utils.prod_vector_vector_inplace, utils.py:500) or y += f a b (1: add_vector_vector_inplace, :330) */
+int pm_addcmul(pm_ctx *ctx, float *d_y, float f, const float *d_a, const float *d_b, int64_t count, int accumulate);
+/* initialise_1LPT_center / _edge (mode 0 / 1: x = q - D psi, v = -(D fH) psi, initial_conditions.py:1688-1806) and
+ * add_nLPT (mode 2: x += D psi, v += (D fH) psi, :1809-1856) on a displacement field psi [n, n, n, 3]; ctx of size n */
+int pm_lpt_displace(pm_ctx *ctx, const float *d_psi, float dplus, float dfh, int mode, float *d_pos, float *d_vel);
 /* three planar arrays of m floats -> [m, 3] (the force grid's layout; the tail of fourier.ifft_3D_real_grad, :343) */
 int pm_interleave3(pm_ctx *ctx, const float *d_planar, int64_t m, float *d_out);
 int pm_pk(pm_ctx *ctx, int p, void *d_xk, const float *h_sinc, double *h_ksum, double *h_pksum,

@@ -890,3 +890,74 @@ def _mond_additional_field(additional_field, density, param, tables):  # solver.
     if solver == "fft_7pt":
         return fft(density, param)
     raise NotImplementedError(f"{param['linear_newton_solver']=}, should be 'multigrid' or 'fft_7pt'")
+
+
+# ------------------------------------------------------------------ initial conditions: nLPT (row f3)
+
+
+def _kvec(n):
+    k = _kfreq(n)
+    return k[:, None, None], k[None, :, None], np.arange(n // 2 + 1, dtype=np.float32)[None, None, :]
+
+
+def gradient(x) -> np.ndarray:  # fourier.py:730-781: i 2 pi k_m x -> [n, n, n/2+1, 3]
+    n = x.shape[0]
+    twopi = np.float32(2 * np.pi)
+    re, im = -(twopi * x.imag), twopi * x.real
+    out = np.empty(x.shape + (3,), dtype=np.complex64)
+    for m, km in enumerate(_kvec(n)):
+        out[..., m] = (re * km) + 1j * (im * km)
+    return out
+
+
+def hessian(x, ij) -> np.ndarray:  # fourier.py:784-839
+    kk = _kvec(x.shape[0])
+    c = (-kk[ij[0]] * kk[ij[1]]) * np.float32(4 * np.pi**2)
+    return ((c * x.real) + 1j * (c * x.imag)).astype(np.complex64)
+
+
+def sum_of_hessian(x, ij1, ij2) -> np.ndarray:  # fourier.py:842-904
+    kk = _kvec(x.shape[0])
+    c = -(kk[ij1[0]] * kk[ij1[1]] + kk[ij2[0]] * kk[ij2[1]]) * np.float32(4 * np.pi**2)
+    return ((c * x.real) + 1j * (c * x.imag)).astype(np.complex64)
+
+
+def compute_2ndorder_rhs(phi_1_k) -> np.ndarray:  # initial_conditions.py:976-1039 (no de-aliasing)
+    phi_2 = ifft_3D_real(hessian(phi_1_k, (0, 0)))
+    phi_2 = phi_2 * ifft_3D_real(sum_of_hessian(phi_1_k, (1, 1), (2, 2)))
+    phi_2 = phi_2 + np.float32(1) * ifft_3D_real(hessian(phi_1_k, (1, 1))) * ifft_3D_real(hessian(phi_1_k, (2, 2)))
+    for ij in ((0, 1), (0, 2), (1, 2)):
+        t = ifft_3D_real(hessian(phi_1_k, ij))
+        phi_2 = phi_2 + np.float32(-1) * t * t
+    return phi_2.astype(np.float32)
+
+
+def lpt_particles(density_k_half, order: str, position_ics: str, scalars):
+    """The grid part of initial_conditions.generate (initial_conditions.py:108-158, 1688-1856) from the Fourier-space
+    density: inverse Laplacian -> displacement -> particles; `scalars`: Hz [km/s/Mpc], d1_z0, d1, f1, d2, f2, unit_t."""
+    pc = 3.0856775814913674e16
+    n = density_k_half.shape[0]
+    Hz = scalars["Hz"] * scalars["unit_t"] / (1e3 * pc)
+    pot1 = np.ascontiguousarray(density_k_half.astype(np.complex64))
+    with np.errstate(all="ignore"):
+        inverse_laplacian(pot1)
+    psi = ifft_3D_real_grad(gradient(pot1))
+    dplus_1 = np.float32(scalars["d1"] / scalars["d1_z0"])
+    fH_1 = np.float32(scalars["f1"] * Hz)
+    h = np.float32(1.0 / n)
+    q = np.arange(n, dtype=np.float32) * h + (np.float32(0.5 / n) if position_ics.casefold() == "center" else np.float32(0))
+    lattice = np.stack(np.meshgrid(q, q, q, indexing="ij"), axis=-1)
+    position = (lattice + dplus_1 * (-psi)).astype(np.float32)
+    velocity = ((dplus_1 * fH_1) * (-psi)).astype(np.float32)
+    if order.casefold() == "2lpt":
+        rho2_k = fft_3D_real(compute_2ndorder_rhs(pot1))
+        with np.errstate(all="ignore"):
+            inverse_laplacian(rho2_k)
+        psi2 = ifft_3D_real_grad(gradient(rho2_k))
+        dplus_2 = np.float32(scalars["d2"] / scalars["d1_z0"] ** 2)
+        fH_2 = np.float32(scalars["f2"] * Hz)
+        position = (position + dplus_2 * psi2).astype(np.float32)
+        velocity = (velocity + (dplus_2 * fH_2) * psi2).astype(np.float32)
+    position, velocity = np.ascontiguousarray(position.reshape(-1, 3)), np.ascontiguousarray(velocity.reshape(-1, 3))
+    periodic_wrap(position)
+    return position, velocity

@@ -49,6 +49,10 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_greens": (_vp, _i, _i, _vp, _vp, _vp, _f),
     "pm_grad_inverse_laplacian": (_vp, _i, _vp, _vp, _vp, _vp),
     "pm_interleave3": (_vp, _vp, _i64, _vp),
+    "pm_kspace_gradient": (_vp, _vp, _vp, _vp),
+    "pm_kspace_hessian": (_vp, _vp, _vp, _vp, _i, _i, _i, _i),
+    "pm_addcmul": (_vp, _vp, _f, _vp, _vp, _i64, _i),
+    "pm_lpt_displace": (_vp, _vp, _f, _f, _i, _vp, _vp),
     "pm_pk": (_vp, _i, _vp, _vp, _vp, _vp, _vp),
     "pm_poisson_fft": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),
     "pm_poisson_fft_fused": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),

@@ -577,6 +577,123 @@ extern "C" int pm_grad_inverse_laplacian(pm_ctx *c, int p, const void *d_xk, voi
     return PM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k-space operators of the initial conditions (fourier.py:730-905): gradient i 2 pi k_m x (three planar half-spectra)
+// and -(k_a1 k_b1 + k_a2 k_b2) 4 pi^2 x (hessian: second pair off; sum_of_hessian: both), products in the
+// reference's order.
+
+__global__ __launch_bounds__(BLK) void kspace_gradient_kernel(const float2 *__restrict__ x, int n,
+                                                              const float *__restrict__ kf, float2 *__restrict__ out) {
+    const int nh = (n >> 1) + 1;
+    const int64_t total = (int64_t)n * n * nh;
+    const float twopi = (float)(2.0 * 3.14159265358979323846);
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t % nh);
+        const int64_t ij = t / nh;
+        const float kx = kf[(int)(ij / n)], ky = kf[(int)(ij % n)], kz = (float)k;
+        const float2 v = x[t];
+        const float re = -(twopi * v.y), im = twopi * v.x;  // (0 + i 2 pi)(a + i b)
+        out[t] = make_float2(re * kx, im * kx);
+        out[total + t] = make_float2(re * ky, im * ky);
+        out[2 * total + t] = make_float2(re * kz, im * kz);
+    }
+}
+
+__global__ __launch_bounds__(BLK) void kspace_hessian_kernel(const float2 *__restrict__ x, int n,
+                                                             const float *__restrict__ kf, int a1, int b1, int a2, int b2,
+                                                             float2 *__restrict__ out) {
+    const int nh = (n >> 1) + 1;
+    const int64_t total = (int64_t)n * n * nh;
+    const float fourpi2 = (float)(4.0 * 3.14159265358979323846 * 3.14159265358979323846);
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t % nh);
+        const int64_t ij = t / nh;
+        const float kk[3] = {kf[(int)(ij / n)], kf[(int)(ij % n)], (float)k};
+        float c;
+        if (a2 < 0)
+            c = (-kk[a1] * kk[b1]) * fourpi2;  // hessian: -kn * km * fourpi2
+        else
+            c = -(kk[a1] * kk[b1] + kk[a2] * kk[b2]) * fourpi2;  // sum_of_hessian
+        const float2 v = x[t];
+        out[t] = make_float2(c * v.x, c * v.y);
+    }
+}
+
+extern "C" int pm_kspace_gradient(pm_ctx *c, const void *d_xk, void *d_out3, const float *h_kfreq) {
+    PM_REQUIRE(c && d_xk && d_out3 && h_kfreq, "NULL argument");
+    const int n = c->n;
+    PM_HIP(hipMemcpyAsync(c->d_tab, h_kfreq, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const int64_t total = (int64_t)n * n * (n / 2 + 1);
+    hipLaunchKernelGGL(kspace_gradient_kernel, dim3(pm_stream_blocks(total, BLK * 2)), dim3(BLK), 0, c->stream,
+                       reinterpret_cast<const float2 *>(d_xk), n, c->d_tab, reinterpret_cast<float2 *>(d_out3));
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+extern "C" int pm_kspace_hessian(pm_ctx *c, const void *d_xk, void *d_out, const float *h_kfreq, int a1, int b1, int a2,
+                                 int b2) {
+    PM_REQUIRE(c && d_xk && d_out && h_kfreq, "NULL argument");
+    PM_REQUIRE(a1 >= 0 && a1 < 3 && b1 >= 0 && b1 < 3 && a2 < 3 && b2 < 3 && (a2 < 0) == (b2 < 0), "axes are 0, 1, 2 (second pair -1, -1: off)");
+    const int n = c->n;
+    PM_HIP(hipMemcpyAsync(c->d_tab, h_kfreq, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const int64_t total = (int64_t)n * n * (n / 2 + 1);
+    hipLaunchKernelGGL(kspace_hessian_kernel, dim3(pm_stream_blocks(total, BLK * 2)), dim3(BLK), 0, c->stream,
+                       reinterpret_cast<const float2 *>(d_xk), n, c->d_tab, a1, b1, a2, b2, reinterpret_cast<float2 *>(d_out));
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// y = (accumulate ? y : 0) + f * a * b (utils.prod_vector_vector_inplace :500, add_vector_vector_inplace :330)
+__global__ __launch_bounds__(BLK) void addcmul_kernel(float *__restrict__ y, float f, const float *__restrict__ a,
+                                                      const float *__restrict__ b, int64_t count, int accumulate) {
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < count; t += (int64_t)gridDim.x * BLK) {
+        const float p = f * a[t] * b[t];
+        y[t] = accumulate ? y[t] + p : p;
+    }
+}
+
+extern "C" int pm_addcmul(pm_ctx *c, float *d_y, float f, const float *d_a, const float *d_b, int64_t count, int accumulate) {
+    PM_REQUIRE(c && d_y && d_a && d_b && count >= 0, "bad argument");
+    if (count == 0) return PM_OK;
+    hipLaunchKernelGGL(addcmul_kernel, dim3(pm_stream_blocks(count, BLK)), dim3(BLK), 0, c->stream, d_y, f, d_a, d_b, count,
+                       accumulate);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// Particles from a displacement field psi [n, n, n, 3] (initial_conditions.py:1688-1856).  mode 0 / 1: first order
+// from cell centres / edges: x = q - D psi, v = -(D fH) psi; mode 2: add an n-th order term: x += D psi, v += (D fH) psi.
+__global__ __launch_bounds__(BLK) void lpt_displace_kernel(const float *__restrict__ psi, int n, float dplus, float dfh,
+                                                           int mode, float *__restrict__ pos, float *__restrict__ vel) {
+    const int64_t total = (int64_t)n * n * n;
+    const float h = 1.0f / (float)n, half_h = 0.5f / (float)n;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t % n), j = (int)((t / n) % n), i = (int)(t / ((int64_t)n * n));
+        const int q[3] = {i, j, k};
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const float p = psi[3 * t + m];
+            if (mode == 2) {
+                pos[3 * t + m] += dplus * p;
+                vel[3 * t + m] += dfh * p;
+            } else {
+                const float x0 = mode == 0 ? half_h + (float)q[m] * h : (float)q[m] * h;
+                pos[3 * t + m] = x0 + dplus * (-p);
+                vel[3 * t + m] = dfh * (-p);
+            }
+        }
+    }
+}
+
+extern "C" int pm_lpt_displace(pm_ctx *c, const float *d_psi, float dplus, float dfh, int mode, float *d_pos, float *d_vel) {
+    PM_REQUIRE(c && d_psi && d_pos && d_vel && mode >= 0 && mode <= 2, "bad argument");
+    const int64_t total = (int64_t)c->n * c->n * c->n;
+    hipLaunchKernelGGL(lpt_displace_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_psi, c->n, dplus, dfh,
+                       mode, d_pos, d_vel);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
 // three planar arrays of m elements -> one [m, 3] array (the force grid's layout)
 __global__ __launch_bounds__(BLK) void interleave3_kernel(const float *__restrict__ a, int64_t m, float *__restrict__ out) {
     for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < m; t += (int64_t)gridDim.x * BLK) {

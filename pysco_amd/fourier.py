@@ -133,6 +133,35 @@ def ifft_3D_real_grad(x, threads: int = 1):
     return L.like_input(_ifft_grad_planar(xk.permute(3, 0, 1, 2).contiguous()), x)
 
 
+def gradient(x):
+    """i 2 pi k x as [n, n, n/2+1, 3] complex64 (fourier.py:730)."""
+    torch = L.require_gpu()
+    xk = L.to_device(x, torch.complex64)
+    n = xk.shape[0]
+    out = torch.empty((3, n, n, n // 2 + 1), dtype=torch.complex64, device=xk.device)
+    L.context(n).call("pm_kspace_gradient", L.ptr(xk), L.ptr(out), L.hptr(_kfreq(n)))
+    return L.like_input(out.permute(1, 2, 3, 0).contiguous(), x)
+
+
+def _hessian(x, a1, b1, a2, b2):
+    torch = L.require_gpu()
+    xk = L.to_device(x, torch.complex64)
+    n = xk.shape[0]
+    out = torch.empty_like(xk)
+    L.context(n).call("pm_kspace_hessian", L.ptr(xk), L.ptr(out), L.hptr(_kfreq(n)), a1, b1, a2, b2)
+    return L.like_input(out, x)
+
+
+def hessian(x, ij):
+    """-k_i k_j 4 pi^2 x (fourier.py:784)."""
+    return _hessian(x, int(ij[0]), int(ij[1]), -1, -1)
+
+
+def sum_of_hessian(x, ij1, ij2):
+    """-(k_i1 k_j1 + k_i2 k_j2) 4 pi^2 x (fourier.py:842)."""
+    return _hessian(x, int(ij1[0]), int(ij1[1]), int(ij2[0]), int(ij2[1]))
+
+
 def fourier_grid_to_Pk(density_k, p: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """(k, P(k), Nmodes) in grid units; also zeroes density_k[0,0,0] like the reference."""
     torch = L.require_gpu()

@@ -1,8 +1,9 @@
 """Initial conditions: drop-in for the reference's initial_conditions.generate() (initial_conditions.py:25-213).
 
-Row f2 of SURVEY.md section 8: restart from a snapshot this library (or PySCo) wrote -- `initial_conditions` an
-integer -- in either format, with the snapshot's parameters taking over the run's (initial_conditions.py:79-107).
-Row f3 (Lagrangian perturbation theory from a power spectrum) is served by pysco_amd.lpt when present.
+Rows f2 / f3 of SURVEY.md section 8: restart from a snapshot this library (or PySCo) wrote -- `initial_conditions` an
+integer -- in either format, with the snapshot's parameters taking over the run's (initial_conditions.py:79-107); and
+first / second order Lagrangian perturbation theory from a power spectrum table (`1LPT`, `2LPT`: pysco_amd/lpt.py,
+grid operations on the GPU).  3LPT, RayGal and Gadget inputs are not built.
 """
 from __future__ import annotations
 
@@ -35,10 +36,7 @@ def generate(param, tables):
             raise ValueError(f"{param['output_snapshot_format']=}, should be 'parquet' or 'hdf5'")
         return position, velocity
     if isinstance(ic, str) and "lpt" in ic.casefold():
-        try:
-            from . import lpt
-        except ImportError as exc:  # pragma: no cover
-            raise NotImplementedError("LPT initial conditions (SURVEY.md section 8 row f3) are not built yet; start "
-                                      "from a snapshot (initial_conditions = <snapshot number>)") from exc
+        from . import lpt
+
         return lpt.generate(param, tables)
     raise NotImplementedError(f"{param['initial_conditions']=}: this library starts from a snapshot number or nLPT")

@@ -1,0 +1,184 @@
+"""Initial conditions from a power spectrum with first / second order Lagrangian perturbation theory: the nLPT branch of
+the reference's initial_conditions.generate (initial_conditions.py:108-158; row f3 of SURVEY.md section 8).
+
+Pipeline (initial_conditions.py:402-445, 531-728, 976-1039, 1635-1856): Gaussian white noise in Fourier space drawn
+with NumPy's generator exactly as the reference draws it (same seed -> same field), times sqrt(P(k)) interpolated on
+the grid -> inverse Laplacian -> displacement = gradient -> particles displaced from the lattice; second order from
+the Hessian products of the first-order potential.  The random numbers and the transfer table are host work (a few
+NumPy calls); every grid operation -- Green's function, k-space gradient / Hessians, FFTs, products, the particle
+displacement -- is a HIP kernel behind the C ABI (include/pmstep.h).  3LPT and de-aliasing are not built.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from . import _lib as L
+from . import fourier, iostream, utils
+
+_PC = 3.0856775814913674e16  # astropy.constants.pc (initial_conditions.py:118)
+
+
+# ---- host side: random field and transfer table (same draws and rounding as the reference) -------------------
+
+
+def _hermitian_fill(upper: np.ndarray, corners) -> np.ndarray:
+    """The reference's loop (initial_conditions.py:626-640) as array operations: for i <= n/2 and all (j, k),
+    D[i, j, k] = upper[i, j, k] and D[-i, -j, -k] = conj(upper[i, j, k]); on the two self-conjugate planes (i = 0,
+    n/2) the loop writes every cell twice and the later write (row-major iteration order) stays.  Returns the half
+    spectrum D[:, :, :n/2+1], the only part the pipeline reads."""
+    m1, n = upper.shape[0], upper.shape[1]
+    m = m1 - 1
+    D = np.empty((n, n, n), dtype=np.complex64)
+    D[:m1] = upper
+    idx = (-np.arange(n)) % n
+    if m > 1:
+        D[n - np.arange(1, m)] = np.conj(upper[1:m][:, idx][:, :, idx])
+    order = np.arange(n)[:, None] * n + np.arange(n)[None, :]
+    order_partner = order[idx][:, idx]  # iteration number of the (j, k) whose conjugate write lands here
+    for p in (0, m):
+        partner = np.conj(upper[p][idx][:, idx])
+        D[p] = np.where(order > order_partner, upper[p], partner)
+    for (a, b, c), v in corners:
+        D[a, b, c] = v
+    return np.ascontiguousarray(D[:, :, :m1])
+
+
+def white_noise_fourier(ncells_1d: int, rng) -> np.ndarray:
+    """Rayleigh amplitudes, uniform phases (initial_conditions.py:585-660): half spectrum [n, n, n/2+1] complex64."""
+    n, m = ncells_1d, ncells_1d // 2
+    ra = rng.random((m + 1, n, n), dtype=np.float32)
+    rp = rng.random((m + 1, n, n), dtype=np.float32)
+    amplitude = np.sqrt(-np.log((np.float32(1) - ra).astype(np.float64)))
+    phase = (np.float32(2 * np.pi) * rp).astype(np.float64)
+    upper = (amplitude * np.cos(phase) + 1j * (amplitude * np.sin(phase))).astype(np.complex64)
+    pts = [(0, 0, m), (0, m, 0), (0, m, m), (m, 0, 0), (m, 0, m), (m, m, 0), (m, m, m)]
+    corners = [((0, 0, 0), 0)] + [(p, np.sqrt(-np.log(float(np.float32(1) - rng.random(dtype=np.float32))))) for p in pts]
+    return _hermitian_fill(upper, corners)
+
+
+def white_noise_fourier_fixed(ncells_1d: int, rng, is_paired: bool) -> np.ndarray:
+    """Unit amplitudes, uniform phases (+ pi when paired) (initial_conditions.py:664-728)."""
+    n, m = ncells_1d, ncells_1d // 2
+    rp = rng.random((m + 1, n, n), dtype=np.float32)
+    shift = np.float32(np.pi) if is_paired else np.float32(0)
+    phase = (np.float32(2 * np.pi) * rp + shift).astype(np.float64)
+    upper = (np.cos(phase) + 1j * np.sin(phase)).astype(np.complex64)
+    pts = [(0, 0, m), (0, m, 0), (0, m, m), (m, 0, 0), (m, 0, m), (m, m, 0), (m, m, m)]
+    return _hermitian_fill(upper, [((0, 0, 0), 0)] + [(p, 1.0) for p in pts])
+
+
+def get_transfer_grid(param) -> np.ndarray:
+    """sqrt(P(k)) on the half grid [n, n, n/2+1], float64 (initial_conditions.py:531-581)."""
+    k, Pk = np.loadtxt(param["power_spectrum_file"]).T
+    n = int(round(param["npart"] ** (1.0 / 3.0)))
+    if n**3 != param["npart"]:
+        raise ValueError(f"{param['npart']=}, should be a cube")
+    kf = 2 * np.pi / param["boxlen"]
+    sqrtPk = (np.sqrt(Pk / param["boxlen"] ** 3) * n**3).astype(np.float32)
+    k1 = np.fft.fftfreq(n, 1 / n)
+    kz = k1[: n // 2 + 1].copy()
+    kz[-1] = abs(kz[-1])  # (fftfreq gives -n/2 there; only its square is used)
+    k_grid = np.sqrt(kz[None, None, :] ** 2 + k1[:, None, None] ** 2 + k1[None, :, None] ** 2)
+    return np.interp(k_grid, k / kf, sqrtPk)
+
+
+def generate_density_fourier(param) -> np.ndarray:
+    """White noise times the transfer function: half spectrum complex64 (initial_conditions.py:402-445)."""
+    n = int(round(param["npart"] ** (1.0 / 3.0)))
+    rng = np.random.default_rng() if param["seed"] < 0 else np.random.default_rng(param["seed"])
+    if param["fixed_ICS"]:
+        density_k = white_noise_fourier_fixed(n, rng, param["paired_ICS"])
+    else:
+        density_k = white_noise_fourier(n, rng)
+    return (density_k.astype(np.complex128) * get_transfer_grid(param)).astype(np.complex64)
+
+
+# ---- device side ------------------------------------------------------------------------------------------
+
+
+def _displacement(potential_k):
+    """psi = ifft(i 2 pi k phi) as [n, n, n, 3] (fourier.gradient + ifft_3D_real_grad)."""
+    torch = L.require_gpu()
+    n = potential_k.shape[0]
+    planar = torch.empty((3, n, n, n // 2 + 1), dtype=torch.complex64, device=potential_k.device)
+    L.context(n).call("pm_kspace_gradient", L.ptr(potential_k), L.ptr(planar), L.hptr(fourier._kfreq(n)))
+    return fourier._ifft_grad_planar(planar)
+
+
+def _hessian_real(potential_k, ij, ij2=(-1, -1)):
+    torch = L.require_gpu()
+    n = potential_k.shape[0]
+    ctx = L.context(n)
+    tmp = torch.empty_like(potential_k)
+    ctx.call("pm_kspace_hessian", L.ptr(potential_k), L.ptr(tmp), L.hptr(fourier._kfreq(n)), ij[0], ij[1], ij2[0], ij2[1])
+    out = torch.empty((n, n, n), dtype=torch.float32, device=potential_k.device)
+    ctx.call("pm_fft_c2r", L.ptr(tmp), L.ptr(out))
+    return out
+
+
+def compute_2ndorder_rhs(potential_1_k, param):
+    """phi,xx (phi,yy + phi,zz) + phi,yy phi,zz - phi,xy^2 - phi,xz^2 - phi,yz^2 (initial_conditions.py:976-1039)."""
+    if param.get("dealiased_ICS", False):
+        raise NotImplementedError("dealiased_ICS (Orszag 3/2 padding) is not built")
+    n = potential_1_k.shape[0]
+    ctx = L.context(n)
+    cells = n**3
+    phi_2 = _hessian_real(potential_1_k, (0, 0))
+    tmp = _hessian_real(potential_1_k, (1, 1), (2, 2))
+    ctx.call("pm_addcmul", L.ptr(phi_2), 1.0, L.ptr(phi_2), L.ptr(tmp), cells, 0)
+    t1, t2 = _hessian_real(potential_1_k, (1, 1)), _hessian_real(potential_1_k, (2, 2))
+    ctx.call("pm_addcmul", L.ptr(phi_2), 1.0, L.ptr(t1), L.ptr(t2), cells, 1)
+    del t1, t2
+    for ij in ((0, 1), (0, 2), (1, 2)):
+        tmp = _hessian_real(potential_1_k, ij)
+        ctx.call("pm_addcmul", L.ptr(phi_2), -1.0, L.ptr(tmp), L.ptr(tmp), cells, 1)
+    return phi_2
+
+
+def generate(param, tables):
+    """(position, velocity) [Np, 3] float32 device tensors from 1LPT or 2LPT (initial_conditions.py:108-158), wrapped
+    into the box and written as snapshot 0 like finalise_initial_conditions (:216-279)."""
+    torch = L.require_gpu()
+    order = param["initial_conditions"].casefold()
+    if order not in ("1lpt", "2lpt"):
+        raise NotImplementedError(f"{param['initial_conditions']=}: 1LPT and 2LPT are built (3LPT is not)")
+    lna_start = np.log(1.0 / (1 + param["z_start"]))
+    logging.warning(f"{param['z_start']=}")
+    Hz = float(tables[2](lna_start)) * param["unit_t"] / (1e3 * _PC)  # km/s/Mpc -> box units
+    density_k = torch.from_numpy(generate_density_fourier(param)).cuda()
+    n = density_k.shape[0]
+    ctx = L.context(n)
+    fourier.inverse_laplacian(density_k)
+    potential_1_k = density_k
+    psi = _displacement(potential_1_k)
+    logging.warning("Compute 1LPT contribution")
+    d1_z0 = float(tables[3](0))
+    dplus_1 = np.float32(float(tables[3](lna_start)) / d1_z0)
+    fH_1 = np.float32(float(tables[4](lna_start)) * Hz)
+    position, velocity = torch.empty_like(psi), torch.empty_like(psi)
+    POSITION = param["position_ICS"].casefold()
+    if POSITION not in ("center", "edge"):
+        raise NotImplementedError(f"{POSITION=}, should be 'center' or 'edge'")
+    ctx.call("pm_lpt_displace", L.ptr(psi), float(dplus_1), float(dplus_1 * fH_1), 0 if POSITION == "center" else 1,
+             L.ptr(position), L.ptr(velocity))
+    del psi
+    if order == "2lpt":
+        logging.warning("Compute 2LPT contribution")
+        density_2 = compute_2ndorder_rhs(potential_1_k, param)
+        density_2_k = fourier.fft_3D_real(density_2)
+        del density_2
+        fourier.inverse_laplacian(density_2_k)
+        psi_2 = _displacement(density_2_k)
+        dplus_2 = np.float32(float(tables[5](lna_start)) / d1_z0**2)
+        fH_2 = np.float32(float(tables[6](lna_start)) * Hz)
+        ctx.call("pm_lpt_displace", L.ptr(psi_2), float(dplus_2), float(dplus_2 * fH_2), 2, L.ptr(position), L.ptr(velocity))
+        del psi_2
+    position, velocity = position.view(-1, 3), velocity.view(-1, 3)
+    utils.periodic_wrap(position)
+    if "base" in param:  # finalise_initial_conditions: the initial snapshot
+        snap = dict(param.items()) if not isinstance(param, dict) else dict(param)
+        snap["i_snap"] = 0
+        iostream.write_snapshot_particles(position, velocity, snap)
+    return position, velocity
