@@ -1183,7 +1183,10 @@ __global__ __launch_bounds__(BLK) void deposit_ranges_kernel(const float *__rest
 // second, small kernel deposits tile by tile after a sort by tile key.  The lists are left prepared
 // (pm_tile_lists semantics) for the gather of the same step.
 
-constexpr int PM_SCAP = 1024;  // stragglers staged in LDS per workgroup before the global append
+// stragglers staged in LDS per workgroup before the global append (beyond it: one global atomic per straggler).  256
+// (was 1024): with the stream re-bucketed every step a workgroup has a handful, and the 6 KB let a fifth workgroup
+// onto the CU (28 KB instead of 34: 15.15 -> 14.4 ms for the kernel at 1024^3)
+constexpr int PM_SCAP = 256;
 // Halo buffer of the fused kick + drift + deposit (pmstep.h: pm_kick_drift_wrap_deposit_khalo), three parts:
 //   K  [tile column (ti, tj)][li 0..9][low | high][tk][lj 0..17]   the k-halo cells (lk = 0, 17) of every tile
 //   Hi [tile column (ti, tj)][low | high][lj 0..17][k 0..n)         the i-halo planes (li = 0, 9), lk = 1..16
