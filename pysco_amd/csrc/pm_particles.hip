@@ -1422,9 +1422,6 @@ __global__ __launch_bounds__(BLK) void deposit_list_kernel(const float *__restri
     const TileId t = tile_of_key(key);
     for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0;
     __syncthreads();
-#if defined(PM_EXP_LISTFLUSH) && PM_EXP_LISTFLUSH == 4
-    if (false)
-#endif
     for (unsigned l = ls + tid; l < le; l += BLK) {
         const int64_t p = lists.idx[l];
         const float x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
@@ -1436,19 +1433,7 @@ __global__ __launch_bounds__(BLK) void deposit_list_kernel(const float *__restri
             deposit_global<SCHEME>(x, y, z, geo, rho);
     }
     __syncthreads();
-#ifdef PM_EXP_LISTFLUSH  /* development: 0 = atomics on rho, 1 = atomics on the tile's own addresses, 2 = read-modify-write */
-    if (PM_EXP_LISTFLUSH == 3) return;  // no flush at all (timing experiment)
-    if (PM_EXP_LISTFLUSH == 0) {
-        for (int c = tid; c < PM_TILE; c += BLK) {
-            const pm_acc_t w = tile[c];
-            if (w != 0) unsafeAtomicAdd(rho + tile_cell_global(c, t, geo), weight_of_acc(w));
-        }
-        return;
-    }
-    if (halo.k && PM_EXP_LISTFLUSH == 1) {
-#else
     if (halo.k && le - ls < 128) {
-#endif
         // a short list (the usual case once the stream is re-bucketed every step: ~10 particles per tile) touches a
         // few hundred cells: fire-and-forget atomics on the tile's own addresses, no load to wait for (the
         // read-modify-write form below cost 2.6 ms at 0.5 % stragglers, the atomics 0.4 ms)
