@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--rms-cells", type=float, default=0.5)
     ap.add_argument("--cpu-ncells", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-placement", action="store_true", help="skip pysco_amd.main.tune_placement (development)")
     ap.add_argument("--rebucket-fraction", type=float, default=None,
                     help="param['rebucket_straggler_fraction'] of the timed loop (default: pysco_amd.main's; "
                          "negative: off, i.e. the reference's in-place step + a full sort every n_reorder steps)")
@@ -299,7 +300,11 @@ def main():
     acc, phi, extra = solver.pm(pos, param, tables=tables)
     t_far = np.float32(3.0e38)  # no snapshot inside the run: every step takes its own dt
     if "rebucket_straggler_fraction" in param:
-        pm_main.reserve_step_buffers(pos)  # the second set of particle arrays (0.8 s of hipMalloc per 12.9 GB)
+        # the product loop's set-up (pysco_amd.main.run_nbody): particle arrays and the gather's output set in the
+        # best-placed allocations it can find, no allocation inside the step loop
+        if npart >= 2**24 and not args.no_placement:
+            pos, vel, acc = pm_main.tune_placement(pos, vel, acc)
+        pm_main.reserve_step_buffers(pos)
 
     def step(pos, vel, acc, phi, extra):
         param["nsteps"] += 1

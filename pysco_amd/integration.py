@@ -99,6 +99,7 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
     """Kick-drift-kick (integration.py:192-264).  On device tensors the first kick, the drift and
     the periodic wrap are one fused pass over the particle arrays."""
     half_dt = np.float32(0.5 * dt)
+    acceleration_in = acceleration
     fused = L.is_device_array(position) and L.is_device_array(velocity) and L.is_device_array(acceleration)
     density = None
     if fused:
@@ -154,7 +155,11 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
                                                               _kick=(velocity, half_dt), _density=density,
                                                               _rebucket=rebucket)
         if rebucket is not None and "position" in rebucket:
-            # the gather wrote the arrays out of place, tile after tile (pmstep.h: pm_gradient_interp_kick_rebucket)
+            # the gather wrote the arrays out of place, tile after tile (pmstep.h: pm_gradient_interp_kick_rebucket);
+            # the arrays it read are stale from here on: they become the next step's output arrays
+            from . import mesh
+
+            mesh.pool_give(position, velocity, acceleration_in)
             position, velocity = rebucket["position"], rebucket["velocity"]
             if rebucket["ids"] is not None:
                 param["particle_id"] = rebucket["ids"]

@@ -27,13 +27,78 @@ REORDER_FRACTION = 0.10    # default of param["reorder_straggler_fraction"]
 
 
 def reserve_step_buffers(position) -> None:
-    """The re-bucketing gather writes position, velocity and acceleration into a second set of arrays.  Allocating
-    them once up front (they go back to torch's caching allocator at once and are handed out again by the steps)
-    keeps the device allocations -- 0.8 s per 12.9 GB array at 1024^3 -- out of the step loop."""
+    """The re-bucketing gather writes position, velocity and acceleration into a second set of arrays, which then
+    trade places with the first every step (pysco_amd.mesh._rebucket_pool).  Allocating the second set up front keeps
+    the device allocations -- 0.8 s per 12.9 GB array at 1024^3 -- out of the step loop."""
     if L.is_device_array(position):
+        from . import mesh
+
         torch = L.require_gpu()
-        spare = [torch.empty_like(position) for _ in range(3)]
-        del spare
+        while sum(1 for t in mesh._rebucket_pool if t.shape == position.shape and t.device == position.device) < 3:
+            mesh._rebucket_pool.append(torch.empty_like(position))
+
+
+def tune_placement(position, velocity, acceleration=None, max_candidates: int = 15):
+    """Measured on MI355X: the bandwidth of an in-place read-modify-write pass over a 12.9 GB array depends on the
+    physical memory the allocation landed in -- 5.08 TB/s for some allocations, 4.5 TB/s for others made by the same
+    call a moment earlier (tools/bench_array_single.py) -- and the fused kick + drift + deposit, which updates
+    position and velocity in place, runs 14 or 16-17 ms at 1024^3 accordingly.  Nothing in the virtual layout controls
+    it, so this allocates candidate arrays (as many as fit comfortably), times a multiply-by-one pass over each and
+    over the caller's arrays, moves the particle data into the fastest three and keeps the next three as the gather's
+    output set; the rest is freed.  One-time cost: about 6 ms per candidate at 1024^3.  Returns the (possibly new)
+    position, velocity[, acceleration] tensors; values and order unchanged."""
+    if not L.is_device_array(position):
+        return (position, velocity) if acceleration is None else (position, velocity, acceleration)
+    from . import mesh
+
+    torch = L.require_gpu()
+    ctx = L.context(4)
+    live = [position, velocity] + ([acceleration] if acceleration is not None else [])
+    need = 6
+    free_bytes, _ = torch.cuda.mem_get_info(position.device)
+    each = position.numel() * 4
+    # (the candidates that are not kept are freed again before anything else is allocated: they may use what is free now)
+    n_cand = int(max(0, min(max_candidates, free_bytes // each - 2)))
+    mesh._rebucket_pool.clear()
+    cand = []
+    try:
+        for _ in range(n_cand):
+            cand.append(torch.empty_like(position))
+    except torch.OutOfMemoryError:
+        pass
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def probe(t):  # x *= 1 leaves every bit pattern as it is
+        best = 1e30
+        for _ in range(2):
+            e0.record()
+            ctx.call("pm_scale", L.ptr(t), 1.0, t.numel())
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
+
+    for t in cand:
+        t.zero_()
+    timed = sorted([(probe(t), i, t, i < len(live)) for i, t in enumerate(live + cand)], key=lambda r: r[0])
+    logging.info("placement probe [ms]: " + " ".join(f"{ms:.2f}{'*' if is_live else ''}" for ms, _, _, is_live in timed))
+    fast = [t for _, _, t, _ in timed[:len(live)]]
+    spare = [t for _, _, t, _ in timed[len(live):need]]
+    # particle data into the fastest arrays: those already there stay, the others move into the free fast ones
+    homes = [t for t in fast if all(t.data_ptr() != x.data_ptr() for x in live)]
+    out = []
+    for x in live:
+        if any(x.data_ptr() == t.data_ptr() for t in fast):
+            out.append(x)
+        else:
+            h = homes.pop(0)
+            h.copy_(x)
+            out.append(h)
+            spare.append(x)  # (a slow array is still better than an allocation inside the loop)
+    mesh._rebucket_pool.extend(spare[:3])
+    del cand, timed, fast, spare
+    torch.cuda.empty_cache()
+    return tuple(out)
 
 
 def reorder_policy(position, velocity, acceleration, param):
@@ -83,6 +148,9 @@ def run_nbody(position, velocity, param, tables: List, z_out: Sequence[float],
         frac, complete = utils.straggler_fraction(2 ** int(param["ncoarse"]))
         if not complete or (frac is not None and frac > float(param.get("reorder_straggler_fraction", REORDER_FRACTION))):
             position, velocity, acceleration = _reorder(position, velocity, acceleration, param)
+        if param.get("rebucket_straggler_fraction") is not None and position.shape[0] >= 2**24:
+            # (worth its 0.1 s only for large runs: see tune_placement)
+            position, velocity, acceleration = tune_placement(position, velocity, acceleration)
     aexp_out = 1.0 / (np.array(z_out, dtype=np.float64) + 1)
     aexp_out.sort()
     t_out = tables[1](np.log(aexp_out))

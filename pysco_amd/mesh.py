@@ -201,6 +201,27 @@ def add_prolongation(y, x) -> None:
         y[...] = yd.cpu().numpy()
 
 
+# The second set of particle arrays of the re-bucketing gather: exactly six [Np, 3] arrays circulate (three hold the
+# particles, three are written by the next gather), no device allocation inside the step loop.  main.tune_placement
+# fills the pool with arrays whose placement it has measured; without it the arrays come from torch's allocator.
+_rebucket_pool = []
+
+
+def _pool_take(like):
+    for i, t in enumerate(_rebucket_pool):
+        if t.shape == like.shape and t.dtype == like.dtype and t.device == like.device:
+            return _rebucket_pool.pop(i)
+    return L.require_gpu().empty_like(like)
+
+
+def pool_give(*tensors) -> None:
+    """Hand arrays the caller no longer reads (the inputs of a re-bucketing step) back for the next step's outputs."""
+    for t in tensors:
+        if t is not None and L.is_device_array(t) and t.is_contiguous() and len(_rebucket_pool) < 6:
+            if all(t.data_ptr() != u.data_ptr() for u in _rebucket_pool):
+                _rebucket_pool.append(t)
+
+
 def derivative_interp_vec_kick_rebucket(scheme_name: str, potential, order: int, position, velocity, half_dt, ids=None):
     """derivative_interp_vec_kick with the kick, writing the particle arrays out of place in tile order
     (pmstep.h: pm_gradient_interp_kick_rebucket): returns (acceleration, position, velocity, ids) as NEW
@@ -215,7 +236,7 @@ def derivative_interp_vec_kick_rebucket(scheme_name: str, potential, order: int,
     if order not in (0, 2, 3, 5, 7):  # 0: `potential` is the force grid [n, n, n, 3] (interp_vec_kick's input)
         raise ValueError(f"{order=}, should be 2, 3, 5 or 7")
     ctx = L.context(n)
-    acc, pos_out, vel_out = torch.empty_like(position), torch.empty_like(position), torch.empty_like(velocity)
+    acc, pos_out, vel_out = _pool_take(position), _pool_take(position), _pool_take(velocity)
     ids_out = None if ids is None else torch.empty_like(ids)
     if ids is not None and (ids.dtype != torch.int32 or not ids.is_contiguous() or ids.shape[0] != position.shape[0]):
         raise ValueError("ids must be a contiguous int32 tensor with one entry per particle")
