@@ -257,6 +257,11 @@ int pm_lap_restrict_residual(pm_ctx *ctx, const float *d_x, const float *d_b, in
 int pm_lap_residual_error(pm_ctx *ctx, const float *d_x, const float *d_b, int n, float *h_out);
 /* sqrt(sum (f*a - b)^2): tail of laplacian.truncation_error :529 (f = 1) and cubic.truncation_error :1057 (f = 4) */
 int pm_diff_norm(pm_ctx *ctx, const float *d_a, const float *d_b, float f, int64_t count, float *h_out);
+/* multigrid.V_cycle_FAS (multigrid.py:521-579) for the f(R) scalaron on x in place, the whole recursion issued from C
+ * (fr_n = 1: cubic.py operators, 2: quartic.py): smoothing, restricted residual, restricted solution / density term,
+ * coarse right-hand side 4 res + L(x_c), coarse cycle, x += prolongation(x_corr - x_c), smoothing.  Same kernels,
+ * same bits as the per-operator entry points called in that order.  n >= 8. */
+int pm_fr_vcycle(pm_ctx *ctx, int fr_n, float *d_x, const float *d_b, float q, int n, int npre, int npost);
 /* laplacian.smoothing (laplacian.py:1026): n_smoothing red-black sweeps with omega = 1.25 on x in place.  For
  * n >= 256 each sweep is ONE pass over the grid (red and black updated by a workgroup marching through LDS planes,
  * out of place into a scratch grid of the context, copied back after an odd count): x and b read once, x written once

@@ -1145,6 +1145,59 @@ extern "C" int pm_quartic_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// One whole Full-Approximation-Scheme V-cycle for the f(R) scalaron (multigrid.py:521-579) issued from C, like
+// pm_lap_vcycle: per level -- Npre smoothing sweeps, restricted residual (rhs-less at the top: minus_restriction of the
+// operator; below: restriction of rhs - operator), restricted solution and density term, coarse right-hand side
+// 4 res + L(x_c), coarse cycle (only smoothed below 8^3 cells), x += prolongation(x_corr - x_c), Npost sweeps.  Every
+// operation is the kernel the per-operator entry points launch (same bits); ~45 Python -> C calls per level otherwise.
+
+template <int FRN>
+static int fr_vcycle_level(pm_ctx *c, float *x, const float *b, float q, const float *rhs, int n, int npre, int npost,
+                           float *scratch) {
+    const float f_relax = 1.25f;  // cubic.py:1092 / quartic.py
+    int rc;
+    for (int s = 0; s < npre; ++s)
+        if ((rc = fr_gauss_seidel<FRN>(c, x, b, q, rhs, n, f_relax, xr_cube(n), 0, 3))) return rc;
+    const int nc = n / 2;
+    const int64_t cells = (int64_t)n * n * n, ccells = (int64_t)nc * nc * nc;
+    // scratch of this level: one fine grid (operator / residual), five coarse ones
+    float *fine = scratch, *res_c = fine + cells, *x_c = res_c + ccells, *x_corr_c = x_c + ccells, *b_c = x_corr_c + ccells,
+          *L_c = b_c + ccells, *next = L_c + ccells;
+    // multigrid.restrict_residual (:282): no rhs -> minus_restriction(operator); rhs -> restriction(rhs - operator)
+    if ((rc = fr_operator<FRN>(c, x, b, q, rhs, n, fine, xr_cube(n)))) return rc;
+    if ((rc = pm_restriction(c, fine, n, rhs ? 0.125f : -0.125f, res_c))) return rc;
+    if ((rc = pm_restriction(c, x, n, 0.125f, x_c))) return rc;
+    PM_HIP(hipMemcpyAsync(x_corr_c, x_c, (size_t)ccells * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = pm_restriction(c, b, n, 0.125f, b_c))) return rc;
+    if ((rc = fr_operator<FRN>(c, x_c, b_c, q, nullptr, nc, L_c, xr_cube(nc)))) return rc;
+    // res_c = 4 res_c + L_c  (utils.linear_operator_vectors_inplace with multigrid.normalisation_residual = 4)
+    if ((rc = pm_linear_operator_vectors(c, res_c, 4.0f, L_c, 1.0f, ccells))) return rc;
+    if (n <= 8) {
+        for (int s = 0; s < npre; ++s)
+            if ((rc = fr_gauss_seidel<FRN>(c, x_corr_c, b_c, q, res_c, nc, f_relax, xr_cube(nc), 0, 3))) return rc;
+    } else if ((rc = fr_vcycle_level<FRN>(c, x_corr_c, b_c, q, res_c, nc, npre, npost, next))) {
+        return rc;
+    }
+    if ((rc = pm_axpy(c, x_corr_c, x_c, -1.0f, ccells))) return rc;
+    if ((rc = pm_prolongation(c, x, x_corr_c, nc, 1))) return rc;
+    for (int s = 0; s < npost; ++s)
+        if ((rc = fr_gauss_seidel<FRN>(c, x, b, q, rhs, n, f_relax, xr_cube(n), 0, 3))) return rc;
+    return PM_OK;
+}
+
+extern "C" int pm_fr_vcycle(pm_ctx *c, int fr_n, float *d_x, const float *d_b, float q, int n, int npre, int npost) {
+    PM_REQUIRE(c && d_x && d_b && npre >= 0 && npost >= 0 && (fr_n == 1 || fr_n == 2), "bad argument");
+    PM_CHECK_GRID(n);
+    PM_REQUIRE(n >= 8, "pm_fr_vcycle needs n >= 8 (ncoarse >= 3)");
+    // per level n^3 + 5 (n/2)^3 floats: (1 + 5/8) (1 + 1/8 + ...) n^3 < 13 n^3 / 7
+    float *scratch = nullptr;
+    int rc = mg_arena(c, ((size_t)n * n * n * 13 / 7 + 4096) * sizeof(float), &scratch);
+    if (rc) return rc;
+    return fr_n == 1 ? fr_vcycle_level<1>(c, d_x, d_b, q, nullptr, n, npre, npost, scratch)
+                     : fr_vcycle_level<2>(c, d_x, d_b, q, nullptr, n, npre, npost, scratch);
+}
+
+// ------------------------------------------------------------------------------------------------
 // QUMOND (mond.py)
 
 // mond.py:16-162; kind: 0 simple, 1 n, 2 beta, 3 gamma, 4 delta

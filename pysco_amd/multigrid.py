@@ -145,6 +145,14 @@ def FAS(x, b, param):
 
 def V_cycle_FAS(x, b, param, nlevel: int = 0, rhs=None) -> None:
     """One FAS V-cycle, in place on x (multigrid.py:521)."""
+    n = x.shape[0]
+    if (_NATIVE_VCYCLE and nlevel == 0 and (rhs is None or len(rhs) == 0) and _is_fr_field(param)
+            and param["fR_n"] in (1, 2) and n >= 8 and (n & (n - 1)) == 0 and param["ncoarse"] == int(np.log2(n))
+            and L.is_device_array(x) and L.is_device_array(b)):
+        # the same sequence of kernels issued from C in one call (pmstep.h: pm_fr_vcycle)
+        L.context(4).call("pm_fr_vcycle", int(param["fR_n"]), L.ptr(x), L.ptr(b), float(np.float32(param["fR_q"])), n,
+                          int(param["Npre"]), int(param["Npost"]))
+        return
     smoothing(x, b, param["Npre"], param, rhs)
     res_c = restrict_residual(x, b, param, rhs)
     x_c = mesh.restriction(x)

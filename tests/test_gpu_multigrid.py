@@ -369,3 +369,30 @@ def test_mond_and_fR_at_benchmark_size(amd):
     acc_n, _, _ = amd.solver.pm(pos, p_nw, tables=tables)
     rel = float((acc_r - acc_n).abs().max()) / float(acc_n.abs().max())
     assert 1e-4 < rel < 0.5, rel  # the fifth force is there, and it is a correction
+
+
+@pytest.mark.parametrize("n,fr_n", [(32, 1), (64, 1), (32, 2)])
+def test_native_fas_vcycle_is_the_python_recursion(amd, n, fr_n):
+    """pm_fr_vcycle (the whole FAS V-cycle issued from C) against multigrid.V_cycle_FAS's recursion written out in
+    Python over the per-operator entry points (multigrid.py:521-612), on the same scalaron guess and density: bit for
+    bit (no atomics anywhere in the cycle, so both orders of issue give the same floats)."""
+    torch = amd.torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100 * n + fr_n)
+    b = torch.rand((n, n, n), generator=g, device="cuda") * 0.5 + 0.2
+    x0 = torch.rand((n, n, n), generator=g, device="cuda") * 0.2 + 0.9
+    param = {"Npre": 2, "Npost": 1, "ncoarse": int(np.log2(n)), "fR_n": fr_n, "fR_q": np.float32(-0.1),
+             "theory": "fr", "compute_additional_field": True}
+    out = {}
+    for native in (True, False):
+        amd.multigrid._NATIVE_VCYCLE = native
+        try:
+            x = x0.clone()
+            for _ in range(2):
+                amd.multigrid.V_cycle_FAS(x, b, param)
+            out[native] = x.cpu().numpy()
+        finally:
+            amd.multigrid._NATIVE_VCYCLE = True
+    assert np.isfinite(out[True]).all()
+    assert np.abs(out[True] - x0.cpu().numpy()).max() > 0
+    np.testing.assert_array_equal(out[True], out[False])
