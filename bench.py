@@ -306,11 +306,15 @@ def main():
             pos, vel, acc = pm_main.tune_placement(pos, vel, acc)
         pm_main.reserve_step_buffers(pos)
 
+    resort_at = int(os.environ.get("PMSTEP_EXP_RESORT_AT", "0"))
+
     def step(pos, vel, acc, phi, extra):
         param["nsteps"] += 1
         pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, t_far)
         if world == 1:
             pos, vel, acc = pm_main.reorder_policy(pos, vel, acc, param)
+            if resort_at and param["nsteps"] == resort_at:  # development: does a fresh full sort change the step time?
+                pos, vel, acc = pm_main._reorder(pos, vel, acc, param)
         return pos, vel, acc, phi, extra
 
     for _ in range(args.warmup):
@@ -321,6 +325,7 @@ def main():
     torch.cuda.synchronize()
     L.profile_start()
     t0 = time.perf_counter()
+    dt_series = []
     straggler_frac, step_events = [], [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     step_events[0].record()
     prof = None
@@ -333,6 +338,7 @@ def main():
         pos, vel, acc, phi, extra = step(pos, vel, acc, phi, extra)
         if world == 1:
             straggler_frac.append(utils.straggler_fraction(n)[0])
+            dt_series.append((float(param.get("_dt_last", 0.0)), float(param.get("_dt_pred", 0.0) or 0.0)))
         L.profile_mark()
         step_events[i + 1].record()
     if prof is not None:
@@ -427,6 +433,9 @@ def main():
                         "wall_ms": round(step_events[i].elapsed_time(step_events[i + 1]), 3),
                         "ms": {k[3:]: round(v, 3) for k, v in sorted(per_step[i].items(), key=lambda kv: -kv[1])[:3]}}
                        for i in show]
+    if straggler_frac and straggler_frac[0] is not None:  # every timed step: stragglers found, dt taken, dt guessed for the next
+        out["straggler_series"] = [round(f, 5) for f in straggler_frac]
+        out["dt_series"] = [[float(f"{a:.6g}"), float(f"{b:.6g}")] for a, b in dt_series]
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         del pos, vel, acc, phi, extra
         torch.cuda.empty_cache()

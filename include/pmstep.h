@@ -236,6 +236,11 @@ int pm_gradient_interp_kick_rebucket(pm_ctx *ctx, int order, int scheme, const f
 /* Guess of the next step's dt for the filing above; must be set before the pm_kick_drift_wrap_deposit[_khalo]
  * whose counts the re-bucketing gather uses (the gather takes the value those counts were made with). */
 int pm_set_predicted_dt(pm_ctx *ctx, float dt_next);
+/* ... and of the growth of the accelerations over the coming step: the filing uses scale * a_old for the
+ * acceleration it does not know yet (1, the default: a_old itself).  pm_last_acc_meanabs gives the caller what to
+ * extrapolate: the mean |a_x| over a sample of particles (every 64th tile) of the last fused gather, fetched by the same read-back as pm_last_maxabs (call that first; host value, no synchronisation). */
+int pm_set_predicted_acc_scale(pm_ctx *ctx, float scale);
+int pm_last_acc_meanabs(pm_ctx *ctx, double *h_meanabs);
 /* utils.max_abs of the acc / vel arrays written by the last pm_interp_kick (syncs).  *h_max_vel is 0
  * if that call had d_vel == NULL. */
 int pm_last_maxabs(pm_ctx *ctx, float *h_max_acc, float *h_max_vel);

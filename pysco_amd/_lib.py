@@ -77,6 +77,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_gradient_interp_kick": (_vp, _i, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _f),
     "pm_gradient_interp_kick_rebucket": (_vp, _i, _i, _vp, _vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp),
     "pm_set_predicted_dt": (_vp, _f),
+    "pm_set_predicted_acc_scale": (_vp, _f),
+    "pm_last_acc_meanabs": (_vp, C.POINTER(C.c_double)),
     "pm_last_maxabs": (_vp, C.POINTER(_f), C.POINTER(_f)),
     "pm_set_gather_mode": (_vp, _i),
     "pm_restriction": (_vp, _vp, _i, _f, _vp),

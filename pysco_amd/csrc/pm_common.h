@@ -164,6 +164,8 @@ struct pm_ctx {
     size_t rb_buf_bytes;
     int stay_valid;            // the destination counts belong to the prepared lists (lists_pos)
     float dt_pred, stay_dt_pred;  // guess of the next step's dt (pm_set_predicted_dt); the one the counts were made with
+    float acc_scale_pred;      // expected |a_new| / |a_old| over the next step (pm_set_predicted_acc_scale), 1 = none
+    double last_acc_meanabs;   // mean |a_x| of the last gather's sample (pm_last_acc_meanabs)
     const float *sorted_pos;   // positions that were written tile by tile with table rb_cur (a hint: any table that
     int64_t sorted_np;         // partitions [0, np) gives correct results, an exact one saves the bisection)
     unsigned sorted_ntiles;

@@ -52,6 +52,7 @@ extern "C" int pm_ctx_create(pm_ctx **out, int n, void *stream) {
     PM_REQUIRE(n >= 4 && n <= 16384 && (n & (n - 1)) == 0, "n must be a power of two in [4, 16384]");
     pm_ctx *c = new pm_ctx();
     memset(c, 0, sizeof(*c));
+    c->acc_scale_pred = 1.0f;
     c->n = n;
     c->log2n = __builtin_ctz((unsigned)n);
     c->slab_nx = n;

@@ -1098,7 +1098,9 @@ struct PosQueue {
     __device__ __forceinline__ void load(int slot, unsigned r) {
         r = min(r, last);  // clamp: harmless reload of the range's last particle
         const float *pp = base + 3u * r;
-        x[slot] = pp[0], y[slot] = pp[1], z[slot] = pp[2];
+        // read-once stream: nontemporal, so that it does not push the tile halos neighbours re-read out of the L2
+        x[slot] = __builtin_nontemporal_load(pp), y[slot] = __builtin_nontemporal_load(pp + 1),
+        z[slot] = __builtin_nontemporal_load(pp + 2);
     }
     __device__ __forceinline__ void prime(const float *range_base, unsigned r0, unsigned count) {
         base = range_base, last = count - 1u;
@@ -1318,7 +1320,9 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
             const int64_t p = p0 + u * BLK;
             if (p < e) {
 #pragma unroll
-                for (int m = 0; m < 3; ++m) x[u][m] = pos[3 * p + m], v[u][m] = vel[3 * p + m], a[u][m] = acc[3 * p + m];
+                for (int m = 0; m < 3; ++m)
+                    x[u][m] = __builtin_nontemporal_load(pos + 3 * p + m), v[u][m] = __builtin_nontemporal_load(vel + 3 * p + m),
+                    a[u][m] = __builtin_nontemporal_load(acc + 3 * p + m);
             }
         }
 #pragma unroll
@@ -1328,9 +1332,9 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
 #pragma unroll
                 for (int m = 0; m < 3; ++m) pm_kick_drift_wrap_one(x[u][m], v[u][m], a[u][m], mhalf_dt, dt);
 #pragma unroll
-                for (int m = 0; m < 3; ++m) vel[3 * p + m] = v[u][m];
+                for (int m = 0; m < 3; ++m) __builtin_nontemporal_store(v[u][m], vel + 3 * p + m);
 #pragma unroll
-                for (int m = 0; m < 3; ++m) pos[3 * p + m] = x[u][m];
+                for (int m = 0; m < 3; ++m) __builtin_nontemporal_store(x[u][m], pos + 3 * p + m);
                 if (lv.idx && (x[u][0] < lv.x_lo || x[u][0] >= lv.x_hi)) {  // slab: leaves this rank's planes
                     const int slot = atomicAdd(lv.count, 1);
                     if (slot < lv.cap) lv.idx[slot] = p;
@@ -1572,7 +1576,7 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     // particles)
     RbBufs rb;
     const bool count_stay = !lv.idx && work.nlaunch == ntiles;
-    DestCount dcount{nullptr, nullptr, nullptr, c->dt_pred, -0.5f * (dt + c->dt_pred)};
+    DestCount dcount{nullptr, nullptr, nullptr, c->dt_pred, -0.5f * (dt + c->dt_pred) * c->acc_scale_pred};
     if (count_stay) {
         rc = rebucket_bufs(c, ntiles, np, &rb);
         if (rc) return rc;
@@ -1831,6 +1835,8 @@ struct __attribute__((packed, aligned(4))) Packed3 {
     float a, b, c;
 };
 
+constexpr int PM_SAMPLE_WORD = 32;  // offset (in 4-byte words) of the acceleration sample's sums from the maxima
+
 struct Rebucket {
     const int64_t *newstart;  // [ntiles + 1] offsets of the re-bucketed stream
     unsigned *fill;           // [ntiles] cleared: whoever sends particles to a tile takes a slice of its range here
@@ -2007,6 +2013,14 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     // gather, second kick (utils.py:297, y += a*x) and the CFL maxima in one pass: the acceleration never
     // leaves its registers (PMC: re-reading it in a separate coalesced pass cost a further 12.9 GB of fetch)
     unsigned ma = 0, mv = 0;  // bit patterns of max|a|, max|v| (integer order == float order, NaN on top)
+    // every lane also sums |a_x| over the particles it serves and every 64th workgroup adds its sums to a
+    // global one: the mean |a_x| of a sample, whose step-to-step ratio the caller extrapolates for the re-sort's
+    // prediction (pm_set_predicted_acc_scale).  Summed unconditionally -- two VALU operations per particle: a
+    // branch on `sample` inside the particle loop splits its body and the compiler then drains the prefetch
+    // queues every iteration (the kernel took 29 ms instead of 17).
+    const bool sample = (blockIdx.x & 63u) == 0u;
+    float sabs = 0.f, scnt = 0.f;
+    __shared__ float s_sum[2][BLK / 64];
     // (o, w, p): where the particle's acceleration and velocity go -- the range's own base with a 32-bit
     // relative index, or the arrays' base with the 64-bit index of a listed straggler
     // `src_index`: the particle's index in the input arrays (only read for the tags of a re-bucketing pass)
@@ -2080,13 +2094,17 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                     w[mm] = v[mm] + mhalf_dt * a[mm];
                     mv = max(mv, __float_as_uint(w[mm]) & 0x7fffffffu);
                 }
-                *reinterpret_cast<Packed3 *>(rb.pos_out + 3 * d64) = Packed3{x, y, z};
-                *reinterpret_cast<Packed3 *>(rb.acc_out + 3 * d64) = Packed3{a[0], a[1], a[2]};
-                *reinterpret_cast<Packed3 *>(rb.vel_out + 3 * d64) = Packed3{w[0], w[1], w[2]};
+                sabs += fabsf(a[0]), scnt += 1.0f;
+                typedef float pm_v3f __attribute__((ext_vector_type(3)));
+                const pm_v3f vp = {x, y, z}, va = {a[0], a[1], a[2]}, vw = {w[0], w[1], w[2]};
+                asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(rb.pos_out + 3 * d64), "v"(vp) : "memory");
+                asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(rb.acc_out + 3 * d64), "v"(va) : "memory");
+                asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(rb.vel_out + 3 * d64), "v"(vw) : "memory");
                 if (rb.id) rb.id_out[d64] = rb.id[src_index];
             }
         } else if (!skip) {
             float *op = o + 3 * p, *wp = w3 + 3 * p;
+            sabs += fabsf(a[0]), scnt += 1.0f;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 op[m] = a[m];
@@ -2122,7 +2140,11 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         ma = max(ma, (unsigned)__shfl_down((int)ma, off, 64));
         mv = max(mv, (unsigned)__shfl_down((int)mv, off, 64));
     }
-    if ((tid & 63) == 0) s_max[0][tid >> 6] = ma, s_max[1][tid >> 6] = mv;
+    for (int off = 32; off > 0; off >>= 1) {
+        sabs += __shfl_down(sabs, off, 64);
+        scnt += __shfl_down(scnt, off, 64);
+    }
+    if ((tid & 63) == 0) s_max[0][tid >> 6] = ma, s_max[1][tid >> 6] = mv, s_sum[0][tid >> 6] = sabs, s_sum[1][tid >> 6] = scnt;
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < BLK / 64; ++w) ma = max(ma, s_max[0][w]), mv = max(mv, s_max[1][w]);
@@ -2130,6 +2152,15 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         // it; the maximum only grows, so a workgroup that cannot raise it (nearly all) just reads it
         if (ma > __atomic_load_n(maxbits, __ATOMIC_RELAXED)) atomicMax(maxbits, ma);
         if (KICK && mv > __atomic_load_n(maxbits + 1, __ATOMIC_RELAXED)) atomicMax(maxbits + 1, mv);
+        // the sample's sums live on a cache line of their own (PM_SAMPLE_WORD): on the line of the maxima, which
+        // every workgroup reads, 260 000 atomics took the kernel from 17 to 30 ms
+        if (sample) {
+            for (int w = 1; w < BLK / 64; ++w) sabs += s_sum[0][w], scnt += s_sum[1][w];
+            if (scnt > 0.f) {
+                atomicAdd(reinterpret_cast<double *>(maxbits + PM_SAMPLE_WORD), (double)sabs);
+                atomicAdd(maxbits + PM_SAMPLE_WORD + 2, (unsigned)scnt);
+            }
+        }
     }
 }
 
@@ -2211,6 +2242,7 @@ extern "C" int pm_interp_kick(pm_ctx *c, int scheme, const float *d_force, const
     PM_REQUIRE(c->n >= 16, "pm_interp_kick needs n >= 16 (use pm_interp + pm_axpy below that)");
     PM_REQUIRE((np + PM_CHUNK - 1) / PM_CHUNK < 2147483647LL, "too many particles for one launch");
     PM_HIP(hipMemsetAsync(c->d_scratch + 8, 0, 2 * sizeof(unsigned), c->stream));
+    PM_HIP(hipMemsetAsync(c->d_scratch + 8 + PM_SAMPLE_WORD, 0, 4 * sizeof(unsigned), c->stream));
     if (np == 0) return PM_OK;
     switch (scheme) {
         case PM_NGP: return interp_kick_launch<PM_NGP>(c, d_force, d_pos, np, d_acc, d_vel, half_dt);
@@ -2261,6 +2293,7 @@ extern "C" int pm_gradient_interp_kick(pm_ctx *c, int order, int scheme, const f
     PM_REQUIRE(((uintptr_t)d_phi & 15u) == 0, "d_phi must be 16-byte aligned (the tile fill reads float4)");
     PM_REQUIRE((np + PM_CHUNK - 1) / PM_CHUNK < 2147483647LL, "too many particles for one launch");
     PM_HIP(hipMemsetAsync(c->d_scratch + 8, 0, 2 * sizeof(unsigned), c->stream));
+    PM_HIP(hipMemsetAsync(c->d_scratch + 8 + PM_SAMPLE_WORD, 0, 4 * sizeof(unsigned), c->stream));
     if (np == 0) return PM_OK;
     pm_geom geo = pm_ctx_geom(c);  // tiles are filed on the full mesh; phi is the (slab + ghosts) array given
     geo.nx = nx_phi, geo.x0 = ((x0_phi % c->n) + c->n) % c->n;
@@ -2337,6 +2370,7 @@ extern "C" int pm_gradient_interp_kick_rebucket(pm_ctx *c, int order, int scheme
                                    c->stream));
     PM_HIP(hipMemsetAsync(b.fill, 0, ((size_t)ntiles + 1) * sizeof(unsigned), c->stream));
     PM_HIP(hipMemsetAsync(c->d_scratch + 8, 0, 2 * sizeof(unsigned), c->stream));
+    PM_HIP(hipMemsetAsync(c->d_scratch + 8 + PM_SAMPLE_WORD, 0, 4 * sizeof(unsigned), c->stream));
     Rebucket rb;
     rb.newstart = table, rb.fill = b.fill, rb.wg_hist = b.wg_hist, rb.dcode = b.dcode;
     rb.pos_out = d_pos_out, rb.vel_out = d_vel_out, rb.acc_out = d_acc_out, rb.id = d_id, rb.id_out = d_id_out;
@@ -2364,13 +2398,34 @@ extern "C" int pm_set_predicted_dt(pm_ctx *c, float dt_next) {
     return PM_OK;
 }
 
+// How much the accelerations are expected to grow over the next step (|a_new| ~ scale |a_old|, 1 = no guess): the
+// re-sort's prediction of the next drift uses scale * a_old where the new acceleration is not known yet (dest_of).
+extern "C" int pm_set_predicted_acc_scale(pm_ctx *c, float scale) {
+    PM_REQUIRE(c && scale > 0.f && scale < 1.0e6f, "bad argument");
+    c->acc_scale_pred = scale;
+    return PM_OK;
+}
+
 extern "C" int pm_last_maxabs(pm_ctx *c, float *h_max_acc, float *h_max_vel) {
     PM_REQUIRE(c && h_max_acc && h_max_vel, "NULL argument");
-    unsigned bits[2] = {0, 0};
+    unsigned bits[PM_SAMPLE_WORD + 4];
+    memset(bits, 0, sizeof(bits));
     PM_HIP(hipMemcpyAsync(bits, c->d_scratch + 8, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
     PM_HIP(hipStreamSynchronize(c->stream));
     memcpy(h_max_acc, &bits[0], sizeof(float));
     memcpy(h_max_vel, &bits[1], sizeof(float));
+    double sum;
+    memcpy(&sum, &bits[PM_SAMPLE_WORD], sizeof(double));
+    const unsigned cnt = bits[PM_SAMPLE_WORD + 2];
+    c->last_acc_meanabs = cnt ? sum / (double)cnt : 0.0;  // (came with the same copy: no second round trip)
+    return PM_OK;
+}
+
+// Mean |a_x| over the sample of particles the last fused gather summed (every 64th tile), as read back by the
+// last pm_last_maxabs; 0 if that gather took no sample.  Host value, no synchronisation.
+extern "C" int pm_last_acc_meanabs(pm_ctx *c, double *h_meanabs) {
+    PM_REQUIRE(c && h_meanabs, "NULL argument");
+    *h_meanabs = c->last_acc_meanabs;
     return PM_OK;
 }
 

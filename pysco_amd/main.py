@@ -44,8 +44,8 @@ def tune_placement(position, velocity, acceleration=None, max_candidates: int = 
     call a moment earlier (tools/bench_array_single.py) -- and the fused kick + drift + deposit, which updates
     position and velocity in place, runs 14 or 16-17 ms at 1024^3 accordingly.  Nothing in the virtual layout controls
     it, so this allocates candidate arrays (as many as fit comfortably), times a multiply-by-one pass over each and
-    over the caller's arrays, moves the particle data into the fastest three and keeps the next three as the gather's
-    output set; the rest is freed.  One-time cost: about 6 ms per candidate at 1024^3.  Returns the (possibly new)
+    over the caller's arrays, gives the four fastest to position and velocity of the live set and of the gather's
+    output set, the next two to the accelerations; the rest is freed.  One-time cost: about 6 ms per candidate at 1024^3.  Returns the (possibly new)
     position, velocity[, acceleration] tensors; values and order unchanged."""
     if not L.is_device_array(position):
         return (position, velocity) if acceleration is None else (position, velocity, acceleration)
@@ -82,21 +82,32 @@ def tune_placement(position, velocity, acceleration=None, max_candidates: int = 
         t.zero_()
     timed = sorted([(probe(t), i, t, i < len(live)) for i, t in enumerate(live + cand)], key=lambda r: r[0])
     logging.info("placement probe [ms]: " + " ".join(f"{ms:.2f}{'*' if is_live else ''}" for ms, _, _, is_live in timed))
-    fast = [t for _, _, t, _ in timed[:len(live)]]
-    spare = [t for _, _, t, _ in timed[len(live):need]]
-    # particle data into the fastest arrays: those already there stay, the others move into the free fast ones
-    homes = [t for t in fast if all(t.data_ptr() != x.data_ptr() for x in live)]
-    out = []
-    for x in live:
-        if any(x.data_ptr() == t.data_ptr() for t in fast):
-            out.append(x)
-        else:
-            h = homes.pop(0)
+    ranked = [t for _, _, t, _ in timed[:need]]
+    # roles by rank: the fused kick + drift updates position and velocity IN PLACE, in the live set and -- a step
+    # later -- in the set the gather wrote (mesh._rebucket_pool, whose roles are stable): those four take the four
+    # fastest arrays; the accelerations are only read and written once each (pure streams differ by 5 %)
+    if len(ranked) >= 6:
+        homes = [ranked[0], ranked[1], ranked[4]][:len(live)]
+        spare = [ranked[2], ranked[3], ranked[5]]
+    else:  # not enough memory for a second set: the live arrays into the fastest ones, whatever is left to the pool
+        homes, spare = ranked[:len(live)], ranked[len(live):]
+    same = lambda a, b: a.data_ptr() == b.data_ptr()  # noqa: E731
+    # move the data: a home that still holds another live array's data waits until that array has moved (a cycle is
+    # broken through a scratch copy)
+    pending = [(x, h) for x, h in zip(live, homes) if not same(x, h)]
+    while pending:
+        ready = [k for k, (_, h) in enumerate(pending) if not any(same(h, x2) for x2, _ in pending)]
+        if ready:
+            x, h = pending.pop(ready[0])
             h.copy_(x)
-            out.append(h)
-            spare.append(x)  # (a slow array is still better than an allocation inside the loop)
+        else:
+            x, h = pending[0]
+            pending[0] = (x.clone(), h)
+    displaced = [x for x, h in zip(live, homes) if not same(x, h) and not any(same(x, t) for t in homes + spare)]
+    spare = [t for t in spare if not any(same(t, h) for h in homes)] + displaced  # (a slow array beats a hipMalloc in the loop)
     mesh._rebucket_pool.extend(spare[:3])
-    del cand, timed, fast, spare
+    out = homes
+    del cand, timed, ranked, spare, displaced
     torch.cuda.empty_cache()
     return tuple(out)
 

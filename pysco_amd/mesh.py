@@ -236,7 +236,9 @@ def derivative_interp_vec_kick_rebucket(scheme_name: str, potential, order: int,
     if order not in (0, 2, 3, 5, 7):  # 0: `potential` is the force grid [n, n, n, 3] (interp_vec_kick's input)
         raise ValueError(f"{order=}, should be 2, 3, 5 or 7")
     ctx = L.context(n)
-    acc, pos_out, vel_out = _pool_take(position), _pool_take(position), _pool_take(velocity)
+    # (same order as integration's pool_give: an array keeps its role -- position, velocity or acceleration -- from
+    # step to step, which is what main.tune_placement's choice of arrays relies on)
+    pos_out, vel_out, acc = _pool_take(position), _pool_take(velocity), _pool_take(position)
     ids_out = None if ids is None else torch.empty_like(ids)
     if ids is not None and (ids.dtype != torch.int32 or not ids.is_contiguous() or ids.shape[0] != position.shape[0]):
         raise ValueError("ids must be a contiguous int32 tensor with one entry per particle")

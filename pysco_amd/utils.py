@@ -56,7 +56,19 @@ def _lookup_fused_maxabs(x):
         a, v = C.c_float(0), C.c_float(0)
         f["ctx"].call("pm_last_maxabs", C.byref(a), C.byref(v))
         f["values"] = (np.float32(a.value), np.float32(v.value))
+        ms = C.c_double(0)
+        f["ctx"].call("pm_last_acc_meanabs", C.byref(ms))  # (came with the same read-back)
+        f["meanabs"] = float(ms.value)
     return f["values"][which]
+
+
+def fused_acc_meanabs(acceleration):
+    """Mean |a_x| of a sample of `acceleration` if the fused gather that wrote it took one (pmstep.h:
+    pm_last_acc_meanabs), else None.  Costs nothing beyond the read-back max_abs(acceleration) does anyway."""
+    if _lookup_fused_maxabs(acceleration) is None or _tensor_key(acceleration) != _fused_maxabs["acc"]:
+        return None
+    ms = _fused_maxabs.get("meanabs")
+    return ms if ms and np.isfinite(ms) and ms > 0 else None
 
 
 def _inplace(y, fn):

@@ -157,3 +157,58 @@ def test_rebucket_on_the_force_grid_path_of_fR():
     d = np.abs(ref[0][ref[3]] - new[0][new[3]])
     assert np.minimum(d, 1 - d).max() <= 5e-6
     assert np.abs(ref[2][ref[3]] - new[2][new[3]]).max() <= 2e-3 * np.abs(ref[2]).max()
+
+
+def test_acc_meanabs_sample_and_predicted_scale():
+    """pm_last_acc_meanabs: the fused gather's sampled mean |a_x| (every sixteenth tile; what integrate() extrapolates
+    from step to step) -- its step-to-step ratio against that of the whole array; pm_set_predicted_acc_scale changes
+    which tile a particle is filed under, never a value.  The sample rides on the read-back of pm_last_maxabs."""
+    import ctypes as C
+
+    import torch
+
+    import bench
+    from pysco_amd import _lib as L
+    from pysco_amd import integration, solver, utils
+
+    n = 128
+    pos_h, vel_h = zeldovich_particles(n, seed=11, rms_cells=0.8, vel_factor=0.5)
+    out = {}
+    for scale in (1.0, 1.3):
+        L._ctxs.clear()
+        param, tables = bench.make_param(n, pos_h.shape[0], "newton_fft")
+        param["rebucket_straggler_fraction"] = 0.0
+        pos, vel = utils.reorder_particles(torch.from_numpy(pos_h).cuda(), torch.from_numpy(vel_h).cuda())
+        param["particle_id"] = torch.arange(pos.shape[0], dtype=torch.int32, device="cuda")
+        acc, pot, extra = solver.pm(pos, param, tables=tables)
+        orig = L.Context.call
+        sampled, full = [], []
+        try:
+            for step in range(4):
+                pos, vel, acc, pot, extra = integration.integrate(pos, vel, acc, pot, extra, tables, param, np.float32(3e38))
+                sampled.append(utils.fused_acc_meanabs(acc))
+                full.append(float(acc[:, 0].abs().double().mean()))
+                if step == 0 and scale != 1.0:  # from the second step on: a caller's own scale instead of the library's
+
+                    def call(self, name, *args, _orig=orig, _scale=scale):
+                        if name == "pm_set_predicted_acc_scale":
+                            args = (_scale,)
+                        return _orig(self, name, *args)
+
+                    L.Context.call = call
+        finally:
+            L.Context.call = orig
+        assert all(m is not None and 0.3 < m / f < 3.0 for m, f in zip(sampled, full)), (sampled, full)
+        for k in range(1, 4):  # the growth from step to step is what the sample is for
+            assert abs((sampled[k] / sampled[k - 1]) / (full[k] / full[k - 1]) - 1.0) < 0.02, (sampled, full)
+        got = C.c_double(0)
+        L.context(n).call("pm_last_acc_meanabs", C.byref(got))
+        assert got.value == sampled[-1]
+        inv = np.argsort(param["particle_id"].cpu().numpy())
+        out[scale] = (pos.cpu().numpy()[inv], vel.cpu().numpy()[inv], acc.cpu().numpy()[inv], param.get("_acc_scale_pred"))
+    assert 0.5 <= out[1.0][3] <= 2.0 and out[1.0][3] != 1.0
+    for k in range(3):
+        d = np.abs(out[1.0][k] - out[1.3][k])
+        if k == 0:
+            d = np.minimum(d, 1 - d)
+        assert d.max() <= 2e-4 * max(1e-30, np.abs(out[1.0][k]).max())

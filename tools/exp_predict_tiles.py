@@ -35,7 +35,14 @@ def main():
         c = (x * n).to(torch.int32).clamp_(0, n - 1)
         return ((c[:, 0] >> 3) * (n >> 4) + (c[:, 1] >> 4)) * (n >> 4) + (c[:, 2] >> 4)
 
-    pred_v = pred_va = pred_vb = None
+    pred_v = pred_va = pred_vb = pred_vs = None
+    amax_hist = []
+
+    def s_guess_next(h, dtp):
+        # ratio of max|a| over the last step, rescaled to the length of the next one
+        a1, a0_, dt_ = h[-1]
+        return (a1 / a0_) ** (float(dtp) / dt_) if a0_ > 0 and dt_ > 0 else 1.0
+
     t_prev = param["t"]
     dt_last = None
     for s in range(args.steps):
@@ -60,6 +67,21 @@ def main():
         pred_va = tile((pos + d) % 1.0)
         d = (dtp * (v_half - np.float32(0.5 * (dt + float(dtp))) * acc)).clamp_(-1.0 / n, 1.0 / n)
         pred_vb = tile((pos + d) % 1.0)
+        # (vs) the old acceleration scaled by the trend of max|a|: a_new ~ s a_old with one s for all particles
+        amax = float(acc.abs().max())
+        s_opt = float((acc * a0).sum() / (a0 * a0).sum())
+        resid = float(((acc - s_opt * a0) ** 2).sum().sqrt() / (acc ** 2).sum().sqrt())
+        if amax_hist:
+            r_prev = amax_hist[-1][0] / amax_hist[-1][1] if amax_hist[-1][1] > 0 else 1.0
+            s_guess = r_prev ** (dt / amax_hist[-1][2]) if amax_hist[-1][2] > 0 else 1.0
+        else:
+            s_guess = 1.0
+        msg += f"  [a_new ~ s a_old: best s {s_opt:.4f} (residual {resid:.3f}), guessed {s_guess:.4f}, max ratio {amax / float(a0.abs().max()):.4f}]"
+        if pred_vs is not None:
+            msg += f"  vs {float((pred_vs != tl).float().mean()):.4f}"
+        amax_hist.append((amax, float(a0.abs().max()), dt))
+        d = (dtp * (v_half - np.float32(0.5 * (dt + float(dtp)) * s_guess_next(amax_hist, dtp)) * a0)).clamp_(-1.0 / n, 1.0 / n)
+        pred_vs = tile((pos + d) % 1.0)
         # the same with the NEW acceleration (what the gather could do if it knew the counts beforehand)
         print(msg, flush=True)
         del x0, v0, a0, v_half, d
