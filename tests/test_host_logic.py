@@ -45,11 +45,17 @@ def test_dt_guess_follows_the_binding_criterion(monkeypatch):
     a_end = np.exp(tables[0](param["t"] + dt3))
     dt3_next = float(tables[1](np.log(1.1 * a_end)) - tables[1](np.log(a_end)))
     assert param["_dt_pred"] == pytest.approx(dt3_next, rel=1e-6) and param["_dt_pred"] > dt3
-    # the velocity criterion just above this step's dt and shrinking 10 % per step: it binds next step
+    # the velocity criterion just above this step's dt, max|v| (~ 1 / dt2) having grown 10 % over the last step: the
+    # same increment again over a step of the same length (no acceleration trend known), and it binds next step
     monkeypatch.setattr(integration, "dt_CFL_maxvel", lambda vel, p: np.float32(1.05 * dt3))
-    param["_dt_cfl_last"] = (10.0, 1.05 * dt3 / 0.9)
+    param["_dt_cfl_last"] = (10.0, 1.05 * dt3 * 1.1)
     integration.integrate(None, None, None, None, None, tables, param, np.float32(3e38))
-    assert param["_dt_pred"] == pytest.approx(1.05 * dt3 * 0.9, rel=1e-4)
+    assert param["_dt_pred"] == pytest.approx(1.05 * dt3 / 1.2 * 1.1, rel=1e-4)
+    # ... over a step half as long as the last one, half the increment
+    param["_dt_cfl_last"], param["_dt_last"] = (10.0, 1.05 * dt3 * 1.1), 2.0 * float(seen["dt"])
+    integration.integrate(None, None, None, None, None, tables, param, np.float32(3e38))
+    assert param["_dt_pred"] == pytest.approx(1.05 * dt3 / 1.15 * 1.1, rel=1e-3)
+    param.pop("_dt_last")
     # a snapshot right after this step clips the next one
     param["_dt_cfl_last"] = None
     t_snap = param["t"] + dt3 * 1.5
