@@ -281,6 +281,9 @@ def main():
     if world > 1:  # x-slab decomposition: keep the lattice planes of this rank, then hand strays to their owners
         from pysco_amd import slab
 
+        if os.environ.get("PMSTEP_SLAB_REBUCKET") == "0":  # development A/B: ranks never re-sort their streams
+            slab._SLAB_REBUCKET = False
+
         sl = slab.get(n)
         lo, hi = sl.x_lo * n * n, (sl.x_lo + sl.nx) * n * n
         pos, vel = pos[lo:hi].clone(), vel[lo:hi].clone()
@@ -336,6 +339,8 @@ def main():
         prof.enable()
     for i in range(args.steps):
         pos, vel, acc, phi, extra = step(pos, vel, acc, phi, extra)
+        if world > 1:
+            straggler_frac.append(utils.straggler_fraction(n)[0])  # of this rank's stream, as the gather found it
         if world == 1:
             straggler_frac.append(utils.straggler_fraction(n)[0])
             dt_series.append((float(param.get("_dt_last", 0.0)), float(param.get("_dt_pred", 0.0) or 0.0)))
@@ -435,7 +440,8 @@ def main():
                        for i in show]
     if straggler_frac and straggler_frac[0] is not None:  # every timed step: stragglers found, dt taken, dt guessed for the next
         out["straggler_series"] = [round(f, 5) for f in straggler_frac]
-        out["dt_series"] = [[float(f"{a:.6g}"), float(f"{b:.6g}")] for a, b in dt_series]
+        if dt_series:
+            out["dt_series"] = [[float(f"{a:.6g}"), float(f"{b:.6g}")] for a, b in dt_series]
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         del pos, vel, acc, phi, extra
         torch.cuda.empty_cache()

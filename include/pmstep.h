@@ -233,6 +233,22 @@ int pm_gradient_interp_kick(pm_ctx *ctx, int order, int scheme, const float *d_p
 int pm_gradient_interp_kick_rebucket(pm_ctx *ctx, int order, int scheme, const float *d_phi, const float *d_pos,
                                      const float *d_vel, int64_t np, float half_dt, float *d_pos_out, float *d_vel_out,
                                      float *d_acc_out, const unsigned *d_id, unsigned *d_id_out);
+/* The same on a slab (multi-GPU x-decomposition; no reference counterpart): the particles change arrays between the
+ * fused kick (pm_kick_drift_wrap_deposit_slab, which knows where they will go) and the gather (migration of the
+ * leavers to their new owners), so the kick only RECORDS the destination codes -- one byte per particle, relative to
+ * the tile the particle is in, into the caller's array set by pm_set_destination_codes (NULL: off) -- the caller
+ * migrates that array with the particles, and pm_rebucket_prepare counts the destinations of the stream as it is
+ * after the migration (needs complete lists from pm_tile_lists for exactly d_pos / np; destinations outside the
+ * tile window become "stays": those particles are about to leave the rank).  pm_gradient_interp_kick_rebucket_slab
+ * is then pm_gradient_interp_kick_rebucket with pm_gradient_interp_kick's potential-slab geometry. */
+int pm_set_destination_codes(pm_ctx *ctx, unsigned char *d_codes);
+int pm_rebucket_prepare(pm_ctx *ctx, const float *d_pos, int64_t np, unsigned char *d_codes);
+/* pm_tile_lists + pm_rebucket_prepare in one pass over the positions (what the slab step calls after its migration) */
+int pm_tile_lists_codes(pm_ctx *ctx, const float *d_pos, int64_t np, unsigned char *d_codes);
+int pm_gradient_interp_kick_rebucket_slab(pm_ctx *ctx, int order, int scheme, const float *d_phi, int nx_phi, int x0_phi,
+                                          const float *d_pos, const float *d_vel, int64_t np, float half_dt,
+                                          float *d_pos_out, float *d_vel_out, float *d_acc_out, const unsigned *d_id,
+                                          unsigned *d_id_out);
 /* Guess of the next step's dt for the filing above; must be set before the pm_kick_drift_wrap_deposit[_khalo]
  * whose counts the re-bucketing gather uses (the gather takes the value those counts were made with). */
 int pm_set_predicted_dt(pm_ctx *ctx, float dt_next);

@@ -76,6 +76,10 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_kick_drift_wrap_deposit_slab": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _f, _f, _vp, _i, C.POINTER(_i)),
     "pm_gradient_interp_kick": (_vp, _i, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _f),
     "pm_gradient_interp_kick_rebucket": (_vp, _i, _i, _vp, _vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp),
+    "pm_gradient_interp_kick_rebucket_slab": (_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp),
+    "pm_set_destination_codes": (_vp, _vp),
+    "pm_rebucket_prepare": (_vp, _vp, _i64, _vp),
+    "pm_tile_lists_codes": (_vp, _vp, _i64, _vp),
     "pm_set_predicted_dt": (_vp, _f),
     "pm_set_predicted_acc_scale": (_vp, _f),
     "pm_last_acc_meanabs": (_vp, C.POINTER(C.c_double)),

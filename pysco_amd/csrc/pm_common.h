@@ -163,6 +163,8 @@ struct pm_ctx {
     void *rb_buf;
     size_t rb_buf_bytes;
     int stay_valid;            // the destination counts belong to the prepared lists (lists_pos)
+    unsigned char *codes_user;        // where the fused kick records the destination codes on a slab (pm_set_destination_codes)
+    const unsigned char *stay_codes;  // the codes the destination counts were made from (the gather's Rebucket::dcode)
     float dt_pred, stay_dt_pred;  // guess of the next step's dt (pm_set_predicted_dt); the one the counts were made with
     float acc_scale_pred;      // expected |a_new| / |a_old| over the next step (pm_set_predicted_acc_scale), 1 = none
     double last_acc_meanabs;   // mean |a_x| of the last gather's sample (pm_last_acc_meanabs)

@@ -812,8 +812,9 @@ static int rebucket_bufs(pm_ctx *c, unsigned ntiles, int64_t np, RbBufs *b) {
     if (c->rb_buf_bytes < need) {
         if (c->rb_buf) PM_HIP(hipFree(c->rb_buf));
         c->rb_buf = nullptr, c->rb_buf_bytes = 0, c->sorted_pos = nullptr, c->stay_valid = 0;
-        PM_HIP(hipMalloc(&c->rb_buf, need));
-        c->rb_buf_bytes = need;
+        const size_t roomy = need + need / 16;  // (a slab's particle count creeps up and down with the migration)
+        PM_HIP(hipMalloc(&c->rb_buf, roomy));
+        c->rb_buf_bytes = roomy;
     }
     char *p = (char *)c->rb_buf;
     b->tile_count = (unsigned *)p, b->wg_hist = (unsigned *)(p + t32);
@@ -888,26 +889,71 @@ __device__ __forceinline__ unsigned *sub_counter(unsigned *counts) {
     return counts + (blockIdx.x % PM_NSUB) * PM_SUB_STRIDE;
 }
 
+// (with `dc.dcode`: also the destination counts of pm_rebucket_prepare, in the same pass over the positions)
+struct ScanCount {
+    unsigned char *codes;  // NULL: off
+    unsigned *tile_count, *wg_hist;
+};
+
 __global__ __launch_bounds__(BLK) void straggler_scan_kernel(const float *__restrict__ pos, TileWork work, int n,
                                                              unsigned *__restrict__ keys, unsigned *__restrict__ idx,
-                                                             unsigned subcap, unsigned *__restrict__ counts) {
+                                                             unsigned subcap, unsigned *__restrict__ counts, ScanCount sc) {
     unsigned key;
     int64_t s, e;
     if (!tile_work_item(work, key, s, e)) return;
     __shared__ unsigned s_k[PM_RANGE_CHUNK], s_p[PM_RANGE_CHUNK];  // 32 KB
     __shared__ unsigned s_cnt, s_base;
+    __shared__ unsigned s_hist[27];
     const int tid = threadIdx.x;
     const float nf = (float)n;
+    const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
+    const bool windowed = work.nlaunch != work.ntiles;
+    const int w_lo = work.ti0, w_hi = work.ti0 + (1 << work.lnti);
     if (tid == 0) s_cnt = 0;
+    if (tid < 27) s_hist[tid] = 0;
     __syncthreads();
-    for (int64_t p = s + tid; p < e; p += BLK) {
-        const unsigned k = tile_key_of_pos(pos + 3 * p, nf, n);
-        if (k != key) {
-            const unsigned slot = atomicAdd(&s_cnt, 1u);
-            s_k[slot] = k, s_p[slot] = (unsigned)p;
+    for (int64_t p0 = s; p0 < e; p0 += BLK) {  // (whole waves in step: the ballot below)
+        const int64_t p = p0 + tid;
+        int d = -1;
+        if (p < e) {
+            const unsigned k = tile_key_of_pos(pos + 3 * p, nf, n);
+            if (k != key) {
+                const unsigned slot = atomicAdd(&s_cnt, 1u);
+                s_k[slot] = k, s_p[slot] = (unsigned)p;
+            }
+            if (sc.codes) {
+                // the particle's destination code, made safe (a byte the caller owns) and kept inside the window of
+                // tiles this rank serves (a particle filed under an outside tile would never be served: it is about
+                // to leave the rank anyway)
+                const TileId ta = tile_of_key(k);
+                d = min((int)sc.codes[p], 26);
+                if (windowed) {
+                    const int ti = (ta.ti + d / 9 - 1 + Ti) % Ti;
+                    if (ti < w_lo || ti >= w_hi) d = 13;
+                }
+                if (d != (int)sc.codes[p]) sc.codes[p] = (unsigned char)d;
+                if (k != key) {  // served by the tile it is in, from that tile's list: counted there one by one
+                    atomicAdd(sc.tile_count + tile_key((ta.ti + d / 9 - 1 + Ti) % Ti, (ta.tj + (d / 3) % 3 - 1 + Tj) % Tj,
+                                                       (ta.tk + d % 3 - 1 + Tk) % Tk), 1u);
+                    d = -1;
+                }
+            }
+        }
+        if (sc.codes) {  // nearly everybody stays: one LDS atomic per wave for those (64 lanes on one address serialise)
+            const unsigned long long m = __ballot(d == 13);
+            if (m && (tid & 63) == __ffsll((long long)m) - 1) atomicAdd(&s_hist[13], (unsigned)__popcll(m));
+            if (d >= 0 && d != 13) atomicAdd(&s_hist[d], 1u);
         }
     }
     __syncthreads();
+    if (sc.codes && tid < 27) {
+        const unsigned cnt_d = s_hist[tid];
+        const TileId t = tile_of_key(key);
+        sc.wg_hist[(size_t)blockIdx.x * 27 + tid] = cnt_d;
+        if (cnt_d)
+            atomicAdd(sc.tile_count + tile_key((t.ti + tid / 9 - 1 + Ti) % Ti, (t.tj + (tid / 3) % 3 - 1 + Tj) % Tj,
+                                               (t.tk + tid % 3 - 1 + Tk) % Tk), cnt_d);
+    }
     const unsigned cnt = s_cnt;
     if (cnt == 0) return;
     if (tid == 0) s_base = atomicAdd(sub_counter(counts), cnt);
@@ -1037,9 +1083,9 @@ extern "C" int pm_tile_lists_info(pm_ctx *c, int64_t *stragglers, int64_t *np, i
     return PM_OK;
 }
 
-extern "C" int pm_tile_lists(pm_ctx *c, const float *d_pos, int64_t np) {
+static int tile_lists_impl(pm_ctx *c, const float *d_pos, int64_t np, unsigned char *d_codes) {
     PM_REQUIRE(c && np >= 0, "bad argument");
-    if (c->lists_sticky && d_pos && c->lists_pos == d_pos && c->lists_np == np) {
+    if (!d_codes && c->lists_sticky && d_pos && c->lists_pos == d_pos && c->lists_np == np) {
         c->lists_sticky = 0;  // prepared by pm_kick_drift_wrap_deposit for exactly these positions
         return PM_OK;
     }
@@ -1057,9 +1103,17 @@ extern "C" int pm_tile_lists(pm_ctx *c, const float *d_pos, int64_t np) {
         ListBufs b;
         rc = list_bufs(c, np, ntiles, &b);
         if (rc) return rc;
+        ScanCount sc{nullptr, nullptr, nullptr};
+        if (d_codes) {  // the destination counts of the re-bucketing gather in the same pass (pm_tile_lists_codes)
+            RbBufs rb;
+            rc = rebucket_bufs(c, ntiles, np, &rb);
+            if (rc) return rc;
+            PM_HIP(hipMemsetAsync(rb.tile_count, 0, ((size_t)ntiles + 1) * sizeof(unsigned), c->stream));
+            sc.codes = d_codes, sc.tile_count = rb.tile_count, sc.wg_hist = rb.wg_hist;
+        }
         PM_HIP(hipMemsetAsync(b.counts, 0, PM_NSUB * PM_SUB_STRIDE * sizeof(unsigned), c->stream));
         hipLaunchKernelGGL(straggler_scan_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_pos, work, c->n, b.k_in, b.i_in,
-                           (unsigned)b.subcap, b.counts);
+                           (unsigned)b.subcap, b.counts, sc);
         PM_LAUNCH_CHECK();
         const unsigned *idx = nullptr;
         unsigned listed = 0;
@@ -1068,7 +1122,17 @@ extern "C" int pm_tile_lists(pm_ctx *c, const float *d_pos, int64_t np) {
         c->lists_ptr[2] = idx, c->lists_ptr[3] = b.lstart;
     }
     c->lists_pos = d_pos, c->lists_np = np, c->lists_use = use;
+    if (d_codes && use) c->stay_valid = 1, c->stay_codes = d_codes;
     return PM_OK;
+}
+
+extern "C" int pm_tile_lists(pm_ctx *c, const float *d_pos, int64_t np) { return tile_lists_impl(c, d_pos, np, nullptr); }
+
+// pm_tile_lists + pm_rebucket_prepare in one pass over the positions (the scan that finds the stragglers also counts
+// every particle's destination): what a slab step calls after its migration.
+extern "C" int pm_tile_lists_codes(pm_ctx *c, const float *d_pos, int64_t np, unsigned char *d_codes) {
+    PM_REQUIRE(c && d_pos && d_codes && np > 0 && np < 4294967296LL && c->n >= 16, "bad argument");
+    return tile_lists_impl(c, d_pos, np, d_codes);
 }
 
 // ranges (+ lists) for a tile-range launch: the prepared ones if they are for these positions
@@ -1346,10 +1410,10 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
                 for (int m = 0; m < 3; ++m) veff[m] = v[u][m] + dc.kick * a[u][m];
                 if (in_tile(i, j, k, t)) {
                     deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
-                    if (dc.tile_count) {
+                    if (dc.dcode) {  // (codes without counts: a slab, whose migration comes before the counting)
                         const DestCode dd = dest_of(x[u], veff, dc.dtp, nf, n, t);
                         dc.dcode[p] = (unsigned char)dd.d;
-                        if (dd.d != 13) atomicAdd(&s_hist[dd.d], 1u);
+                        if (dc.tile_count && dd.d != 13) atomicAdd(&s_hist[dd.d], 1u);
                     }
                 } else {
                     const unsigned k2 = tile_key(i >> PM_LI, j >> PM_LJ, k >> PM_LK);
@@ -1359,10 +1423,10 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
                     else
                         append(k2, (unsigned)p);
                     // served by the tile it is in now, from that tile's list: counted at its destination one by one
-                    if (dc.tile_count) {
+                    if (dc.dcode) {
                         const DestCode dd = dest_of(x[u], veff, dc.dtp, nf, n, tile_of_cell(i, j, k));
                         dc.dcode[p] = (unsigned char)dd.d;
-                        atomicAdd(dc.tile_count + dd.key, 1u);
+                        if (dc.tile_count) atomicAdd(dc.tile_count + dd.key, 1u);
                     }
                 }
             }
@@ -1582,6 +1646,8 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
         if (rc) return rc;
         PM_HIP(hipMemsetAsync(rb.tile_count, 0, ((size_t)ntiles + 1) * sizeof(unsigned), c->stream));
         dcount.tile_count = rb.tile_count, dcount.wg_hist = rb.wg_hist, dcount.dcode = rb.dcode;
+    } else if (c->codes_user) {
+        dcount.dcode = c->codes_user;  // pm_set_destination_codes: the codes only, counted later (pm_rebucket_prepare)
     }
     const size_t cells = (size_t)c->slab_nx * c->n * c->n;
     const HaloBuf halo = halo_parts(khalo, c->n);
@@ -1635,7 +1701,7 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
         PM_LAUNCH_CHECK();
     }
     c->lists_pos = pos, c->lists_np = np, c->lists_use = 1, c->lists_sticky = 1, c->stay_valid = count_stay ? 1 : 0;
-    c->stay_dt_pred = c->dt_pred;
+    c->stay_dt_pred = c->dt_pred, c->stay_codes = count_stay ? rb.dcode : nullptr;
     return PM_OK;
 }
 
@@ -2338,20 +2404,117 @@ static int rebucket_order(pm_ctx *c, int order, const float *phi, pm_geom geo, c
     return PM_EINVAL;
 }
 
+// Destination counts from the codes alone (pm_rebucket_prepare): what the fused kick counts on a single GPU, for a
+// stream whose particles have moved between arrays since their codes were recorded (a slab's migration: the code,
+// relative to the tile the particle is in, travels with it).  Same workgroup -> range mapping as the gather; a
+// destination outside the window of tiles this rank serves is turned into "stays" (the particle is about to leave
+// the rank; filed under an outside tile no workgroup would ever serve it).
+__global__ __launch_bounds__(BLK) void rebucket_prepare_kernel(const float *__restrict__ pos, TileWork work, TileLists lists,
+                                                               int n, unsigned char *__restrict__ codes,
+                                                               unsigned *__restrict__ tile_count,
+                                                               unsigned *__restrict__ wg_hist) {
+    unsigned key = 0;
+    int64_t s = 0, e = 0;
+    const bool first = (blockIdx.x + work.boff) < work.nlaunch;
+    const bool has_range = tile_work_item(work, key, s, e);
+    if (!first && !has_range) return;
+    __shared__ unsigned s_hist[27];
+    const int tid = threadIdx.x;
+    const float nf = (float)n;
+    const TileId t = tile_of_key(key);
+    const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
+    const bool windowed = work.nlaunch != work.ntiles;
+    const int w_lo = work.ti0, w_hi = work.ti0 + (1 << work.lnti);
+    if (tid < 27) s_hist[tid] = 0;
+    __syncthreads();
+    // code of particle p, which is in tile ta, made safe (a byte the caller owns) and kept inside the window
+    auto code_of = [&](int64_t p, const TileId &ta) {
+        int d = min((int)codes[p], 26);
+        if (windowed) {
+            const int ti = (ta.ti + d / 9 - 1 + Ti) % Ti;
+            if (ti < w_lo || ti >= w_hi) d = 13;
+        }
+        if (d != (int)codes[p]) codes[p] = (unsigned char)d;
+        return d;
+    };
+    auto key_of = [&](const TileId &ta, int d) {
+        return tile_key((ta.ti + d / 9 - 1 + Ti) % Ti, (ta.tj + (d / 3) % 3 - 1 + Tj) % Tj, (ta.tk + d % 3 - 1 + Tk) % Tk);
+    };
+    if (has_range)
+        for (int64_t p0 = s; p0 < e; p0 += BLK) {  // (whole waves in step: the ballot below)
+            const int64_t p = p0 + tid;
+            int d = -1;  // strangers and the tail: counted by the tile they are in / not at all
+            if (p < e) {
+                const int i = cell_of(pos[3 * p] * nf, n), j = cell_of(pos[3 * p + 1] * nf, n), k = cell_of(pos[3 * p + 2] * nf, n);
+                if (in_tile(i, j, k, t)) d = code_of(p, t);
+            }
+            // nearly everybody stays: one LDS atomic per wave for those (64 lanes on one address serialise)
+            const unsigned long long m = __ballot(d == 13);
+            if (m && (tid & 63) == __ffsll((long long)m) - 1) atomicAdd(&s_hist[13], (unsigned)__popcll(m));
+            if (d >= 0 && d != 13) atomicAdd(&s_hist[d], 1u);
+        }
+    if (first && lists.use) {
+        const unsigned ls = lists.lstart[key], le = lists.lstart[key + 1];
+        for (unsigned l = ls + tid; l < le; l += BLK) {
+            const int64_t p = lists.idx[l];
+            const int i = cell_of(pos[3 * p] * nf, n), j = cell_of(pos[3 * p + 1] * nf, n), k = cell_of(pos[3 * p + 2] * nf, n);
+            const TileId ta = tile_of_cell(i, j, k);
+            atomicAdd(tile_count + key_of(ta, code_of(p, ta)), 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < 27) {
+        const unsigned cnt_d = s_hist[tid];
+        wg_hist[(size_t)(blockIdx.x + work.boff) * 27 + tid] = cnt_d;
+        if (cnt_d) atomicAdd(tile_count + key_of(t, tid), cnt_d);
+    }
+}
+
+// Where the fused kick + drift + deposit of a SLAB records every particle's destination code (one byte per
+// particle, NULL: nowhere); see pm_rebucket_prepare.
+extern "C" int pm_set_destination_codes(pm_ctx *c, unsigned char *d_codes) {
+    PM_REQUIRE(c, "NULL argument");
+    c->codes_user = d_codes;
+    return PM_OK;
+}
+
+// Counts the destinations recorded in d_codes for the particles d_pos / np as they are filed NOW, for the
+// re-bucketing gather that follows.  Needs complete tile lists for exactly d_pos / np (pm_tile_lists).
+extern "C" int pm_rebucket_prepare(pm_ctx *c, const float *d_pos, int64_t np, unsigned char *d_codes) {
+    PM_REQUIRE(c && d_pos && d_codes && np > 0 && np < 4294967296LL, "bad argument");
+    PM_REQUIRE(c->n >= 16, "pm_rebucket_prepare needs n >= 16");
+    PM_REQUIRE(c->lists_pos == d_pos && c->lists_np == np && c->lists_use == 1,
+               "no complete tile lists prepared for these positions (pm_tile_lists on the same d_pos first)");
+    TileWork work;
+    TileLists lists;
+    unsigned nblk = 0;
+    int rc = tile_work_for(c, d_pos, np, &work, &lists, &nblk);
+    if (rc) return rc;
+    RbBufs b;
+    rc = rebucket_bufs(c, work.ntiles, np, &b);
+    if (rc) return rc;
+    PM_HIP(hipMemsetAsync(b.tile_count, 0, ((size_t)work.ntiles + 1) * sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(rebucket_prepare_kernel, dim3(nblk), dim3(BLK), 0, c->stream, d_pos, work, lists, c->n, d_codes,
+                       b.tile_count, b.wg_hist);
+    PM_LAUNCH_CHECK();
+    c->stay_valid = 1, c->stay_codes = d_codes;
+    return PM_OK;
+}
+
 // pm_gradient_interp_kick with the kick, writing position, kicked velocity and acceleration (and the optional
 // tags) of every particle to the *_out arrays in tile order (pmstep.h).  Needs the ranges, lists and stay counts
-// pm_kick_drift_wrap_deposit[_khalo] left prepared for exactly d_pos / np.
-extern "C" int pm_gradient_interp_kick_rebucket(pm_ctx *c, int order, int scheme, const float *d_phi, const float *d_pos,
-                                                const float *d_vel, int64_t np, float half_dt, float *d_pos_out,
-                                                float *d_vel_out, float *d_acc_out, const unsigned *d_id,
-                                                unsigned *d_id_out) {
+// pm_kick_drift_wrap_deposit[_khalo] (or pm_tile_lists + pm_rebucket_prepare) left prepared for exactly d_pos / np.
+static int gradient_interp_kick_rebucket(pm_ctx *c, int order, int scheme, const float *d_phi, pm_geom geo, const float *d_pos,
+                                         const float *d_vel, int64_t np, float half_dt, float *d_pos_out, float *d_vel_out,
+                                         float *d_acc_out, const unsigned *d_id, unsigned *d_id_out) {
     PM_REQUIRE(c && d_phi && d_pos && d_vel && d_pos_out && d_vel_out && d_acc_out && np > 0, "bad argument");
     PM_REQUIRE((!d_id) == (!d_id_out), "d_id / d_id_out must come as a pair");
     PM_REQUIRE(d_pos_out != d_pos && d_vel_out != d_vel, "the re-bucketed arrays are written out of place");
-    PM_REQUIRE(c->n >= 16 && c->slab_nx == c->n && c->tile_nx == c->n, "pm_gradient_interp_kick_rebucket is the single-GPU form");
+    PM_REQUIRE(c->n >= 16, "the re-bucketing gather needs n >= 16");
     PM_REQUIRE(((uintptr_t)d_phi & 15u) == 0, "d_phi must be 16-byte aligned (the tile fill reads float4)");
-    PM_REQUIRE(c->lists_pos == d_pos && c->lists_np == np && c->lists_use == 1 && c->stay_valid,
-               "no stay counts prepared for these positions (pm_kick_drift_wrap_deposit[_khalo] on the same d_pos first)");
+    PM_REQUIRE(c->lists_pos == d_pos && c->lists_np == np && c->lists_use == 1 && c->stay_valid && c->stay_codes,
+               "no stay counts prepared for these positions (pm_kick_drift_wrap_deposit[_khalo] on the same d_pos, or "
+               "pm_tile_lists + pm_rebucket_prepare, first)");
     TileWork work;
     TileLists lists;
     unsigned nblk = 0;
@@ -2372,9 +2535,8 @@ extern "C" int pm_gradient_interp_kick_rebucket(pm_ctx *c, int order, int scheme
     PM_HIP(hipMemsetAsync(c->d_scratch + 8, 0, 2 * sizeof(unsigned), c->stream));
     PM_HIP(hipMemsetAsync(c->d_scratch + 8 + PM_SAMPLE_WORD, 0, 4 * sizeof(unsigned), c->stream));
     Rebucket rb;
-    rb.newstart = table, rb.fill = b.fill, rb.wg_hist = b.wg_hist, rb.dcode = b.dcode;
+    rb.newstart = table, rb.fill = b.fill, rb.wg_hist = b.wg_hist, rb.dcode = c->stay_codes;
     rb.pos_out = d_pos_out, rb.vel_out = d_vel_out, rb.acc_out = d_acc_out, rb.id = d_id, rb.id_out = d_id_out;
-    const pm_geom geo = pm_ctx_geom(c);
     float *vel = const_cast<float *>(d_vel);  // read only by the re-bucketing instantiation
     switch (scheme) {
         case PM_NGP: rc = rebucket_order<PM_NGP>(c, order, d_phi, geo, d_pos, vel, np, half_dt, work, lists, nblk, rb); break;
@@ -2387,6 +2549,30 @@ extern "C" int pm_gradient_interp_kick_rebucket(pm_ctx *c, int order, int scheme
     c->rb_cur ^= 1;
     c->sorted_pos = d_pos_out, c->sorted_np = np, c->sorted_ntiles = ntiles;
     return PM_OK;
+}
+
+extern "C" int pm_gradient_interp_kick_rebucket(pm_ctx *c, int order, int scheme, const float *d_phi, const float *d_pos,
+                                                const float *d_vel, int64_t np, float half_dt, float *d_pos_out,
+                                                float *d_vel_out, float *d_acc_out, const unsigned *d_id,
+                                                unsigned *d_id_out) {
+    PM_REQUIRE(c, "NULL argument");
+    PM_REQUIRE(c->slab_nx == c->n && c->tile_nx == c->n, "pm_gradient_interp_kick_rebucket is the single-GPU form");
+    return gradient_interp_kick_rebucket(c, order, scheme, d_phi, pm_ctx_geom(c), d_pos, d_vel, np, half_dt, d_pos_out, d_vel_out,
+                                         d_acc_out, d_id, d_id_out);
+}
+
+// The same from a potential slab with ghost planes (the geometry arguments of pm_gradient_interp_kick) and for the
+// tiles of the window set by pm_set_tile_window: the form of a slab-decomposed step (order 2, 3, 5 or 7).
+extern "C" int pm_gradient_interp_kick_rebucket_slab(pm_ctx *c, int order, int scheme, const float *d_phi, int nx_phi,
+                                                     int x0_phi, const float *d_pos, const float *d_vel, int64_t np,
+                                                     float half_dt, float *d_pos_out, float *d_vel_out, float *d_acc_out,
+                                                     const unsigned *d_id, unsigned *d_id_out) {
+    PM_REQUIRE(c && nx_phi >= 1 && nx_phi <= c->n, "bad potential slab");
+    PM_REQUIRE(order != 0, "the slab form differentiates the potential (order 2, 3, 5 or 7)");
+    pm_geom geo = pm_ctx_geom(c);  // tiles are filed on the full mesh; phi is the (slab + ghosts) array given
+    geo.nx = nx_phi, geo.x0 = ((x0_phi % c->n) + c->n) % c->n;
+    return gradient_interp_kick_rebucket(c, order, scheme, d_phi, geo, d_pos, d_vel, np, half_dt, d_pos_out, d_vel_out,
+                                         d_acc_out, d_id, d_id_out);
 }
 
 // The caller's guess of the NEXT step's dt, used by pm_kick_drift_wrap_deposit[_khalo] to count and by

@@ -14,6 +14,57 @@ from . import _lib as L
 from . import solver, utils
 
 
+def predict_next_step(dt, dt1, dt2, tables, param, t_snap_next, meanabs) -> None:
+    """Guesses for the incremental re-sort, left in param["_dt_pred"] (the NEXT step's dt) and
+    param["_acc_scale_pred"] (growth of the accelerations over the step about to be taken); `meanabs`: mean |a_x| of
+    the current accelerations (utils.fused_acc_meanabs) or None.  Shared by integrate() and the slab step."""
+    # Guess of the NEXT step's dt for the incremental re-sort (pmstep.h: pm_set_predicted_dt): the three criteria
+    # again -- the scale-factor one at the time this step ends (known exactly), the two CFL ones extrapolated
+    # with their own trends -- and the next snapshot's clipping.  It anticipates the step on which the binding
+    # criterion changes, which an extrapolation of dt itself gets wrong by tens of per cent (3 % of the particles
+    # misfiled, one 60 ms step at 1024^3).
+    # First, how much the accelerations grow over this step (the filing uses scale * a_old for the a_new it
+    # cannot know, pmstep.h: pm_set_predicted_acc_scale): the ratio of the mean |a_x| over the last step, to the power of the
+    # ratio of the step lengths.  In the linear regime a_new / a_old is the same number for every particle and
+    # this removes most of the misfilings (tools/exp_predict_tiles.py: 0.42 % -> 0.08 % at the longest steps).
+    ms = meanabs
+    ms_last, dt_between = param.get("_acc_meanabs_last"), param.get("_dt_last")
+    scale = grown = 1.0  # (grown: a_n / a_{n-1}, over the last step)
+    if ms and ms_last and dt_between and dt_between > 0 and dt > 0:
+        grown = float(ms / ms_last)
+        scale = grown ** min(2.0, float(dt) / dt_between)
+        scale = min(2.0, max(0.5, scale)) if np.isfinite(scale) else 1.0
+        grown = min(2.0, max(0.5, grown)) if np.isfinite(grown) else 1.0
+    param["_acc_meanabs_last"], param["_acc_scale_pred"] = ms, scale
+    try:
+        t_end = param["t"] + dt
+        a_end = float(np.exp(tables[0](t_end)))
+        f = 1.0 + 0.01 * param["max_aexp_stepping"]
+        dt3_next = float(tables[1](np.log(f * a_end)) - tables[1](np.log(a_end)))
+        # (each CFL criterion with its own trend over the step about to be taken, h = dt, from its change over
+        # the last one, h_last: max|a| -- dt1 ~ max|a|^-1/2 -- grows geometrically in time; max|v| -- dt2 ~
+        # 1 / max|v| -- by what the kicks add, i.e. in proportion to the time and to the accelerations: extrapolating
+        # dt2's RATIO instead undershoots by 4-10 % on the steps after the velocity criterion takes over, where h
+        # shrinks quickly, and time alone overshoots as much.
+        # Both within [0.5, 1.5] of the present value.)
+        last = param.get("_dt_cfl_last") or (float(dt1), float(dt2))
+        param["_dt_cfl_last"] = (float(dt1), float(dt2))
+        h_last = param.get("_dt_last")
+        r = min(2.0, float(dt) / h_last) if (h_last and h_last > 0) else 1.0
+        clamp = lambda x: min(1.5, max(0.5, x)) if np.isfinite(x) else 1.0  # noqa: E731
+        f1 = clamp((float(dt1) / last[0]) ** r) if last[0] > 0 and dt1 > 0 else 1.0
+        # (a step h adds h (a_before + a_after) / 2 to a velocity: the next increment of max|v| over the last one)
+        u, ul = 1.0 / float(dt2), 1.0 / last[1]
+        u_next = u + (u - ul) * r * grown * (1.0 + scale) / (1.0 + grown)
+        f2 = clamp(u / u_next) if u_next > 0 else 1.5
+        guess = min(float(dt1) * f1, float(dt2) * f2, dt3_next)
+        if t_end < t_snap_next:
+            guess = min(guess, float(t_snap_next) - t_end)
+        param["_dt_pred"] = guess if np.isfinite(guess) and guess > 0 else None
+    except Exception:  # (tables that cannot be evaluated ahead: fall back to the trend of dt)
+        param["_dt_pred"] = None
+
+
 def integrate(position, velocity, acceleration, potential, additional_field, tables: List, param,
               t_snap_next=np.float32(0)):
     """One step: dt = min(free-fall, CFL, scale-factor criterion), then leapfrog or euler."""
@@ -32,51 +83,8 @@ def integrate(position, velocity, acceleration, potential, additional_field, tab
     else:
         param["write_snapshot"] = False
     if param.get("rebucket_straggler_fraction") is not None:
-        # Guess of the NEXT step's dt for the incremental re-sort (pmstep.h: pm_set_predicted_dt): the three criteria
-        # again -- the scale-factor one at the time this step ends (known exactly), the two CFL ones extrapolated
-        # with their own trends -- and the next snapshot's clipping.  It anticipates the step on which the binding
-        # criterion changes, which an extrapolation of dt itself gets wrong by tens of per cent (3 % of the particles
-        # misfiled, one 60 ms step at 1024^3).
-        # First, how much the accelerations grow over this step (the filing uses scale * a_old for the a_new it
-        # cannot know, pmstep.h: pm_set_predicted_acc_scale): the ratio of the mean |a_x| over the last step, to the power of the
-        # ratio of the step lengths.  In the linear regime a_new / a_old is the same number for every particle and
-        # this removes most of the misfilings (tools/exp_predict_tiles.py: 0.42 % -> 0.08 % at the longest steps).
-        ms = utils.fused_acc_meanabs(acceleration) if L.is_device_array(acceleration) else None
-        ms_last, dt_between = param.get("_acc_meanabs_last"), param.get("_dt_last")
-        scale = grown = 1.0  # (grown: a_n / a_{n-1}, over the last step)
-        if ms and ms_last and dt_between and dt_between > 0 and dt > 0:
-            grown = float(ms / ms_last)
-            scale = grown ** min(2.0, float(dt) / dt_between)
-            scale = min(2.0, max(0.5, scale)) if np.isfinite(scale) else 1.0
-            grown = min(2.0, max(0.5, grown)) if np.isfinite(grown) else 1.0
-        param["_acc_meanabs_last"], param["_acc_scale_pred"] = ms, scale
-        try:
-            t_end = param["t"] + dt
-            a_end = float(np.exp(tables[0](t_end)))
-            f = 1.0 + 0.01 * param["max_aexp_stepping"]
-            dt3_next = float(tables[1](np.log(f * a_end)) - tables[1](np.log(a_end)))
-            # (each CFL criterion with its own trend over the step about to be taken, h = dt, from its change over
-            # the last one, h_last: max|a| -- dt1 ~ max|a|^-1/2 -- grows geometrically in time; max|v| -- dt2 ~
-            # 1 / max|v| -- by what the kicks add, i.e. in proportion to the time and to the accelerations: extrapolating
-            # dt2's RATIO instead undershoots by 4-10 % on the steps after the velocity criterion takes over, where h
-            # shrinks quickly, and time alone overshoots as much.
-            # Both within [0.5, 1.5] of the present value.)
-            last = param.get("_dt_cfl_last") or (float(dt1), float(dt2))
-            param["_dt_cfl_last"] = (float(dt1), float(dt2))
-            h_last = param.get("_dt_last")
-            r = min(2.0, float(dt) / h_last) if (h_last and h_last > 0) else 1.0
-            clamp = lambda x: min(1.5, max(0.5, x)) if np.isfinite(x) else 1.0  # noqa: E731
-            f1 = clamp((float(dt1) / last[0]) ** r) if last[0] > 0 and dt1 > 0 else 1.0
-            # (a step h adds h (a_before + a_after) / 2 to a velocity: the next increment of max|v| over the last one)
-            u, ul = 1.0 / float(dt2), 1.0 / last[1]
-            u_next = u + (u - ul) * r * grown * (1.0 + scale) / (1.0 + grown)
-            f2 = clamp(u / u_next) if u_next > 0 else 1.5
-            guess = min(float(dt1) * f1, float(dt2) * f2, dt3_next)
-            if t_end < t_snap_next:
-                guess = min(guess, float(t_snap_next) - t_end)
-            param["_dt_pred"] = guess if np.isfinite(guess) and guess > 0 else None
-        except Exception:  # (tables that cannot be evaluated ahead: fall back to the trend of dt)
-            param["_dt_pred"] = None
+        predict_next_step(dt, dt1, dt2, tables, param, t_snap_next,
+                          utils.fused_acc_meanabs(acceleration) if L.is_device_array(acceleration) else None)
     logging.info(f"Conditions: velocity {dt1=}, acceleration {dt2=}, scale factor {dt3=}")
     INTEGRATOR = param["integrator"].casefold()
     if INTEGRATOR == "leapfrog":

@@ -147,19 +147,55 @@ class HipOps:
                           float(half_dt))
         finally:
             self._window(False)
-        a, v = C.c_float(0), C.c_float(0)
+        a, v, m = C.c_float(0), C.c_float(0), C.c_double(0)
         self.ctx.call("pm_last_maxabs", C.byref(a), C.byref(v))
+        self.ctx.call("pm_last_acc_meanabs", C.byref(m))
+        self.last_meanabs = float(m.value) or None
         return out, float(a.value), float(v.value)
 
-    def tile_lists(self, pos):
-        """Tile ranges + straggler lists for these positions (pmstep.h: pm_tile_lists); None drops them."""
+    def set_destination_codes(self, codes):
+        """Where the next fused kick + deposit records every particle's destination code (uint8 [Np]); None: off."""
+        self.ctx.call("pm_set_destination_codes", L.ptr(codes) if codes is not None else None)
+
+    def set_prediction(self, dt_next, acc_scale):
+        self.ctx.call("pm_set_predicted_dt", float(np.float32(dt_next)))
+        self.ctx.call("pm_set_predicted_acc_scale", float(np.float32(acc_scale)))
+
+    def gradient_interp_kick_rebucket(self, order, scheme, phi_ext, x0_phi, pos, vel, half_dt, codes, pos_out, vel_out,
+                                      acc_out, ids=None, ids_out=None, counted=False):
+        """gradient_interp_kick writing position, kicked velocity and acceleration out of place in tile order
+        (pmstep.h: pm_rebucket_prepare + pm_gradient_interp_kick_rebucket_slab); needs the lists of tile_lists(pos);
+        counted: tile_lists(pos, codes) has counted the destinations already."""
+        self._window(True)
+        try:
+            if not counted:
+                self.ctx.call("pm_rebucket_prepare", L.ptr(pos), pos.shape[0], L.ptr(codes))
+            self.ctx.call("pm_gradient_interp_kick_rebucket_slab", int(order), scheme, L.ptr(phi_ext), phi_ext.shape[0],
+                          int(x0_phi), L.ptr(pos), L.ptr(vel), pos.shape[0], float(half_dt), L.ptr(pos_out), L.ptr(vel_out),
+                          L.ptr(acc_out), L.ptr(ids), L.ptr(ids_out))
+            self._lists_held = False  # (the gather dropped them: they described the old layout)
+        finally:
+            self._window(False)
+        a, v, m = C.c_float(0), C.c_float(0), C.c_double(0)
+        self.ctx.call("pm_last_maxabs", C.byref(a), C.byref(v))
+        self.ctx.call("pm_last_acc_meanabs", C.byref(m))
+        self.last_meanabs = float(m.value) or None
+        return float(a.value), float(v.value)
+
+    def tile_lists(self, pos, codes=None):
+        """Tile ranges + straggler lists for these positions (pmstep.h: pm_tile_lists); None drops them.  `codes`:
+        the particles' destination codes -- the same pass then also counts them for the re-bucketing gather
+        (pm_tile_lists_codes)."""
         if pos is None:
             self.ctx.call("pm_tile_lists", None, 0)
             self._lists_held = False
             self._window(False)
         else:
             self._window(True)
-            self.ctx.call("pm_tile_lists", L.ptr(pos), pos.shape[0])
+            if codes is not None:
+                self.ctx.call("pm_tile_lists_codes", L.ptr(pos), pos.shape[0], L.ptr(codes))
+            else:
+                self.ctx.call("pm_tile_lists", L.ptr(pos), pos.shape[0])
             self._lists_held = True
 
     def lists_complete(self) -> bool:
@@ -355,6 +391,7 @@ def all_reduce_max(values: List[float], device) -> List[float]:
 _FUSE_SLAB_DEPOSIT = True  # False: kick_drift_wrap, migration, then a separate deposit
 _PIPELINE_FFT = True    # False: the slab FFT exchanges the whole spectrum in one all-to-all each way
 _SLAB_MULTIGRID = True  # False: multigrid / MOND under slabs all-gather the density and solve replicated
+_SLAB_REBUCKET = True   # False: the gather writes in place and the particle stream of a rank is never re-sorted
 
 
 class Slab:
@@ -427,11 +464,22 @@ class Slab:
             b = torch.empty((cap,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
             b[:n] = a
             bufs.append(b)
-        self._store = {"bufs": bufs, "n": n, "cap": cap}
+        codes = self._rebucket_on(position)
+        if codes:  # destination codes of the incremental re-sort: one more per-particle array that migrates (13 = stays)
+            bufs.append(torch.full((cap,), 13, dtype=torch.uint8, device=position.device))
+        self._store = {"bufs": bufs, "n": n, "cap": cap, "codes": codes, "out": None}
+
+    def _rebucket_on(self, position) -> bool:
+        return bool(_SLAB_REBUCKET and hasattr(self.ops, "gradient_interp_kick_rebucket") and self.n >= 16
+                    and getattr(position, "is_cuda", False) and 0 < position.shape[0] < 2**32)
 
     def _views(self):
         st = self._store
         v = [b[:st["n"]] for b in st["bufs"]]
+        if st.get("codes"):
+            self._codes, v = v[-1], v[:-1]
+        else:
+            self._codes = None
         self.carry = tuple(v[2:])
         return v[0], v[1]
 
@@ -445,7 +493,7 @@ class Slab:
             nb = torch.empty((cap,) + tuple(b.shape[1:]), dtype=b.dtype, device=b.device)
             nb[:st["n"]] = b[:st["n"]]
             new.append(nb)
-        st["bufs"], st["cap"] = new, cap
+        st["bufs"], st["cap"], st["out"] = new, cap, None
 
     def _migrate_leavers(self, leave):
         """Send the particles at (sorted) indices `leave` to their owners and file the arrivals into the
@@ -530,10 +578,14 @@ class Slab:
             return self._pm_replicated_grid(position, param, potential, additional_field, tables, kick, scheme)
         param["save_pk"] = False
         param["parametrized_mu_z"] = np.float32(1)
+        # (with a second kick to apply and the rank's own arrays: the gather will re-bucket, and the scan that makes the
+        # lists counts the destinations in the same pass)
+        codes = self._codes_for(position, kick)
+        self._codes_counted = codes is not None
         if grid_solvers:
             lists = getattr(ops, "tile_lists", None)
             if lists is not None:
-                lists(position)
+                lists(position, codes) if codes is not None else lists(position)
             try:
                 return self._pm_decomposed_grid_solvers(position, param, potential, additional_field, tables, kick,
                                                         scheme)
@@ -543,12 +595,22 @@ class Slab:
 
         lists = getattr(ops, "tile_lists", None)
         if lists is not None:
-            lists(position)
+            lists(position, codes) if codes is not None else lists(position)
         try:
             return self._pm_decomposed(position, param, scheme, kick)
         finally:
             if lists is not None:
                 lists(None)
+
+    def _codes_for(self, position, kick):
+        """The destination codes of `position` if the gather of this pm() can re-bucket: the rank's own capacity-backed
+        arrays with their codes, and a kick to apply."""
+        st = getattr(self, "_store", None)
+        if (kick is None or kick[0] is None or st is None or not st.get("codes") or getattr(self, "_codes", None) is None
+                or position.shape[0] != st["n"] or st["n"] == 0 or position.data_ptr() != st["bufs"][0].data_ptr()
+                or kick[0].data_ptr() != st["bufs"][1].data_ptr() or self._codes.shape[0] != st["n"]):
+            return None
+        return self._codes
 
     def _deposit_folded(self, position, scheme):
         """Density on the owned planes [nx, n, n] (a view into the deposit's [nx + 2W] array): deposit with W
@@ -590,7 +652,31 @@ class Slab:
         fused = hasattr(ops, "gradient_interp_kick") and n >= 16
         if fused and hasattr(ops, "lists_complete") and not ops.lists_complete():
             fused = False  # more stragglers than the lists hold: force grid + order-independent gather
-        if fused:  # the gather differentiates its own LDS tile
+        st = getattr(self, "_store", None)
+        if fused and self._codes_for(position, kick) is not None:
+            # Incremental re-sort (on a slab): the gather writes position, kicked velocity and
+            # acceleration out of place, every particle into the range of the tile the fused kick expected it in after
+            # the next drift (codes recorded before the migration, which carried them along), so a rank's stream
+            # stays tile-sorted without ever being sorted; the two sets of capacity-backed arrays trade places.
+            npart, cap = st["n"], st["cap"]
+            if st["out"] is None:
+                st["out"] = [torch.empty_like(st["bufs"][0]), torch.empty_like(st["bufs"][1])]
+            acc = torch.empty((npart, 3), dtype=torch.float32, device=position.device)
+            ids = ids_out = None
+            if self.carry:
+                ids = torch.arange(npart, dtype=torch.int32, device=position.device)
+                ids_out = torch.empty_like(ids)
+            ma, mv = ops.gradient_interp_kick_rebucket(order, scheme, phi_ext, self.x_lo - H, position, vel, half_dt,
+                                                       self._codes, st["out"][0][:npart], st["out"][1][:npart], acc,
+                                                       ids, ids_out, counted=getattr(self, "_codes_counted", False))
+            old = [st["bufs"][0], st["bufs"][1]]
+            st["bufs"][0], st["bufs"][1], st["out"] = st["out"][0], st["out"][1], old
+            if self.carry:  # the caller's per-particle arrays follow the permutation
+                perm = ids_out.long()
+                for b in st["bufs"][2:2 + len(self.carry)]:
+                    b[:npart] = b[:npart][perm]
+            self._rebucketed = True
+        elif fused:  # the gather differentiates its own LDS tile
             acc, ma, mv = ops.gradient_interp_kick(order, scheme, phi_ext, self.x_lo - H, position, vel, half_dt)
         else:
             force = ops.gradient(order, phi_ext, self.x_lo - H, nx + 2, self.x_lo - 1)
@@ -870,18 +956,37 @@ class Slab:
                 reach = (float(dt) * float(mv) + 0.5 * float(dt) ** 2 * float(ma)) * self.n + 1.5
                 if reach < 4.0:
                     W = int(np.ceil(reach))
+            codes = getattr(self, "_codes", None)
             if W > 0:
-                rho_ext, leave = ops.kick_drift_wrap_deposit(_SCHEME[MASS_SCHEME], position, velocity, acceleration,
-                                                             half_dt, np.float32(dt), x_lo, x_hi, self.nx + 2 * W,
-                                                             self.x_lo - W)
+                if codes is not None:
+                    # where every particle is expected after the NEXT drift (integration.predict_next_step; the
+                    # growth of the accelerations from this rank's own sample): recorded by the fused kick
+                    from . import integration
+
+                    integration.predict_next_step(dt, dt1, dt2, tables, param, t_snap_next, getattr(ops, "last_meanabs", None))
+                    ops.set_prediction(param.get("_dt_pred") or dt, param.get("_acc_scale_pred", 1.0))
+                    ops.set_destination_codes(codes)
+                try:
+                    rho_ext, leave = ops.kick_drift_wrap_deposit(_SCHEME[MASS_SCHEME], position, velocity, acceleration,
+                                                                 half_dt, np.float32(dt), x_lo, x_hi, self.nx + 2 * W,
+                                                                 self.x_lo - W)
+                finally:
+                    if codes is not None:
+                        ops.set_destination_codes(None)
+                param["_dt_last"] = float(dt)
                 self._predeposited = (rho_ext, W)
             else:
                 leave = ops.kick_drift_wrap(position, velocity, acceleration, half_dt, np.float32(dt), x_lo, x_hi)
+                if codes is not None:
+                    codes.fill_(13)  # nothing recorded: every particle is filed under the tile it is in
             advance_clock()
             self._migrate_leavers(leave)
             position, velocity = self._views()
+            self._rebucketed = False
             acceleration, potential, additional_field = self.pm(position, param, potential, additional_field, tables,
                                                                 kick=(velocity, half_dt))
+            if self._rebucketed:  # the gather wrote the other set of arrays
+                position, velocity = self._views()
         else:
             # drift with the old velocity, then kick with the old acceleration (integration.py:178-183)
             leave = ops.kick_drift_wrap(position, velocity, acceleration, np.float32(0), np.float32(dt), x_lo, x_hi)

@@ -33,7 +33,7 @@ def main():
              "nsteps": 0}
     if len(sys.argv) > 8:
         param["integrator"] = sys.argv[8]
-    if len(sys.argv) > 10:  # "mond" / "fr" / "newton_mg" [+ "_replicated": all-gathered density, replicated grid solve]
+    if len(sys.argv) > 10 and sys.argv[10] != "newton":  # "mond" / "fr" / "newton_mg" [+ "_replicated": all-gathered density, replicated grid solve]
         kind = sys.argv[10]
         if kind.endswith("_replicated"):
             kind = kind[: -len("_replicated")]
@@ -59,11 +59,21 @@ def main():
     mine = (np.floor(pos[:, 0] * world).astype(int).clip(0, world - 1) == rank)
     p = torch.from_numpy(pos[mine].copy()).to(dev)
     v = torch.from_numpy(vel[mine].copy()).to(dev)
-    s.carry = (torch.from_numpy(np.nonzero(mine)[0].astype(np.int64)).to(dev),)  # particle IDs migrate too
+    ids = torch.from_numpy(np.nonzero(mine)[0].astype(np.int64)).to(dev)
+    if len(sys.argv) > 11 and sys.argv[11] == "sorted" and backend == "hip":  # a Morton-sorted stream, as bench.py starts from
+        order = []
+        p, v = amd_utils.reorder_particles(p, v, _order_out=order)
+        ids = ids[order[0]].contiguous()
+    s.carry = (ids,)  # particle IDs migrate too
     acc, phi, extra = s.pm(p, param, tables=tables)
     out = {"acc0": acc.cpu().numpy(), "phi0": phi.cpu().numpy(), "id0": s.carry[0].cpu().numpy()}
+    rebucketed, fracs = 0, []
     for _ in range(steps):
         p, v, acc, phi, extra = s.integrate(p, v, acc, phi, extra, tables, param, np.float32(1))
+        rebucketed += int(bool(getattr(s, "_rebucketed", False)))
+        if backend == "hip":  # stragglers the gather of this step found in the rank's stream (after the migration)
+            fracs.append(amd_utils.straggler_fraction(n)[0] or 0.0)
+    out["rebucketed"], out["stragglers"] = np.int64(rebucketed), np.asarray(fracs, dtype=np.float64)
     out["id"] = s.carry[0].cpu().numpy()
     out.update(pos=p.cpu().numpy(), vel=v.cpu().numpy(), acc=acc.cpu().numpy(), phi=phi.cpu().numpy(),
                t=param["t"], aexp=param["aexp"])

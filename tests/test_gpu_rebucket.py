@@ -212,3 +212,62 @@ def test_acc_meanabs_sample_and_predicted_scale():
         if k == 0:
             d = np.minimum(d, 1 - d)
         assert d.max() <= 2e-4 * max(1e-30, np.abs(out[1.0][k]).max())
+
+
+@pytest.mark.parametrize("fused_scan", [False, True])
+def test_rebucket_from_codes_alone(fused_scan):
+    """The slab form of the re-sort on one GPU: destination codes in a caller's array (here: some "stay", some "one
+    tile up in y"), counted by pm_rebucket_prepare -- or by pm_tile_lists_codes, in the pass that makes the lists --
+    for a stream that is NOT tile-sorted (a fifth of it shuffled: those are served from the lists), then
+    pm_gradient_interp_kick_rebucket_slab.  Every particle must land in the range of the tile its code names, with
+    the acceleration and kicked velocity pm_gradient_interp_kick gives it."""
+    import torch
+
+    from pysco_amd import _lib as L
+    from pysco_amd import mesh, utils
+
+    n, npart = 64, 200_000
+    L._ctxs.clear()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    pos = torch.rand((npart, 3), generator=g, device="cuda")
+    vel = torch.rand((npart, 3), generator=g, device="cuda") - 0.5
+    pos, vel = utils.reorder_particles(pos, vel)
+    swap = torch.randperm(npart, generator=g, device="cuda")[: npart // 5]
+    pos[swap], vel[swap] = pos[swap.flip(0)].clone(), vel[swap.flip(0)].clone()  # strangers in their ranges
+    phi = torch.rand((n, n, n), generator=g, device="cuda")
+    codes = torch.full((npart,), 13, dtype=torch.uint8, device="cuda")
+    up = torch.rand(npart, generator=g, device="cuda") < 0.3
+    codes[up] = 13 + 3  # dtj = +1
+    codes[:7] = 200     # rubbish is read as 26, never out of bounds
+    half_dt = 0.01
+    ref_vel = vel.clone()
+    ref_acc = mesh.derivative_interp_vec_kick("tsc", phi, 5, pos, ref_vel, half_dt) if hasattr(mesh, "derivative_interp_vec_kick") else None
+    ctx = L.context(n)
+    if fused_scan:
+        ctx.call("pm_tile_lists_codes", L.ptr(pos), npart, L.ptr(codes))
+    else:
+        ctx.call("pm_tile_lists", L.ptr(pos), npart)
+        ctx.call("pm_rebucket_prepare", L.ptr(pos), npart, L.ptr(codes))
+    pos_out, vel_out, acc_out = torch.empty_like(pos), torch.empty_like(vel), torch.empty_like(pos)
+    ids = torch.arange(npart, dtype=torch.int32, device="cuda")
+    ids_out = torch.empty_like(ids)
+    ctx.call("pm_gradient_interp_kick_rebucket_slab", 5, L.TSC, L.ptr(phi), n, 0, L.ptr(pos), L.ptr(vel), npart,
+             float(np.float32(half_dt)), L.ptr(pos_out), L.ptr(vel_out), L.ptr(acc_out), L.ptr(ids), L.ptr(ids_out))
+    torch.cuda.synchronize()
+    perm = ids_out.long().cpu().numpy()
+    assert np.array_equal(np.sort(perm), np.arange(npart))
+    assert torch.equal(pos_out.cpu(), pos.cpu()[perm])
+    # destination tiles in stream order must be non-decreasing, and equal to "own tile + code"
+    c = np.minimum(codes.cpu().numpy().astype(int), 26)[perm]
+    cell = np.minimum((pos_out.cpu().numpy() * np.float32(n)).astype(np.int64), n - 1)
+    ti, tj, tk = cell[:, 0] >> 3, cell[:, 1] >> 4, cell[:, 2] >> 4
+    T = (n >> 3, n >> 4, n >> 4)
+    di, dj, dk = c // 9 - 1, (c // 3) % 3 - 1, c % 3 - 1
+
+    corner = np.stack([((ti + di) % T[0]) * 8, ((tj + dj) % T[1]) * 16, ((tk + dk) % T[2]) * 16], axis=1)
+    dest = _tile_keys(((corner + 0.5) / n).astype(np.float32), n)  # key of the tile every particle was sent to
+    assert (np.diff(dest) >= 0).all()
+    if ref_acc is not None:
+        assert torch.equal(acc_out.cpu(), ref_acc.cpu()[perm])
+        assert torch.equal(vel_out.cpu(), ref_vel.cpu()[perm])
