@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); 6.29e12 measured float4 copy
+HBM_COPY = 6.3e12    # what a float4 copy kernel sustains (torch add / fill: 6.0-6.9 TB/s here)
 B_ALG_PER_PARTICLE = 200.0  # fused-ideal bytes per particle-step, fp32, Np = N^3
 
 
@@ -310,6 +311,10 @@ def main():
         pm_main.reserve_step_buffers(pos)
 
     resort_at = int(os.environ.get("PMSTEP_EXP_RESORT_AT", "0"))
+    if os.environ.get("PMSTEP_VCYCLE_GRAPHS") == "0":  # development A/B
+        from pysco_amd import multigrid as _mg
+
+        _mg._VCYCLE_GRAPHS = False
 
     def step(pos, vel, acc, phi, extra):
         param["nsteps"] += 1
@@ -382,6 +387,8 @@ def main():
                    "pm_fftp_z_forward": 8.0 * cells, "pm_fftp_z_inverse": 8.0 * cells,
                    "pm_fftp_y_forward": 2.0 * spec / 4, "pm_fftp_y_inverse": 2.0 * spec / 4,
                    "pm_fftp_xgreen_kz": 2.0 * spec / 4,
+                   "pm_gradient_interp_kick_rebucket_slab": 48.0 * npart / world + 4.0 * cells,
+                   "pm_tile_lists_codes": 13.0 * npart / world, "pm_tile_lists": 12.0 * npart / world,
                    "pm_kick_drift_wrap_slab": 60.0 * npart / world,
                    "pm_kick_drift_wrap_deposit_slab": 60.0 * npart / world + 4.0 * cells})
     table = []
@@ -410,6 +417,18 @@ def main():
                 "alg_bytes_per_launch": ab.get(dom["stage"], alg_bytes_level(dom["stage"])),
                 "step_frac": round(B_ALG_PER_PARTICLE * npart / (wall / args.steps) / (HBM_PEAK * world), 4),
                 "step_alg_bytes_per_particle": B_ALG_PER_PARTICLE, "stages": table}
+    # the same two figures against what a float4 copy reaches on this GPU (SURVEY.md section 8d asks for both
+    # denominators), and the dominant stage's HBM-side rate from the counters
+    roofline["peak_copy"] = HBM_COPY / 1e9
+    roofline["frac_of_copy"] = round(achieved / (HBM_COPY / 1e9), 4)
+    roofline["step_frac_of_copy"] = round(B_ALG_PER_PARTICLE * npart / (wall / args.steps) / (HBM_COPY * world), 4)
+    if traffic:
+        roofline["traffic_GBps"] = round(traffic / (dom["avg_ms"] * 1e-3) / 1e9, 1)
+    if dom["stage"].startswith("pm_gradient_interp_kick_rebucket"):
+        # (the stage also does the re-sort: the position written again in tile order and the destination byte read
+        # are compulsory traffic of THAT job, 13 B per particle; `frac` above counts the gather's bytes only)
+        with_resort = roofline["alg_bytes_per_launch"] + 13.0 * npart / world
+        roofline["frac_with_resort_bytes"] = round(with_resort / (dom["avg_ms"] * 1e-3) / HBM_PEAK, 4)
 
     solver_name = {"newton_fft": "Newtonian TSC+FFT", "newton_mg": "Newtonian TSC + multigrid", "fr": "f(R) n=1 FAS multigrid",
                    "mond": "QUMOND simple, multigrid"}[args.config]

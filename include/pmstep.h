@@ -295,6 +295,12 @@ int pm_set_fused_sweep(pm_ctx *ctx, int on);
  * only Npre sweeps), added prolongation, Npost sweeps; omega = 1.25.  Same kernels, same bits as the per-operator
  * entry points called in that order.  n >= 8. */
 int pm_lap_vcycle(pm_ctx *ctx, float *d_x, const float *d_b, int n, int npre, int npost);
+/* A cycle is 40-90 small launches (the levels below 64^3 are launch-bound): pm_lap_vcycle captures the sequence as a
+ * hipGraph the first time it sees a set of arguments and replays it when the same arrays come back (8 graphs kept per
+ * context; switches itself off if the caller's arrays keep changing or any graph call fails).  mode 0: plain launches.
+ * pm_vcycle_graph_stats: cycles replayed / captured so far.  No reference counterpart. */
+int pm_set_vcycle_graphs(pm_ctx *ctx, int mode);
+int pm_vcycle_graph_stats(pm_ctx *ctx, unsigned *replayed, unsigned *captured);
 /* laplacian.gauss_seidel :844: one red + one black sweep with over-relaxation f_relax, in place */
 int pm_lap_gauss_seidel(pm_ctx *ctx, float *d_x, const float *d_b, int n, float f_relax);
 /* cubic.operator :23 (d_rhs NULL) / cubic.residual_with_rhs :90 */

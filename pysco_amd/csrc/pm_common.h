@@ -115,6 +115,12 @@ struct Stencil {
         }
     }
 };
+
+// Small device -> host read-back on the context's stream, synchronised: through pinned memory (a copy into pageable
+// memory is staged by the runtime and costs 10-20 us more; the step does five of these at 128^3).
+int pm_read_back(pm_ctx *c, void *h_dst, const void *d_src, size_t bytes);
+constexpr size_t PM_PINNED_BYTES = 16384;
+
 #endif
 
 struct pm_ctx {
@@ -175,6 +181,20 @@ struct pm_ctx {
     int mg_fused_sweep;  // 1 (default): single-pass red + black sweep for n >= 256 (pm_set_fused_sweep; tests compare)
     void *mg_buf;        // scratch grids of pm_lap_vcycle (grown on demand)
     size_t mg_buf_bytes;
+    // captured V-cycles (pm_lap_vcycle, pm_fr_vcycle): a cycle is 40-90 small launches, replayed as one hipGraph when the
+    // same arrays come back (keyed by every argument and the arena)
+    struct VcGraph {
+        const void *x, *b, *arena;
+        int kind, n, npre, npost;
+        float q;
+        hipGraphExec_t exec;
+        unsigned long long last_use;
+    } vc_graphs[8];
+    int vc_graph_mode;           // 1: capture and replay, 0: plain launches (also after any capture failure)
+    unsigned vc_hits, vc_misses;
+    unsigned long long vc_clock;
+    hipStream_t capture_stream;  // captures happen here (the caller's stream may be the legacy default stream)
+    void *h_pinned;              // 16 KB of pinned host memory: landing zone of the small read-backs (pm_read_back)
     // sort workspace (grown on demand)
     void *sort_tmp;
     size_t sort_tmp_bytes;

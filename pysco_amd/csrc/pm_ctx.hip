@@ -53,6 +53,8 @@ extern "C" int pm_ctx_create(pm_ctx **out, int n, void *stream) {
     pm_ctx *c = new pm_ctx();
     memset(c, 0, sizeof(*c));
     c->acc_scale_pred = 1.0f;
+    c->vc_graph_mode = 1;
+    if (hipHostMalloc(&c->h_pinned, PM_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) c->h_pinned = nullptr, (void)hipGetLastError();
     c->n = n;
     c->log2n = __builtin_ctz((unsigned)n);
     c->slab_nx = n;
@@ -95,6 +97,10 @@ extern "C" int pm_ctx_destroy(pm_ctx *c) {
     if (c->list_buf) hipFree(c->list_buf);
     if (c->rb_buf) hipFree(c->rb_buf);
     if (c->mg_buf) hipFree(c->mg_buf);
+    for (auto &g : c->vc_graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    if (c->capture_stream) hipStreamDestroy(c->capture_stream);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
     hipFree(c->d_scratch);
     hipFree(c->d_tab);
     hipFree(c->d_hist);
@@ -113,6 +119,14 @@ extern "C" int pm_ctx_set_stream(pm_ctx *c, void *stream) {
     }
     for (int i = 0; i < 4; ++i)
         if (c->info_s[i]) PM_FFT(rocfft_execution_info_set_stream(c->info_s[i], c->stream));
+    return PM_OK;
+}
+
+int pm_read_back(pm_ctx *c, void *h_dst, const void *d_src, size_t bytes) {
+    void *land = (c->h_pinned && bytes <= PM_PINNED_BYTES) ? c->h_pinned : h_dst;
+    PM_HIP(hipMemcpyAsync(land, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
+    if (land != h_dst) memcpy(h_dst, land, bytes);
     return PM_OK;
 }
 

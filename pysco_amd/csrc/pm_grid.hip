@@ -164,8 +164,7 @@ extern "C" int pm_kick_drift_wrap_slab(pm_ctx *c, float *d_pos, float *d_vel, co
                            -half_dt, dt, count, vec_ok, x_lo, x_hi, d_leave_idx, cap, d_count);
         PM_LAUNCH_CHECK();
     }
-    PM_HIP(hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    PM_HIP(hipStreamSynchronize(c->stream));
+    if (int rb_rc = pm_read_back(c, h_count, d_count, sizeof(int))) return rb_rc;
     return PM_OK;
 }
 
@@ -207,8 +206,7 @@ extern "C" int pm_max_abs(pm_ctx *c, const float *d_x, int64_t count, float *h_o
                        c->d_scratch);
     PM_LAUNCH_CHECK();
     unsigned bits = 0;
-    PM_HIP(hipMemcpyAsync(&bits, c->d_scratch, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    PM_HIP(hipStreamSynchronize(c->stream));
+    if (int rb_rc = pm_read_back(c, &bits, c->d_scratch, sizeof(unsigned))) return rb_rc;
     memcpy(h_out, &bits, sizeof(float));
     return PM_OK;
 }
@@ -764,7 +762,6 @@ extern "C" int pm_pk(pm_ctx *c, int p, void *d_xk, const float *h_sinc, double *
     PM_LAUNCH_CHECK();
     PM_HIP(hipMemcpyAsync(h_ksum, c->d_hist, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PM_HIP(hipMemcpyAsync(h_pksum, c->d_hist + n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PM_HIP(hipMemcpyAsync(h_nmodes, c->d_hist + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PM_HIP(hipStreamSynchronize(c->stream));
+    if (int rb_rc = pm_read_back(c, h_nmodes, c->d_hist + 2 * n, n * sizeof(double))) return rb_rc;
     return PM_OK;
 }

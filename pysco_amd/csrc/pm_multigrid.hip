@@ -307,8 +307,7 @@ __device__ __forceinline__ void block_sum_to(double v, double *result) {
 
 static int read_norm(pm_ctx *c, float *h_out) {
     double s = 0;
-    PM_HIP(hipMemcpyAsync(&s, c->d_hist, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PM_HIP(hipStreamSynchronize(c->stream));
+    if (int rb_rc = pm_read_back(c, &s, c->d_hist, sizeof(double))) return rb_rc;
     *h_out = (float)sqrt(s);
     return PM_OK;
 }
@@ -375,8 +374,7 @@ static int lap_residual_sumsq(pm_ctx *c, const float *d_x, const float *d_b, int
         hipLaunchKernelGGL(lap_residual_error_kernel, dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n),
                            (float)((double)n * n), c->d_hist, xr);
     PM_LAUNCH_CHECK();
-    PM_HIP(hipMemcpyAsync(h_sum, c->d_hist, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PM_HIP(hipStreamSynchronize(c->stream));
+    if (int rb_rc = pm_read_back(c, h_sum, c->d_hist, sizeof(double))) return rb_rc;
     return PM_OK;
 }
 
@@ -423,8 +421,7 @@ extern "C" int pm_diff_sumsq(pm_ctx *c, const float *d_a, const float *d_b, floa
     hipLaunchKernelGGL(diff_norm_kernel, dim3(pm_stream_blocks(count, BLK * 4)), dim3(BLK), 0, c->stream, d_a, d_b, f,
                        count, c->d_hist);
     PM_LAUNCH_CHECK();
-    PM_HIP(hipMemcpyAsync(h_sum, c->d_hist, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PM_HIP(hipStreamSynchronize(c->stream));
+    if (int rb_rc = pm_read_back(c, h_sum, c->d_hist, sizeof(double))) return rb_rc;
     return PM_OK;
 }
 
@@ -799,6 +796,74 @@ static int lap_vcycle_level(pm_ctx *c, float *x, const float *b, int n, int npre
     return PM_OK;
 }
 
+// Runs `body` (a whole V-cycle: nothing but kernel launches, copies and memsets on c->stream) -- as a replay of its
+// captured hipGraph when the very same call was seen before (same arrays, sizes, sweeps, arena), else capturing it
+// on the way.  Any failure of the capture machinery switches it off for the context and the launches go out plainly.
+template <class F>
+static int vcycle_graphed(pm_ctx *c, int kind, const void *x, const void *b, float q, int n, int npre, int npost, F body) {
+    if (!c->vc_graph_mode) return body();
+    const void *arena = c->mg_buf;
+    for (auto &g : c->vc_graphs)
+        if (g.exec && g.x == x && g.b == b && g.arena == arena && g.kind == kind && g.n == n && g.npre == npre &&
+            g.npost == npost && g.q == q) {
+            g.last_use = ++c->vc_clock, ++c->vc_hits;
+            if (hipGraphLaunch(g.exec, c->stream) == hipSuccess) return PM_OK;
+            (void)hipGetLastError();
+            c->vc_graph_mode = 0;
+            return body();
+        }
+    ++c->vc_misses;
+    if (c->vc_misses > 32 && c->vc_misses > 2 * c->vc_hits) {  // the caller's arrays keep changing: capturing costs more than it saves
+        c->vc_graph_mode = 0;
+        return body();
+    }
+    auto give_up = [&]() {
+        (void)hipGetLastError();
+        c->vc_graph_mode = 0;
+        return body();
+    };
+    if (!c->capture_stream && hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess) return give_up();
+    hipStream_t user = c->stream;
+    if (hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeRelaxed) != hipSuccess) return give_up();
+    c->stream = c->capture_stream;
+    const int rc = body();
+    c->stream = user;
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->capture_stream, &graph);
+    if (rc) {
+        if (graph) hipGraphDestroy(graph);
+        return rc;
+    }
+    if (e != hipSuccess || !graph) return give_up();
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (ei != hipSuccess || !exec) return give_up();
+    pm_ctx::VcGraph *slot = &c->vc_graphs[0];
+    for (auto &g : c->vc_graphs)
+        if (!g.exec || (slot->exec && g.last_use < slot->last_use)) slot = &g;
+    if (slot->exec) hipGraphExecDestroy(slot->exec);
+    *slot = pm_ctx::VcGraph{x, b, arena, kind, n, npre, npost, q, exec, ++c->vc_clock};
+    if (hipGraphLaunch(exec, c->stream) == hipSuccess) return PM_OK;
+    slot->exec = nullptr;
+    hipGraphExecDestroy(exec);
+    return give_up();
+}
+
+// mode 1 (default): V-cycles are captured and replayed as hipGraphs; 0: plain launches.  Either way the same kernels
+// with the same arguments in the same order.
+extern "C" int pm_set_vcycle_graphs(pm_ctx *c, int mode) {
+    PM_REQUIRE(c && (mode == 0 || mode == 1), "bad argument");
+    c->vc_graph_mode = mode;
+    return PM_OK;
+}
+
+extern "C" int pm_vcycle_graph_stats(pm_ctx *c, unsigned *replayed, unsigned *captured) {
+    PM_REQUIRE(c && replayed && captured, "NULL argument");
+    *replayed = c->vc_hits, *captured = c->vc_misses;
+    return PM_OK;
+}
+
 extern "C" int pm_lap_vcycle(pm_ctx *c, float *d_x, const float *d_b, int n, int npre, int npost) {
     PM_REQUIRE(c && d_x && d_b && npre >= 0 && npost >= 0, "bad argument");
     PM_CHECK_GRID(n);
@@ -808,7 +873,8 @@ extern "C" int pm_lap_vcycle(pm_ctx *c, float *d_x, const float *d_b, int n, int
     float *scratch = nullptr;
     int rc = mg_arena(c, ((size_t)n * n * n * (n >= 256 ? 11 : 2) / 7 + 1024) * sizeof(float), &scratch);
     if (rc) return rc;
-    return lap_vcycle_level(c, d_x, d_b, n, npre, npost, scratch);
+    return vcycle_graphed(c, c->mg_fused_sweep ? 1 : 0, d_x, d_b, 0.f, n, npre, npost,
+                          [&]() { return lap_vcycle_level(c, d_x, d_b, n, npre, npost, scratch); });
 }
 
 // One colour half-sweep on a slab [nx + 2, n, n] (owned planes 1..nx, ghosts filled by the caller, who
@@ -951,8 +1017,7 @@ static int fr_residual_sumsq(pm_ctx *c, const float *d_x, const float *d_b, floa
     hipLaunchKernelGGL((cubic_operator_kernel<2, FRN>), dim3(pm_stream_blocks(total, BLK * 4)), dim3(BLK), 0, c->stream,
                        d_x, d_b, q * h2, (const float *)nullptr, ilog2(n), h2, invsix, (float *)nullptr, c->d_hist, xr);
     PM_LAUNCH_CHECK();
-    PM_HIP(hipMemcpyAsync(h_sum, c->d_hist, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PM_HIP(hipStreamSynchronize(c->stream));
+    if (int rb_rc = pm_read_back(c, h_sum, c->d_hist, sizeof(double))) return rb_rc;
     return PM_OK;
 }
 

@@ -1037,8 +1037,7 @@ static int list_bufs(pm_ctx *c, int64_t np, unsigned ntiles, ListBufs *b) {
 static int list_group(pm_ctx *c, const ListBufs &b, unsigned ntiles, const unsigned **idx, unsigned *listed,
                       int *complete) {
     unsigned h_counts[PM_NSUB * PM_SUB_STRIDE];
-    PM_HIP(hipMemcpyAsync(h_counts, b.counts, sizeof(h_counts), hipMemcpyDeviceToHost, c->stream));
-    PM_HIP(hipStreamSynchronize(c->stream));
+    if (int rb_rc = pm_read_back(c, h_counts, b.counts, sizeof(h_counts))) return rb_rc;
     SubLists sub;
     unsigned cnt = 0, biggest = 0;
     *complete = 1;
@@ -1802,8 +1801,7 @@ extern "C" int pm_kick_drift_wrap_deposit_slab(pm_ctx *c, int scheme, float *d_p
                                 Leavers{x_lo, x_hi, d_leave_idx, cap, d_count});
     tile_lists_drop(c);
     if (rc) return rc;
-    PM_HIP(hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    PM_HIP(hipStreamSynchronize(c->stream));
+    if (int rb_rc = pm_read_back(c, h_count, d_count, sizeof(int))) return rb_rc;
     return PM_OK;
 }
 
@@ -2596,8 +2594,7 @@ extern "C" int pm_last_maxabs(pm_ctx *c, float *h_max_acc, float *h_max_vel) {
     PM_REQUIRE(c && h_max_acc && h_max_vel, "NULL argument");
     unsigned bits[PM_SAMPLE_WORD + 4];
     memset(bits, 0, sizeof(bits));
-    PM_HIP(hipMemcpyAsync(bits, c->d_scratch + 8, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
-    PM_HIP(hipStreamSynchronize(c->stream));
+    if (int rb_rc = pm_read_back(c, bits, c->d_scratch + 8, sizeof(bits))) return rb_rc;
     memcpy(h_max_acc, &bits[0], sizeof(float));
     memcpy(h_max_vel, &bits[1], sizeof(float));
     double sum;

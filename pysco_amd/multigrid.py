@@ -48,6 +48,7 @@ def linear(x, b, param):
 
 
 _NATIVE_VCYCLE = True  # tests flip this to compare with the recursion written out below
+_VCYCLE_GRAPHS = True  # False: pm_lap_vcycle issues plain launches instead of replaying captured hipGraphs
 
 
 def V_cycle(x, b, param, nlevel: int = 0) -> None:
@@ -58,7 +59,11 @@ def V_cycle(x, b, param, nlevel: int = 0) -> None:
         # the same sequence of kernels issued from C in one call (pmstep.h: pm_lap_vcycle)
         torch = L.require_gpu()
         xd, bd = L.to_device(x, torch.float32), L.to_device(b, torch.float32)
-        L.context(4).call("pm_lap_vcycle", L.ptr(xd), L.ptr(bd), n, int(param["Npre"]), int(param["Npost"]))
+        ctx = L.context(4)
+        if getattr(ctx, "_vcycle_graphs", True) != _VCYCLE_GRAPHS:
+            ctx.call("pm_set_vcycle_graphs", int(_VCYCLE_GRAPHS))
+            ctx._vcycle_graphs = _VCYCLE_GRAPHS
+        ctx.call("pm_lap_vcycle", L.ptr(xd), L.ptr(bd), n, int(param["Npre"]), int(param["Npost"]))
         if not L.is_device_array(x):
             x[...] = xd.cpu().numpy()
         return

@@ -396,3 +396,35 @@ def test_native_fas_vcycle_is_the_python_recursion(amd, n, fr_n):
     assert np.isfinite(out[True]).all()
     assert np.abs(out[True] - x0.cpu().numpy()).max() > 0
     np.testing.assert_array_equal(out[True], out[False])
+
+
+def test_vcycle_graph_replay_is_the_plain_cycle(amd):
+    """pm_lap_vcycle replayed from its captured hipGraph (second and later calls on the same arrays) against plain
+    launches: same bits, for two grid sizes sharing one context, and the replay counter moves."""
+    import ctypes as C
+
+    torch = amd.torch
+    from pysco_amd import _lib as L
+
+    ctx = L.context(4)
+    for n in (32, 128):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(n)
+        b = torch.rand((n, n, n), generator=g, device="cuda") - 0.5
+        x0 = torch.rand((n, n, n), generator=g, device="cuda") * 1e-3
+        out = {}
+        for mode in (0, 1):
+            ctx.call("pm_set_vcycle_graphs", mode)
+            x = x0.clone()
+            rep0, cap0 = C.c_uint(0), C.c_uint(0)
+            ctx.call("pm_vcycle_graph_stats", C.byref(rep0), C.byref(cap0))
+            for _ in range(4):
+                ctx.call("pm_lap_vcycle", L.ptr(x), L.ptr(b), n, 2, 1)
+            rep, cap = C.c_uint(0), C.c_uint(0)
+            ctx.call("pm_vcycle_graph_stats", C.byref(rep), C.byref(cap))
+            out[mode] = (x.cpu().numpy(), rep.value - rep0.value, cap.value - cap0.value)
+        ctx.call("pm_set_vcycle_graphs", 1)
+        assert out[0][1:] == (0, 0)
+        assert out[1][1:] == (3, 1), out[1][1:]  # captured once, replayed three times
+        np.testing.assert_array_equal(out[0][0], out[1][0])
+        assert np.isfinite(out[1][0]).all() and np.abs(out[1][0] - x0.cpu().numpy()).max() > 0
