@@ -138,13 +138,12 @@ struct Dft<16, INV> {
 // reads in[j + t n/R], multiplies by w^(t (j mod Ns)) (w = exp(-+2 pi i / (Ns R))), does the R-point DFT and
 // writes out[(j / Ns) Ns R + (j mod Ns) + t Ns].  BPL = butterflies per lane (n / R / 64, at least 1).
 // tw[k] = exp(-2 pi i k / n).
-template <int R, int BPL, bool INV>
-__device__ __forceinline__ void stockham_stage(float2 *ln, const float2 *tw, int n, int log2n, int lNs) {
+// (in three pieces, so that a pass can feed a stage from global memory or registers and take its outputs there:
+// fftp_x_green's fused form)
+template <int R, int BPL>
+__device__ __forceinline__ void stage_load(float2 (&a)[BPL][R], const float2 *ln, int n) {
     const int lane = threadIdx.x & 63;
     const int nb = n / R;              // butterflies in the line
-    const int Ns = 1 << lNs;
-    const int tstep = n >> (lNs + (R == 16 ? 4 : (R == 8 ? 3 : 2)));  // n / (Ns R)
-    float2 a[BPL][R];
 #pragma unroll
     for (int i = 0; i < BPL; ++i) {
         const int j = lane + 64 * i;
@@ -162,6 +161,14 @@ __device__ __forceinline__ void stockham_stage(float2 *ln, const float2 *tw, int
             }
         }
     }
+}
+
+template <int R, int BPL, bool INV>
+__device__ __forceinline__ void stage_compute(float2 (&a)[BPL][R], const float2 *tw, int n, int lNs) {
+    const int lane = threadIdx.x & 63;
+    const int nb = n / R;
+    const int Ns = 1 << lNs;
+    const int tstep = n >> (lNs + (R == 16 ? 4 : (R == 8 ? 3 : 2)));  // n / (Ns R)
 #pragma unroll
     for (int i = 0; i < BPL; ++i) {
         const int j = lane + 64 * i;
@@ -180,6 +187,13 @@ __device__ __forceinline__ void stockham_stage(float2 *ln, const float2 *tw, int
             Dft<R, INV>::run(a[i]);
         }
     }
+}
+
+template <int R, int BPL>
+__device__ __forceinline__ void stage_store(const float2 (&a)[BPL][R], float2 *ln, int n, int lNs) {
+    const int lane = threadIdx.x & 63;
+    const int nb = n / R;
+    const int Ns = 1 << lNs;
 #pragma unroll
     for (int i = 0; i < BPL; ++i) {
         const int j = lane + 64 * i;
@@ -198,6 +212,14 @@ __device__ __forceinline__ void stockham_stage(float2 *ln, const float2 *tw, int
             }
         }
     }
+}
+
+template <int R, int BPL, bool INV>
+__device__ __forceinline__ void stockham_stage(float2 *ln, const float2 *tw, int n, int log2n, int lNs) {
+    float2 a[BPL][R];
+    stage_load<R, BPL>(a, ln, n);
+    stage_compute<R, BPL, INV>(a, tw, n, lNs);
+    stage_store<R, BPL>(a, ln, n, lNs);
 }
 
 // forward / inverse FFT of the 8 lines of the workgroup (wave w owns line w); barriers only publish a
@@ -525,6 +547,71 @@ __global__ __launch_bounds__(FBLK) void fftp_y(float2 *__restrict__ B, float2 *_
 // ---- P3: x forward, Green's function, x inverse, in place ----------------------------------------------
 // workgroup = 8 consecutive lines (ky_local, kz) of C viewed as [nseg][nky*nh lines][nx]; ky0 = global
 // index of the first local ky (0 on a single GPU)
+// The x pass of one line for n = 64 R1 (1024 = 16 * 16 * 4, 512 = 8 * 8 * 8), the line passing through LDS four times
+// instead of nine: the first forward stage takes its inputs straight from global memory (butterfly `lane` reads
+// elements lane + 64 t: consecutive lanes, consecutive addresses), the last forward stage leaves element lane + 64 m
+// in the lane that the first INVERSE stage wants it in (both cover exactly the elements = lane mod 64), so the
+// Green's function is applied and the hand-over made in registers, and the last inverse stage stores to global
+// memory.  Same stages, same twiddles, same Green's expression as the generic form below.
+template <int KIND, int R1, int R2, int R3, class XAddr>
+__device__ __forceinline__ void xgreen_line_fused(float2 *__restrict__ C, XAddr xaddr, float2 *ln, const float2 *tw, int n,
+                                                  int log2n, const float *__restrict__ k2, const float *__restrict__ s,
+                                                  float c0, float norm, int ky, int kz) {
+    constexpr int BPL3 = R1 / R3;  // butterflies per lane of the last stage (n / R3 / 64)
+    constexpr int L1 = R1 == 16 ? 4 : 3, L2 = R2 == 16 ? 4 : 3;
+    const int lane = threadIdx.x & 63;
+    float2 a1[1][R1];
+#pragma unroll
+    for (int t = 0; t < R1; ++t) {
+        const fft_v2f v = *reinterpret_cast<const fft_v2f *>(C + xaddr(lane + 64 * t));
+        a1[0][t] = make_float2(v.x, v.y);
+    }
+    stage_compute<R1, 1, false>(a1, tw, n, 0);
+    stage_store<R1, 1>(a1, ln, n, 0);
+    wave_lds_fence();
+    stockham_stage<R2, 1, false>(ln, tw, n, log2n, L1);
+    wave_lds_fence();
+    float2 a3[BPL3][R3];
+    stage_load<R3, BPL3>(a3, ln, n);
+    stage_compute<R3, BPL3, false>(a3, tw, n, L1 + L2);
+    // output t of butterfly lane + 64 i is element lane + 64 i + t (n / R3) = lane + 64 (i + t BPL3)
+    float2 b1[1][R1];
+#pragma unroll
+    for (int i = 0; i < BPL3; ++i)
+#pragma unroll
+        for (int t = 0; t < R3; ++t) {
+            const int m = i + t * BPL3, kx = lane + 64 * m;
+            float g;  // fourier.py:460-595; for the compensated kernel `s` already holds sinc^(-2p) per axis
+            if (KIND == PM_GREEN_7PT) {
+                g = c0 / ((s[kx] + s[ky]) + s[kz]);
+            } else {
+                const float invk2 = c0 / ((k2[kx] + k2[ky]) + k2[kz]);
+                g = (KIND == PM_GREEN_COMPENSATED) ? ((s[kx] * s[ky]) * s[kz]) * invk2 : invk2;
+            }
+            g *= norm;  // 1/n^3 of the inverse transform
+            float2 v = a3[i][t];
+            if ((kx | ky | kz) == 0)
+                v = make_float2(0.f, 0.f);
+            else
+                v.x *= g, v.y *= g;
+            b1[0][m] = v;
+        }
+    stage_compute<R1, 1, true>(b1, tw, n, 0);
+    wave_lds_fence();  // (every lane has read its stage-3 inputs before the line is overwritten)
+    stage_store<R1, 1>(b1, ln, n, 0);
+    wave_lds_fence();
+    stockham_stage<R2, 1, true>(ln, tw, n, log2n, L1);
+    wave_lds_fence();
+    float2 c3[BPL3][R3];
+    stage_load<R3, BPL3>(c3, ln, n);
+    stage_compute<R3, BPL3, true>(c3, tw, n, L1 + L2);
+#pragma unroll
+    for (int i = 0; i < BPL3; ++i)
+#pragma unroll
+        for (int t = 0; t < R3; ++t)
+            *reinterpret_cast<fft_v2f *>(C + xaddr(lane + 64 * (i + t * BPL3))) = fft_v2f{c3[i][t].x, c3[i][t].y};
+}
+
 template <int KIND>
 __global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, const float2 *__restrict__ g_tw, int n,
                                                      int log2n, int p, const float *__restrict__ k2,
@@ -549,6 +636,14 @@ __global__ __launch_bounds__(FBLK) void fftp_x_green(float2 *__restrict__ C, con
         const int seg = e / nx, xl = e - seg * nx;
         return ((int64_t)seg * nlines_total + line) * nx + xl;
     };
+    if (log2n == 10) {
+        xgreen_line_fused<KIND, 16, 16, 4>(C, xaddr, ln, tw, n, log2n, k2, s, c0, norm, ky, kz);
+        return;
+    }
+    if (log2n == 9) {
+        xgreen_line_fused<KIND, 8, 8, 8>(C, xaddr, ln, tw, n, log2n, k2, s, c0, norm, ky, kz);
+        return;
+    }
     batched<8>(  // 16-byte accesses: elements (e, e+1), e even; the clamp keeps e even (n - 2)
         lane, n >> 1, 64, [&](int h) { return *reinterpret_cast<const fft_v4f *>(C + xaddr(2 * h)); },
         [&](int h, fft_v4f v) {

@@ -628,15 +628,50 @@ def test_fused_fft_poisson_vs_numpy_and_rocfft(amd, n):
         assert torch.equal(rhs_d.cpu(), torch.from_numpy(rhs))  # the source grid is preserved
 
 
-@pytest.mark.parametrize("nseg", [2, 4])
-def test_fftp_stages_on_slabs_match_fused(amd, nseg):
-    """The slab form of the LDS-FFT passes (forward on x-slabs -> segmented x pass -> inverse on x-slabs),
-    with the all-to-all emulated by index shuffles on one GPU, reproduces pm_poisson_fft_fused bit for bit."""
+@pytest.mark.parametrize("n", [512, 1024])
+def test_fused_fft_poisson_large_lines(amd, n):
+    """n = 512 and 1024: the x pass keeps the hand-over between its forward and inverse transforms in registers
+    (xgreen_line_fused: first stage fed from global memory, Green's function on the last stage's outputs, last
+    inverse stage stored to global memory).  Against the rocFFT path for three Green's functions; at 512^3 also
+    against numpy's fp64 FFT + the oracle's Green's function."""
     import pysco_amd._lib as L
     from pysco_amd import fourier
 
     torch = amd.torch
-    n = 64
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n)
+    rhs_d = torch.randn((n, n, n), generator=g, dtype=torch.float32, device="cuda")
+    ctx = L.context(n)
+    for kind, p in ((L.GREEN_COMPENSATED, 3), (L.GREEN_PLAIN, 0), (L.GREEN_7PT, 0)):
+        k2, s, c0 = fourier.green_tables(n, kind)
+        phi = torch.empty_like(rhs_d)
+        ctx.call("pm_poisson_fft_fused", kind, p, L.ptr(rhs_d), L.ptr(phi), L.hptr(k2), L.hptr(s), c0)
+        phi2 = torch.empty_like(rhs_d)
+        ctx.call("pm_poisson_fft", kind, p, L.ptr(rhs_d), L.ptr(phi2), L.hptr(k2), L.hptr(s), c0)
+        sc = float(phi2.abs().max())
+        assert torch.isfinite(phi).all() and sc > 0
+        assert float((phi - phi2).abs().max()) <= 3e-6 * sc, (kind, float((phi - phi2).abs().max()) / sc)
+        del phi2
+        if n == 512 and kind == L.GREEN_COMPENSATED:
+            xk = np.fft.rfftn(rhs_d.cpu().numpy().astype(np.float64)).astype(np.complex64)
+            orc.inverse_laplacian_compensated(xk, 3)
+            ref = np.fft.irfftn(xk.astype(np.complex128), s=(n, n, n), axes=(0, 1, 2)).astype(np.float32)
+            np.testing.assert_allclose(phi.cpu().numpy(), ref, rtol=0, atol=3e-6 * _scale(ref))
+            del xk, ref
+        del phi
+    L._ctxs.pop((torch.cuda.current_device(), n), None)  # (its 1024^3 work buffers: 17 GB)
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n,nseg", [(64, 2), (64, 4), (512, 2)])
+def test_fftp_stages_on_slabs_match_fused(amd, n, nseg):
+    """The slab form of the LDS-FFT passes (forward on x-slabs -> segmented x pass -> inverse on x-slabs),
+    with the all-to-all emulated by index shuffles on one GPU, reproduces pm_poisson_fft_fused bit for bit
+    (512: the x pass's register hand-over on segmented lines)."""
+    import pysco_amd._lib as L
+    from pysco_amd import fourier
+
+    torch = amd.torch
     nx = ny = n // nseg
     nh = n // 2 + 1
     rhs = torch.randn((n, n, n), dtype=torch.float32, device="cuda")
