@@ -457,6 +457,8 @@ def main():
                         "wall_ms": round(step_events[i].elapsed_time(step_events[i + 1]), 3),
                         "ms": {k[3:]: round(v, 3) for k, v in sorted(per_step[i].items(), key=lambda kv: -kv[1])[:3]}}
                        for i in show]
+    if pm_main.last_placement_probe_ms:  # in-place pass over each candidate particle array [ms], ascending: the first six are in use
+        out["placement_probe_ms"] = pm_main.last_placement_probe_ms
     if straggler_frac and straggler_frac[0] is not None:  # every timed step: stragglers found, dt taken, dt guessed for the next
         out["straggler_series"] = [round(f, 5) for f in straggler_frac]
         if dt_series:

@@ -38,9 +38,9 @@ def predict_next_step(dt, dt1, dt2, tables, param, t_snap_next, meanabs) -> None
     param["_acc_meanabs_last"], param["_acc_scale_pred"] = ms, scale
     try:
         t_end = param["t"] + dt
-        a_end = float(np.exp(tables[0](t_end)))
+        a_end = float(np.exp(utils.table_eval(tables[0], t_end)))
         f = 1.0 + 0.01 * param["max_aexp_stepping"]
-        dt3_next = float(tables[1](np.log(f * a_end)) - tables[1](np.log(a_end)))
+        dt3_next = float(utils.table_eval(tables[1], np.log(f * a_end)) - utils.table_eval(tables[1], np.log(a_end)))
         # (each CFL criterion with its own trend over the step about to be taken, h = dt, from its change over
         # the last one, h_last: max|a| -- dt1 ~ max|a|^-1/2 -- grows geometrically in time; max|v| -- dt2 ~
         # 1 / max|v| -- by what the kicks add, i.e. in proportion to the time and to the accelerations: extrapolating
@@ -97,7 +97,7 @@ def integrate(position, velocity, acceleration, potential, additional_field, tab
 def _advance_clock(dt, tables, param) -> None:
     param["t"] += dt
     param["aexp_old"] = param["aexp"]
-    param["aexp"] = np.exp(tables[0](param["t"]))
+    param["aexp"] = np.exp(utils.table_eval(tables[0], param["t"]))
     utils.set_units(param)
 
 
@@ -205,15 +205,20 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
 
 def _rebucket_request(density, param, position):
     """Incremental re-sort policy (no reference counterpart; the reference re-sorts every n_reorder steps,
-    main.py:146-150).  With param["rebucket_straggler_fraction"] = f set (main.run_nbody sets it), a step whose
-    fused kick + drift + deposit found more than f of the particles outside the tile they are filed under has its
-    gather write position, velocity and acceleration out of place in tile order: integrate() then returns NEW
+    main.py:146-150).  With param["rebucket_straggler_fraction"] = f set (main.run_nbody sets it to 0: every step), a
+    step whose fused kick + drift + deposit found more than f of the particles outside the tile they are filed under has
+    its gather write position, velocity and acceleration out of place in tile order: integrate() then returns NEW
     tensors (same particles, permuted; param["particle_id"], an optional int32 tensor, follows them)."""
     thr = param.get("rebucket_straggler_fraction")
     if thr is None or density is None:
         return None
     frac, complete = utils.straggler_fraction(2 ** int(param["ncoarse"]))
-    if frac is None or not complete or frac <= float(thr):
+    if frac is None or not complete:
+        return None
+    # f <= 0: every step -- also one that found nobody out of place: the particles are filed for the NEXT drift, and a
+    # stream left as it is hands the next step every tile crosser of that drift (a perfect prediction at 32^3 used
+    # to be punished that way every other step)
+    if float(thr) > 0.0 and frac <= float(thr):
         return None
     return {"ids": param.get("particle_id")}
 
@@ -235,4 +240,5 @@ def dt_CFL_maxvel(velocity, param) -> np.float32:
 def dt_weak_variation(func_t_a, param) -> np.float32:
     """Step giving a max_aexp_stepping % change of the scale factor (integration.py:329-358)."""
     aexp_factor = 1.0 + 0.01 * param["max_aexp_stepping"]
-    return np.float32(func_t_a(np.log(aexp_factor * param["aexp"])) - func_t_a(np.log(param["aexp"])))
+    return np.float32(utils.table_eval(func_t_a, np.log(aexp_factor * param["aexp"]))
+                      - utils.table_eval(func_t_a, np.log(param["aexp"])))

@@ -24,6 +24,7 @@ REBUCKET_FRACTION = 0.0    # default of param["rebucket_straggler_fraction"] in 
                            # that found a straggler re-buckets (measured at 1024^3: 47.7 ms per step sustained against
                            # 48.5 / 49.7 with 0.02 / 0.04, where in-place and re-bucketing steps alternate)
 REORDER_FRACTION = 0.10    # default of param["reorder_straggler_fraction"]
+last_placement_probe_ms = None  # tune_placement's timings of its candidate arrays, ascending (diagnostics)
 
 
 def reserve_step_buffers(position) -> None:
@@ -82,6 +83,8 @@ def tune_placement(position, velocity, acceleration=None, max_candidates: int = 
         t.zero_()
     timed = sorted([(probe(t), i, t, i < len(live)) for i, t in enumerate(live + cand)], key=lambda r: r[0])
     logging.info("placement probe [ms]: " + " ".join(f"{ms:.2f}{'*' if is_live else ''}" for ms, _, _, is_live in timed))
+    global last_placement_probe_ms
+    last_placement_probe_ms = [round(ms, 3) for ms, _, _, _ in timed]  # (ascending; the first six are kept)
     ranked = [t for _, _, t, _ in timed[:need]]
     # roles by rank: the fused kick + drift updates position and velocity IN PLACE, in the live set and -- a step
     # later -- in the set the gather wrote (mesh._rebucket_pool, whose roles are stable): those four take the four

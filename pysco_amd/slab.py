@@ -24,7 +24,7 @@ from typing import List, Optional
 import numpy as np
 
 from . import _lib as L
-from . import fourier
+from . import fourier, utils
 
 _REACH = {2: 1, 3: 1, 5: 2, 7: 3}
 _SCHEME = {"cic": L.CIC, "tsc": L.TSC}
@@ -780,8 +780,8 @@ class Slab:
         pot0 = owned(potential)
         warm = None
         if pot0 is not None:  # solver.py:273-280
-            warm = np.float32(param["aexp"] * tables[3](np.log(param["aexp"]))
-                              / (param["aexp_old"] * tables[3](np.log(param["aexp_old"]))))
+            warm = np.float32(param["aexp"] * utils.table_eval(tables[3], np.log(param["aexp"]))
+                              / (param["aexp_old"] * utils.table_eval(tables[3], np.log(param["aexp_old"]))))
         phi_lvl = solve(pot0, rhs, warm)
         del rhs, dens
         phi = phi_lvl[1:nx + 1]
@@ -926,7 +926,8 @@ class Slab:
             dt1 = np.float32(param["Courant_factor"]) * np.sqrt(dx / np.float32(ma))      # integration.py:267
             dt2 = np.float32(param["Courant_factor"]) * dx / np.float32(mv)                # :298
         aexp_factor = 1.0 + 0.01 * param["max_aexp_stepping"]
-        dt3 = np.float32(tables[1](np.log(aexp_factor * param["aexp"])) - tables[1](np.log(param["aexp"])))
+        dt3 = np.float32(utils.table_eval(tables[1], np.log(aexp_factor * param["aexp"]))
+                         - utils.table_eval(tables[1], np.log(param["aexp"])))
         dt = np.min([dt1, dt2, dt3])
         if (param["t"] + dt) > t_snap_next:
             dt = t_snap_next - param["t"]
@@ -940,7 +941,7 @@ class Slab:
         def advance_clock():
             param["t"] += dt
             param["aexp_old"] = param["aexp"]
-            param["aexp"] = np.exp(tables[0](param["t"]))
+            param["aexp"] = np.exp(utils.table_eval(tables[0], param["t"]))
             utils.set_units(param)
 
         x_lo, x_hi = self.rank / self.world, (self.rank + 1) / self.world  # exact in fp32 (G is a power of two)

@@ -264,8 +264,8 @@ def initialise_potential(potential, rhs, param, tables):
     else:
         if not param["compute_additional_field"]:
             scaling = (
-                param["aexp"] * tables[3](np.log(param["aexp"]))
-                / (param["aexp_old"] * tables[3](np.log(param["aexp_old"])))
+                param["aexp"] * utils.table_eval(tables[3], np.log(param["aexp"]))
+                / (param["aexp_old"] * utils.table_eval(tables[3], np.log(param["aexp_old"])))
             )
             utils.prod_vector_scalar_inplace(potential, scaling)
     return potential

@@ -103,3 +103,25 @@ def test_pmc_summary_reduces_the_timed_steps_only(tmp_path):
     assert dep["write_bytes_per_call"] == pytest.approx((200 + 300) / 2 * 1024)
     gat = d["stages"]["pm_gradient_interp_kick_rebucket"]
     assert gat["calls"] == 2 and gat["write_bytes_per_call"] == pytest.approx((2000 + 3000) / 2 * 1024)
+
+
+def test_table_eval_is_interp1d_bit_for_bit():
+    """utils.table_eval: a linear extrapolating interp1d evaluated with interp1d's own operations on scalars -- same
+    float64 bits inside, at the knots, between them and outside the range; other interpolators are called as they are."""
+    from scipy.interpolate import interp1d
+
+    from pysco_amd import utils
+
+    rng = np.random.default_rng(2)
+    x = np.sort(rng.uniform(-3.0, 2.0, 400))
+    y = np.cumsum(rng.uniform(0.1, 1.0, 400))
+    f = interp1d(x, y, fill_value="extrapolate")
+    probes = list(rng.uniform(-4.0, 3.0, 300)) + [x[0], x[-1], x[7], x[0] - 1.0, x[-1] + 2.0, np.float32(0.3), 0]
+    for q in probes:
+        got, ref = utils.table_eval(f, q), f(q)
+        assert np.float64(got).tobytes() == np.float64(ref).tobytes(), (q, got, ref)
+    cubic = interp1d(x, y, kind="cubic", fill_value="extrapolate")
+    assert float(utils.table_eval(cubic, 0.1)) == float(cubic(0.1))
+    bounded = interp1d(x, y)
+    assert float(utils.table_eval(bounded, 0.1)) == float(bounded(0.1))
+    np.testing.assert_array_equal(utils.table_eval(f, np.array([0.1, 0.2])), f(np.array([0.1, 0.2])))
