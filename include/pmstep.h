@@ -299,6 +299,9 @@ int pm_lap_vcycle(pm_ctx *ctx, float *d_x, const float *d_b, int n, int npre, in
  * hipGraph the first time it sees a set of arguments and replays it when the same arrays come back (8 graphs kept per
  * context; switches itself off if the caller's arrays keep changing or any graph call fails).  mode 0: plain launches.
  * pm_vcycle_graph_stats: cycles replayed / captured so far.  No reference counterpart. */
+/* on (default): pm_lap_vcycle runs every level from 16^3 down (22 launches) in one workgroup with the grids in LDS,
+ * same expressions in the same order (same bits); off: level by level. */
+int pm_set_fused_coarse(pm_ctx *ctx, int on);
 int pm_set_vcycle_graphs(pm_ctx *ctx, int mode);
 int pm_vcycle_graph_stats(pm_ctx *ctx, unsigned *replayed, unsigned *captured);
 /* laplacian.gauss_seidel :844: one red + one black sweep with over-relaxation f_relax, in place */

@@ -65,12 +65,14 @@ extern "C" int pm_restriction_slab(pm_ctx *c, const float *d_x, int nf, int nxf,
 }
 
 // mesh.py:206-330 prolongation / :334-455 add_prolongation: one thread per FINE cell
-__global__ __launch_bounds__(BLK) void prolongation_kernel(float *__restrict__ y, const float *__restrict__ xc,
-                                                           int log2nc, int add, XRange xf, XRange xcr) {
+// (the loop bodies of the scalar level kernels are functions of (first item, stride): the grid-stride kernels run
+// them over the whole grid, lap_vcycle_coarse_kernel runs them on one workgroup's LDS arrays -- same expressions)
+__device__ __forceinline__ void prolongation_body(float *__restrict__ y, const float *__restrict__ xc, int log2nc, int add,
+                                                  XRange xf, XRange xcr, int64_t first, int64_t stride) {
     const int log2nf = log2nc + 1, nf = 1 << log2nf, nc = 1 << log2nc, mc = nc - 1;
     const float f0 = (float)(27.0 / 64), f1 = (float)(9.0 / 64), f2 = (float)(3.0 / 64), f3 = (float)(1.0 / 64);
     const int64_t total = (int64_t)xf.ni << (2 * log2nf);
-    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+    for (int64_t t = first; t < total; t += stride) {
         const int kf = (int)(t & (nf - 1)), jf = (int)((t >> log2nf) & (nf - 1)), fi = (int)(t >> (2 * log2nf));
         const int i = xcr.i0 + (fi >> 1), j = jf >> 1, k = kf >> 1;
         const int ia = (i + ((fi & 1) ? 1 : -1)) & xcr.xmask, jb = (j + ((jf & 1) ? 1 : -1)) & mc,
@@ -83,6 +85,11 @@ __global__ __launch_bounds__(BLK) void prolongation_kernel(float *__restrict__ y
         float *dst = y + cidx(xf.i0 + fi, jf, kf, log2nf);
         *dst = add ? *dst + v : v;
     }
+}
+
+__global__ __launch_bounds__(BLK) void prolongation_kernel(float *__restrict__ y, const float *__restrict__ xc,
+                                                           int log2nc, int add, XRange xf, XRange xcr) {
+    prolongation_body(y, xc, log2nc, add, xf, xcr, (int64_t)blockIdx.x * BLK + threadIdx.x, (int64_t)gridDim.x * BLK);
 }
 
 // four fine k-cells per thread (nc >= 8): the four coarse rows are read as one aligned float2 + two scalars each,
@@ -191,15 +198,14 @@ extern "C" int pm_lap_operator_slab(pm_ctx *c, const float *d_x, const float *d_
 }
 
 // laplacian.py:125-226 restrict_residual: fused residual + 1/8 restriction, reference summation order
-__global__ __launch_bounds__(BLK) void lap_restrict_residual_kernel(const float *__restrict__ x,
-                                                                    const float *__restrict__ b, int log2n,
-                                                                    float invh2, float *__restrict__ out, XRange xf,
-                                                                    XRange xc) {
+__device__ __forceinline__ void lap_restrict_residual_body(const float *__restrict__ x, const float *__restrict__ b,
+                                                           int log2n, float invh2, float *__restrict__ out, XRange xf,
+                                                           XRange xc, int64_t first, int64_t stride) {
     const int n = 1 << log2n, m = n - 1, log2nc = log2n - 1, nc = n >> 1;
     const int64_t total = (int64_t)xc.ni << (2 * log2nc);
 #define X(a, bb, cc) x[cidx((a)&xf.xmask, (bb)&m, (cc)&m, log2n)]
 #define B(a, bb, cc) b[cidx(a, bb, cc, log2n)]
-    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+    for (int64_t t = first; t < total; t += stride) {
         const int k = (int)(t & (nc - 1)), j = (int)((t >> log2nc) & (nc - 1)), i = (int)(t >> (2 * log2nc));
         const int ii = xf.i0 + 2 * i, jj = 2 * j, kk = 2 * k;
         const int m1 = ii - 1, p1 = ii + 1, p2 = ii + 2, jm1 = jj - 1, jp1 = jj + 1, jp2 = jj + 2, km1 = kk - 1,
@@ -217,6 +223,14 @@ __global__ __launch_bounds__(BLK) void lap_restrict_residual_kernel(const float 
     }
 #undef X
 #undef B
+}
+
+__global__ __launch_bounds__(BLK) void lap_restrict_residual_kernel(const float *__restrict__ x,
+                                                                    const float *__restrict__ b, int log2n,
+                                                                    float invh2, float *__restrict__ out, XRange xf,
+                                                                    XRange xc) {
+    lap_restrict_residual_body(x, b, log2n, invh2, out, xf, xc, (int64_t)blockIdx.x * BLK + threadIdx.x,
+                               (int64_t)gridDim.x * BLK);
 }
 
 // The same with 16-byte accesses (n >= 16): a thread computes two adjacent coarse cells (four fine k) from twelve
@@ -447,11 +461,11 @@ __device__ __forceinline__ void gs_cell(float *__restrict__ x, const float *__re
 }
 
 template <int COLOUR>
-__global__ __launch_bounds__(BLK) void lap_gauss_seidel_kernel(float *__restrict__ x, const float *__restrict__ b,
-                                                               int log2n, float h2, float invsix, float f_relax) {
+__device__ __forceinline__ void lap_gauss_seidel_body(float *__restrict__ x, const float *__restrict__ b, int log2n, float h2,
+                                                      float invsix, float f_relax, int64_t first, int64_t stride) {
     const int n = 1 << log2n, m = n - 1, log2nc = log2n - 1, nc = n >> 1;
     const int64_t total = (int64_t)nc * nc * nc;
-    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+    for (int64_t t = first; t < total; t += stride) {
         const int k = 2 * (int)(t & (nc - 1)), j = 2 * (int)((t >> log2nc) & (nc - 1)), i = 2 * (int)(t >> (2 * log2nc));
         if (COLOUR == 1) {  // red: i+j+k odd
             gs_cell<5, 3, 1, 0, 2, 4, 6>(x, b, i + 1, j + 1, k + 1, m, log2n, h2, invsix, f_relax);  // 111
@@ -465,6 +479,13 @@ __global__ __launch_bounds__(BLK) void lap_gauss_seidel_kernel(float *__restrict
             gs_cell<0, 2, 4, 6, 5, 3, 1>(x, b, i, j, k, m, log2n, h2, invsix, f_relax);              // 000
         }
     }
+}
+
+template <int COLOUR>
+__global__ __launch_bounds__(BLK) void lap_gauss_seidel_kernel(float *__restrict__ x, const float *__restrict__ b,
+                                                               int log2n, float h2, float invsix, float f_relax) {
+    lap_gauss_seidel_body<COLOUR>(x, b, log2n, h2, invsix, f_relax, (int64_t)blockIdx.x * BLK + threadIdx.x,
+                                  (int64_t)gridDim.x * BLK);
 }
 
 // Row form of the same half-sweep for n >= 16: a thread owns 8 consecutive k-cells of one (i, j) row, four
@@ -764,9 +785,74 @@ extern "C" int pm_lap_smoothing(pm_ctx *c, float *d_x, const float *d_b, int n, 
 // taken from one arena of the context, every level operation the kernel the stand-alone entry points launch (same
 // bits).  Issued one by one from Python the ~20 calls per level cost more than the kernels below 128^3.
 
+// ---- every level from 16^3 down in ONE workgroup ------------------------------------------------------------
+// Below 32^3 a level is nine dependent launches of 2.5-3 us each whatever issues them (stream or hipGraph): 22 launches
+// for the levels 16^3, 8^3 and the 4^3 smoothing.  Here one workgroup keeps the solution and right-hand side of those
+// levels in LDS (37 KB) and runs the same sequence -- the loop bodies of the scalar level kernels over its own threads,
+// a barrier where a launch boundary was -- so every cell goes through the same expression in the same order of
+// half-sweeps: the same bits as the launches (test_fused_coarse_levels_are_the_launches).
+constexpr int CV_BLK = 512, CV_CELLS = 4096 + 512 + 64;
+
+__global__ __launch_bounds__(CV_BLK) void lap_vcycle_coarse_kernel(float *__restrict__ gx, const float *__restrict__ gb,
+                                                                   int log2n0, int npre, int npost, float f_relax) {
+    __shared__ float sx[CV_CELLS], sb[CV_CELLS];
+    const int tid = threadIdx.x;
+    const int n0 = 1 << log2n0, cells0 = n0 * n0 * n0;
+    const int off[3] = {0, cells0, cells0 + (cells0 >> 3)};
+    for (int c = tid; c < cells0; c += CV_BLK) sx[c] = gx[c], sb[c] = gb[c];
+    __syncthreads();
+    const float invsix = (float)(1.0 / 6);
+    auto smooth = [&](float *x, const float *b, int log2n, int sweeps) {  // pm_lap_gauss_seidel, `sweeps` times
+        const int n = 1 << log2n;
+        const float h2 = (float)(1.0 / ((double)n * n));
+        for (int s = 0; s < sweeps; ++s) {
+            lap_gauss_seidel_body<1>(x, b, log2n, h2, invsix, f_relax, tid, CV_BLK);
+            __syncthreads();
+            lap_gauss_seidel_body<0>(x, b, log2n, h2, invsix, f_relax, tid, CV_BLK);
+            __syncthreads();
+        }
+    };
+    const int D = log2n0 - 2;  // levels of 8^3 cells and more (16^3: two, 8^3: one); the one below is only smoothed
+    for (int l = 0; l < D; ++l) {
+        const int log2n = log2n0 - l, n = 1 << log2n, nc = n >> 1;
+        float *x = sx + off[l], *xc = sx + off[l + 1];
+        const float *b = sb + off[l];
+        float *bc = sb + off[l + 1];
+        smooth(x, b, log2n, npre);
+        lap_restrict_residual_body(x, b, log2n, (float)((double)n * n), bc, XRange{0, n, n - 1}, XRange{0, nc, nc - 1}, tid,
+                                   CV_BLK);
+        __syncthreads();
+        // laplacian.initialise_potential (laplacian.py:765) as lap_vcycle_level does it: pm_linear_operator(f1, 0)
+        const float h = 1.0f / (float)nc;
+        const float minus_h2_over_six = (float)(-(double)(h * h) / 6.0);
+        for (int cc = tid; cc < nc * nc * nc; cc += CV_BLK) xc[cc] = minus_h2_over_six * bc[cc] + 0.0f;
+        __syncthreads();
+    }
+    smooth(sx + off[D], sb + off[D], log2n0 - D, npre);
+    for (int l = D - 1; l >= 0; --l) {
+        const int log2n = log2n0 - l, n = 1 << log2n, nc = n >> 1;
+        prolongation_body(sx + off[l], sx + off[l + 1], log2n - 1, 1, XRange{0, n, n - 1}, XRange{0, nc, nc - 1}, tid, CV_BLK);
+        __syncthreads();
+        smooth(sx + off[l], sb + off[l], log2n, npost);
+    }
+    for (int c = tid; c < cells0; c += CV_BLK) gx[c] = sx[c];
+}
+
+// on (default): pm_lap_vcycle runs the levels from 16^3 down in one launch; off: level by level
+extern "C" int pm_set_fused_coarse(pm_ctx *c, int on) {
+    PM_REQUIRE(c, "NULL argument");
+    c->mg_fused_coarse = on ? 1 : 0;
+    return PM_OK;
+}
+
 static int lap_vcycle_level(pm_ctx *c, float *x, const float *b, int n, int npre, int npost, float *scratch) {
     const float f_relax = 1.25f;  // laplacian.py:1051
     int rc;
+    if (c->mg_fused_coarse && n <= 16) {
+        hipLaunchKernelGGL(lap_vcycle_coarse_kernel, dim3(1), dim3(CV_BLK), 0, c->stream, x, b, ilog2(n), npre, npost, f_relax);
+        PM_LAUNCH_CHECK();
+        return PM_OK;
+    }
     // (the level's ping-pong grid for the single-pass sweep sits first in its share of the arena)
     float *tmp = n >= 256 ? scratch : nullptr;
     if (tmp) scratch += (int64_t)n * n * n;
@@ -873,7 +959,7 @@ extern "C" int pm_lap_vcycle(pm_ctx *c, float *d_x, const float *d_b, int n, int
     float *scratch = nullptr;
     int rc = mg_arena(c, ((size_t)n * n * n * (n >= 256 ? 11 : 2) / 7 + 1024) * sizeof(float), &scratch);
     if (rc) return rc;
-    return vcycle_graphed(c, c->mg_fused_sweep ? 1 : 0, d_x, d_b, 0.f, n, npre, npost,
+    return vcycle_graphed(c, (c->mg_fused_sweep ? 1 : 0) | (c->mg_fused_coarse ? 2 : 0), d_x, d_b, 0.f, n, npre, npost,
                           [&]() { return lap_vcycle_level(c, d_x, d_b, n, npre, npost, scratch); });
 }
 

@@ -428,3 +428,35 @@ def test_vcycle_graph_replay_is_the_plain_cycle(amd):
         assert out[1][1:] == (3, 1), out[1][1:]  # captured once, replayed three times
         np.testing.assert_array_equal(out[0][0], out[1][0])
         assert np.isfinite(out[1][0]).all() and np.abs(out[1][0] - x0.cpu().numpy()).max() > 0
+
+
+@pytest.mark.parametrize("n", [8, 16, 32, 128])
+def test_fused_coarse_levels_are_the_launches(amd, n):
+    """pm_lap_vcycle with every level from 16^3 down run by one workgroup in LDS (lap_vcycle_coarse_kernel) against
+    the same cycle issued level by level: bit for bit, for top-level grids of 8^3 (one kernel is the whole cycle) to
+    128^3, plain launches and graph replay alike."""
+    torch = amd.torch
+    from pysco_amd import _lib as L
+
+    ctx = L.context(4)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7 * n)
+    b = torch.rand((n, n, n), generator=g, device="cuda") - 0.5
+    x0 = (torch.rand((n, n, n), generator=g, device="cuda") - 0.5) * 1e-3
+    out = {}
+    try:
+        for fused in (0, 1):
+            ctx.call("pm_set_fused_coarse", fused)
+            for graphs in (0, 1):
+                ctx.call("pm_set_vcycle_graphs", graphs)
+                x = x0.clone()
+                for _ in range(3):
+                    ctx.call("pm_lap_vcycle", L.ptr(x), L.ptr(b), n, 2, 1)
+                out[(fused, graphs)] = x.cpu().numpy()
+    finally:
+        ctx.call("pm_set_fused_coarse", 1)
+        ctx.call("pm_set_vcycle_graphs", 1)
+    ref = out[(0, 0)]
+    assert np.isfinite(ref).all() and np.abs(ref - x0.cpu().numpy()).max() > 0
+    for key, val in out.items():
+        np.testing.assert_array_equal(val, ref, err_msg=str(key))
