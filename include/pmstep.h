@@ -68,6 +68,10 @@ int pm_gradient_fr(pm_ctx *ctx, int order, int fr_n, float f, const float *d_phi
 /* ---- utils.py ----------------------------------------------------------------------------- */
 int pm_axpy(pm_ctx *ctx, float *d_y, const float *d_x, float a, int64_t count);              /* :264 */
 int pm_scale(pm_ctx *ctx, float *d_y, float a, int64_t count);                                /* :410 */
+/* The memory traffic of the fused kick + drift of np particles with every value left as it is (two [np, 3] arrays
+ * rewritten in place, a third read): the probe main.tune_placement times over combinations of allocations.  No
+ * reference counterpart. */
+int pm_probe_update(pm_ctx *ctx, float *d_a, float *d_b, const float *d_c, int64_t np);
 int pm_linear_operator(pm_ctx *ctx, float *d_out, const float *d_x, float f1, float f2,
                        int64_t count);                                                        /* :644, :684 */
 int pm_linear_operator_vectors(pm_ctx *ctx, float *d_x, float f1, const float *d_y, float f2,

@@ -38,6 +38,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_gradient_fr": (_vp, _i, _i, _f, _vp, _vp, _vp),
     "pm_axpy": (_vp, _vp, _vp, _f, _i64),
     "pm_scale": (_vp, _vp, _f, _i64),
+    "pm_probe_update": (_vp, _vp, _vp, _vp, _i64),
     "pm_linear_operator": (_vp, _vp, _vp, _f, _f, _i64),
     "pm_linear_operator_vectors": (_vp, _vp, _f, _vp, _f, _i64),
     "pm_max_abs": (_vp, _vp, _i64, C.POINTER(_f)),

@@ -72,6 +72,36 @@ extern "C" int pm_scale(pm_ctx *c, float *d_y, float a, int64_t count) {
     return ew_launch<OP_SCALE, true, false>(c, d_y, nullptr, a, 0.f, count);
 }
 
+// The memory traffic of the fused kick + drift of np particles -- two [np, 3] arrays updated in place, a third one
+// read, 16-byte nontemporal accesses -- with the values left as they are (x * 1): what
+// main.tune_placement times to choose which allocations hold position, velocity and acceleration.  How fast the
+// update runs depends on the COMBINATION of arrays, not only on each one (placement).
+typedef float probe_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(BLK) void probe_update_kernel(probe_v4f *__restrict__ a, probe_v4f *__restrict__ b,
+                                                           const probe_v4f *__restrict__ c4, int64_t quads, float one) {
+    for (int64_t q = (int64_t)blockIdx.x * BLK + threadIdx.x; q < quads; q += (int64_t)gridDim.x * BLK) {
+        const probe_v4f x = __builtin_nontemporal_load(a + q), y = __builtin_nontemporal_load(b + q),
+                        z = __builtin_nontemporal_load(c4 + q);
+        const bool never = z.x != z.x && z.y == 12345.0f && z.z == 54321.0f;  // (keeps the third stream's loads alive)
+        // (`one` is 1 at run time only: with a literal the compiler sees stores of the values just loaded and drops
+        // them -- the first version of this probe timed three reads and no write)
+        __builtin_nontemporal_store(never ? z : x * one, a + q);
+        __builtin_nontemporal_store(y * one, b + q);
+    }
+}
+
+extern "C" int pm_probe_update(pm_ctx *c, float *d_a, float *d_b, const float *d_c, int64_t np) {
+    PM_REQUIRE(c && d_a && d_b && d_c && np >= 0 && d_a != d_b, "bad argument");
+    PM_REQUIRE(pm_aligned16(d_a) && pm_aligned16(d_b) && pm_aligned16(d_c) && (np % 4) == 0,
+               "pm_probe_update wants 16-byte aligned arrays of a multiple of four particles");
+    if (np == 0) return PM_OK;
+    const int64_t quads = 3 * np / 4;
+    hipLaunchKernelGGL(probe_update_kernel, dim3(pm_stream_blocks(quads, BLK)), dim3(BLK), 0, c->stream, (probe_v4f *)d_a,
+                       (probe_v4f *)d_b, (const probe_v4f *)d_c, quads, 1.0f);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
 extern "C" int pm_linear_operator(pm_ctx *c, float *d_out, const float *d_x, float f1, float f2, int64_t count) {
     PM_REQUIRE(c && d_out && d_x && count >= 0, "bad argument");
     return ew_launch<OP_LINOP, false, true>(c, d_out, d_x, f1, f2, count);

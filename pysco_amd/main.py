@@ -39,15 +39,19 @@ def reserve_step_buffers(position) -> None:
             mesh._rebucket_pool.append(torch.empty_like(position))
 
 
-def tune_placement(position, velocity, acceleration=None, max_candidates: int = 15):
-    """Measured on MI355X: the bandwidth of an in-place read-modify-write pass over a 12.9 GB array depends on the
-    physical memory the allocation landed in -- 5.08 TB/s for some allocations, 4.5 TB/s for others made by the same
-    call a moment earlier (tools/bench_array_single.py) -- and the fused kick + drift + deposit, which updates
-    position and velocity in place, runs 14 or 16-17 ms at 1024^3 accordingly.  Nothing in the virtual layout controls
-    it, so this allocates candidate arrays (as many as fit comfortably), times a multiply-by-one pass over each and
-    over the caller's arrays, gives the four fastest to position and velocity of the live set and of the gather's
-    output set, the next two to the accelerations; the rest is freed.  One-time cost: about 6 ms per candidate at 1024^3.  Returns the (possibly new)
-    position, velocity[, acceleration] tensors; values and order unchanged."""
+def tune_placement(position, velocity, acceleration=None, max_candidates: int = 10):
+    """Measured on MI355X: how fast the fused kick + drift + deposit streams through the particle arrays -- position
+    and velocity updated in place, acceleration read -- depends on the physical memory the allocations landed in, and
+    on the COMBINATION of arrays more than on each one: an in-place pass over a single 12.9 GB array runs at 5.08 or
+    4.5 TB/s depending on the allocation (tools/bench_array_single.py), and the three-array update takes 11.05 to
+    11.85 ms over triples of arrays that are all "fast" on their own, while a "slow" one can be part of the fastest
+    triples (tools/exp_triples.py); the kernel then runs 13.2 or 15.1 ms at 1024^3.  Nothing in the virtual layout
+    controls it, so this allocates candidate arrays, times the update's own access pattern (pm_probe_update: values
+    unchanged) over every PAIR (updated, updated) of candidates, takes the best pair for position and velocity of the
+    live set, the best disjoint pair for the set the re-bucketing gather writes (the fused kick updates that one in
+    place a step later), then the best third array for each; the rest is freed.  One-time cost at 1024^3: 0.3 s per
+    candidate allocated + about 11 ms per combination timed (1 s).  Returns the (possibly new) position, velocity[,
+    acceleration] tensors; values and order unchanged."""
     if not L.is_device_array(position):
         return (position, velocity) if acceleration is None else (position, velocity, acceleration)
     from . import mesh
@@ -55,7 +59,6 @@ def tune_placement(position, velocity, acceleration=None, max_candidates: int = 
     torch = L.require_gpu()
     ctx = L.context(4)
     live = [position, velocity] + ([acceleration] if acceleration is not None else [])
-    need = 6
     free_bytes, _ = torch.cuda.mem_get_info(position.device)
     each = position.numel() * 4
     # (the candidates that are not kept are freed again before anything else is allocated: they may use what is free now)
@@ -64,36 +67,55 @@ def tune_placement(position, velocity, acceleration=None, max_candidates: int = 
     cand = []
     try:
         for _ in range(n_cand):
-            cand.append(torch.empty_like(position))
+            cand.append(torch.zeros_like(position))
     except torch.OutOfMemoryError:
         pass
+    arrays = live + cand
+    n, npart = len(arrays), position.shape[0]
+    if npart % 4:  # (the probe streams whole float4: odd sizes are not worth tuning)
+        reserve_step_buffers(position)
+        return tuple(live)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def probe(t):  # x *= 1 leaves every bit pattern as it is
-        best = 1e30
-        for _ in range(2):
-            e0.record()
-            ctx.call("pm_scale", L.ptr(t), 1.0, t.numel())
-            e1.record()
-            torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1))
+    def probe(i, j, k):  # the update's traffic over (arrays[i], arrays[j]) in place + arrays[k] read; x * 1 leaves every value
+        e0.record()
+        ctx.call("pm_probe_update", L.ptr(arrays[i]), L.ptr(arrays[j]), L.ptr(arrays[k]), npart)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    global last_placement_probe_ms
+    if n < 6:  # no room for a second set: leave things as they are
+        last_placement_probe_ms = None
+        reserve_step_buffers(position)
+        return tuple(live)
+    probe(0, 1, 2)  # (warm-up)
+    pairs = []
+    for i in range(n):
+        for j in range(i + 1, n):
+            k = next(m for m in range(n) if m != i and m != j)
+            pairs.append((probe(i, j, k), i, j))
+    pairs.sort()
+    # the leaders again (one timing each is noisy at the 1 % level), best of three
+    top = sorted((min(ms, probe(i, j, next(m for m in range(n) if m != i and m != j)),
+                      probe(i, j, next(m for m in range(n) if m != i and m != j))), i, j) for ms, i, j in pairs[:8])
+    set_a = top[0]
+    rest = [t for t in top[1:] if not {t[1], t[2]} & {set_a[1], set_a[2]}]
+    set_b = rest[0] if rest else next(t for t in pairs if not {t[1], t[2]} & {set_a[1], set_a[2]})
+    used = {set_a[1], set_a[2], set_b[1], set_b[2]}
+
+    def third(pair):  # the array read beside this pair: the best of those still free
+        free = [m for m in range(n) if m not in used]
+        best = min((probe(pair[1], pair[2], m), m) for m in free)
+        used.add(best[1])
         return best
 
-    for t in cand:
-        t.zero_()
-    timed = sorted([(probe(t), i, t, i < len(live)) for i, t in enumerate(live + cand)], key=lambda r: r[0])
-    logging.info("placement probe [ms]: " + " ".join(f"{ms:.2f}{'*' if is_live else ''}" for ms, _, _, is_live in timed))
-    global last_placement_probe_ms
-    last_placement_probe_ms = [round(ms, 3) for ms, _, _, _ in timed]  # (ascending; the first six are kept)
-    ranked = [t for _, _, t, _ in timed[:need]]
-    # roles by rank: the fused kick + drift updates position and velocity IN PLACE, in the live set and -- a step
-    # later -- in the set the gather wrote (mesh._rebucket_pool, whose roles are stable): those four take the four
-    # fastest arrays; the accelerations are only read and written once each (pure streams differ by 5 %)
-    if len(ranked) >= 6:
-        homes = [ranked[0], ranked[1], ranked[4]][:len(live)]
-        spare = [ranked[2], ranked[3], ranked[5]]
-    else:  # not enough memory for a second set: the live arrays into the fastest ones, whatever is left to the pool
-        homes, spare = ranked[:len(live)], ranked[len(live):]
+    acc_a, acc_b = third(set_a), third(set_b)
+    last_placement_probe_ms = {"pairs": [round(t[0], 3) for t in pairs], "live_set": round(acc_a[0], 3),
+                               "output_set": round(acc_b[0], 3)}
+    logging.info(f"placement probe [ms]: pairs {pairs[0][0]:.2f} .. {pairs[-1][0]:.2f}, chosen triples {acc_a[0]:.2f} {acc_b[0]:.2f}")
+    homes = [arrays[set_a[1]], arrays[set_a[2]], arrays[acc_a[1]]][:len(live)]
+    spare = [arrays[set_b[1]], arrays[set_b[2]], arrays[acc_b[1]]]
     same = lambda a, b: a.data_ptr() == b.data_ptr()  # noqa: E731
     # move the data: a home that still holds another live array's data waits until that array has moved (a cycle is
     # broken through a scratch copy)
@@ -106,11 +128,9 @@ def tune_placement(position, velocity, acceleration=None, max_candidates: int = 
         else:
             x, h = pending[0]
             pending[0] = (x.clone(), h)
-    displaced = [x for x, h in zip(live, homes) if not same(x, h) and not any(same(x, t) for t in homes + spare)]
-    spare = [t for t in spare if not any(same(t, h) for h in homes)] + displaced  # (a slow array beats a hipMalloc in the loop)
-    mesh._rebucket_pool.extend(spare[:3])
+    mesh._rebucket_pool.extend(spare)
     out = homes
-    del cand, timed, ranked, spare, displaced
+    del cand, arrays, pairs, top, spare
     torch.cuda.empty_cache()
     return tuple(out)
 

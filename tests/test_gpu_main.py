@@ -189,3 +189,39 @@ def test_run_from_a_power_spectrum_2lpt(tmp_path):
     def rms(p):
         return np.sqrt(((((p * 128) % 1) - 0.5) ** 2).sum(-1).mean())
     assert rms(p2) > 1.2 * rms(p0)
+
+
+def test_tune_placement_keeps_the_values_and_fills_the_pool():
+    """main.tune_placement: the particle data end up in (possibly different) allocations chosen by timing the update's
+    own access pattern over combinations of candidates (pm_probe_update leaves every value as it is); the three arrays
+    of the gather's output set are in the pool, distinct from the live ones."""
+    import torch
+
+    from pysco_amd import _lib as L
+    from pysco_amd import main as amd_main
+    from pysco_amd import mesh
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    pos = torch.rand((300_000, 3), generator=g, device="cuda")
+    vel = torch.randn((300_000, 3), generator=g, device="cuda")
+    acc = torch.randn((300_000, 3), generator=g, device="cuda")
+    vel[7, 1] = -0.0
+    ref = [t.clone() for t in (pos, vel, acc)]
+    # the probe itself leaves the arrays bit for bit
+    L.context(4).call("pm_probe_update", L.ptr(pos), L.ptr(vel), L.ptr(acc), pos.shape[0])
+    for t, r in zip((pos, vel, acc), ref):
+        assert torch.equal(t.view(torch.int32), r.view(torch.int32))
+    try:
+        out = amd_main.tune_placement(pos, vel, acc, max_candidates=5)
+        assert len(out) == 3
+        for t, r in zip(out, ref):
+            assert torch.equal(t.view(torch.int32), r.view(torch.int32))
+        ptrs = {t.data_ptr() for t in out}
+        pool = list(mesh._rebucket_pool)
+        assert len(pool) == 3 and len(ptrs | {t.data_ptr() for t in pool}) == 6
+        assert isinstance(amd_main.last_placement_probe_ms, dict) and len(amd_main.last_placement_probe_ms["pairs"]) == 28
+        two = amd_main.tune_placement(out[0], out[1], None, max_candidates=4)
+        assert len(two) == 2 and torch.equal(two[0], ref[0]) and torch.equal(two[1], ref[1])
+    finally:
+        mesh._rebucket_pool.clear()
