@@ -720,6 +720,59 @@ __global__ __launch_bounds__(FBLK) void fftp_z_c2r(const float2 *__restrict__ B,
 
 // ---- host side -----------------------------------------------------------------------------------------------
 
+// The work arrays of the five passes are rewritten in place (C by the x pass) or read and written whole by every
+// pass; how fast an in-place pass over a multi-GB allocation runs depends on the physical memory it landed in (5.08
+// or 4.5 TB/s, DESIGN.md section 5 "placement").  Large buffers are therefore chosen: a few candidate allocations, an
+// in-place pass over each (x * 1, the multiplier known at run time only), the fastest kept, the others freed.
+typedef float fftp_pv4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void fftp_probe_kernel(fftp_pv4 *__restrict__ a, int64_t quads, float one) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(a + q) * one, a + q);
+}
+
+static int fftp_alloc_chosen(pm_ctx *c, size_t bytes, void **out) {
+    *out = nullptr;
+    constexpr int K = 5;
+    size_t free_b = 0, total_b = 0;
+    if (bytes < ((size_t)1 << 30) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < (K + 1) * bytes) {
+        (void)hipGetLastError();
+        PM_HIP(hipMalloc(out, bytes));
+        return PM_OK;
+    }
+    void *cand[K] = {nullptr};
+    float ms[K];
+    int got = 0;
+    for (; got < K; ++got)
+        if (hipMalloc(&cand[got], bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+    if (got == 0) {
+        pm_set_error("out of device memory for the FFT work arrays");
+        return PM_EHIP;
+    }
+    const int64_t quads = (int64_t)(bytes / 16);
+    int best = 0;
+    for (int k = 0; k < got; ++k) {
+        ms[k] = 1e30f;
+        (void)hipMemsetAsync(cand[k], 0, bytes, c->stream);
+        for (int rep = 0; rep < 3; ++rep) {  // (the first pass also faults the pages in)
+            (void)hipEventRecord(c->ev0, c->stream);
+            hipLaunchKernelGGL(fftp_probe_kernel, dim3(256 * 16), dim3(256), 0, c->stream, (fftp_pv4 *)cand[k], quads, 1.0f);
+            (void)hipEventRecord(c->ev1, c->stream);
+            (void)hipEventSynchronize(c->ev1);
+            float t = 1e30f;
+            if (hipEventElapsedTime(&t, c->ev0, c->ev1) == hipSuccess && rep > 0 && t < ms[k]) ms[k] = t;
+        }
+        if (ms[k] < ms[best]) best = k;
+    }
+    (void)hipGetLastError();
+    for (int k = 0; k < got; ++k)
+        if (k != best) (void)hipFree(cand[k]);
+    *out = cand[best];
+    return PM_OK;
+}
+
 static int ensure_fused_buffers(pm_ctx *c, size_t b_bytes, size_t c_bytes) {
     const int n = c->n;
     if (!c->fp_tw) {
@@ -745,13 +798,13 @@ static int ensure_fused_buffers(pm_ctx *c, size_t b_bytes, size_t c_bytes) {
     if (c->fp_B_bytes < b_bytes) {
         if (c->fp_B) PM_HIP(hipFree(c->fp_B));
         c->fp_B = nullptr, c->fp_B_bytes = 0;
-        PM_HIP(hipMalloc(&c->fp_B, b_bytes));
+        if (int rc = fftp_alloc_chosen(c, b_bytes, &c->fp_B)) return rc;
         c->fp_B_bytes = b_bytes;
     }
     if (c->fp_C_bytes < c_bytes) {
         if (c->fp_C) PM_HIP(hipFree(c->fp_C));
         c->fp_C = nullptr, c->fp_C_bytes = 0;
-        PM_HIP(hipMalloc(&c->fp_C, c_bytes));
+        if (int rc = fftp_alloc_chosen(c, c_bytes, &c->fp_C)) return rc;
         c->fp_C_bytes = c_bytes;
     }
     return PM_OK;
