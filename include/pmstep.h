@@ -108,10 +108,13 @@ int pm_grad_inverse_laplacian(pm_ctx *ctx, int p, const void *d_xk, void *d_out3
 /* ---- initial conditions (initial_conditions.py:108-158, fourier.py:730-905) -------- */
 /* fourier.gradient (fourier.py:730): out_m = i 2 pi k_m x, three planar half-spectra [3][n, n, n/2+1] */
 int pm_kspace_gradient(pm_ctx *ctx, const void *d_xk, void *d_out3, const float *h_kfreq);
-/* fourier.hessian (:784; a2 = b2 = -1): -k_a1 k_b1 4 pi^2 x;  fourier.sum_of_hessian (:842): -(k_a1 k_b1 + k_a2 k_b2) 4 pi^2 x */
+/* fourier.hessian (:784; a2 = b2 = -1): -k_a1 k_b1 4 pi^2 x;  fourier.sum_of_hessian (:842): -(k_a1 k_b1 + k_a2 k_b2) 4 pi^2 x;
+ * fourier.diff_of_hessian (:907; second pair given as 4 + axis): -(k_a1 k_b1 - k_a2 k_b2) 4 pi^2 x */
 int pm_kspace_hessian(pm_ctx *ctx, const void *d_xk, void *d_out, const float *h_kfreq, int a1, int b1, int a2, int b2);
 /* y = f a b (accumulate 0: utils.prod_vector_vector_inplace, utils.py:500) or y += f a b (1: add_vector_vector_inplace, :330) */
 int pm_addcmul(pm_ctx *ctx, float *d_y, float f, const float *d_a, const float *d_b, int64_t count, int accumulate);
+/* y += f a b c (utils.add_vector_vector_vector_inplace, utils.py:368) */
+int pm_addcmul3(pm_ctx *ctx, float *d_y, float f, const float *d_a, const float *d_b, const float *d_c, int64_t count);
 /* initialise_1LPT_center / _edge (mode 0 / 1: x = q - D psi, v = -(D fH) psi, initial_conditions.py:1688-1806) and
  * add_nLPT (mode 2: x += D psi, v += (D fH) psi, :1809-1856) on a displacement field psi [n, n, n, 3]; ctx of size n */
 int pm_lpt_displace(pm_ctx *ctx, const float *d_psi, float dplus, float dfh, int mode, float *d_pos, float *d_vel);

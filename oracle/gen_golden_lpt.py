@@ -46,10 +46,15 @@ CASES = {
     "2lpt_center_n16": dict(npart=16**3, initial_conditions="2LPT", position_ICS="center", fixed_ICS=False, paired_ICS=False, seed=7),
     "2lpt_edge_fixed_paired_n16": dict(npart=16**3, initial_conditions="2LPT", position_ICS="edge", fixed_ICS=True, paired_ICS=True, seed=3),
     "2lpt_center_n32": dict(npart=32**3, initial_conditions="2LPT", position_ICS="center", fixed_ICS=False, paired_ICS=False, seed=11),
+    "3lpt_center_n16": dict(npart=16**3, initial_conditions="3LPT", position_ICS="center", fixed_ICS=False, paired_ICS=False, seed=5),
+    "3lpt_edge_n32": dict(npart=32**3, initial_conditions="3LPT", position_ICS="edge", fixed_ICS=False, paired_ICS=False, seed=13),
 }
+ONLY = [a for a in sys.argv[1:] if a in CASES]  # regenerate a subset: python oracle/gen_golden_lpt.py 3lpt_center_n16 ...
 
 k_tab, pk_tab = power_spectrum_table()
 for tag, case in CASES.items():
+    if ONLY and tag not in ONLY:
+        continue
     with tempfile.TemporaryDirectory() as tmp:
         pk_file = os.path.join(tmp, "pk.dat")
         np.savetxt(pk_file, np.c_[k_tab, pk_tab])
@@ -68,7 +73,9 @@ for tag, case in CASES.items():
         n = int(round(case["npart"] ** (1 / 3)))
         lna = np.log(1.0 / (1 + p["z_start"]))
         scalars = {"Hz": float(tables[2](lna)), "d1_z0": float(tables[3](0)), "d1": float(tables[3](lna)), "f1": float(tables[4](lna)),
-                   "d2": float(tables[5](lna)), "f2": float(tables[6](lna)), "unit_t": float(p["unit_t"]), "aexp": float(p["aexp"])}
+                   "d2": float(tables[5](lna)), "f2": float(tables[6](lna)), "unit_t": float(p["unit_t"]), "aexp": float(p["aexp"]),
+                   "d3a": float(tables[7](lna)), "f3a": float(tables[8](lna)), "d3b": float(tables[9](lna)),
+                   "f3b": float(tables[10](lna)), "d3c": float(tables[11](lna)), "f3c": float(tables[12](lna))}
         out = {"k_table": k_tab, "pk_table": pk_tab, "density_k_half": np.ascontiguousarray(dk[:, :, : n // 2 + 1]),
                "position": pos.reshape(-1, 3), "velocity": vel.reshape(-1, 3),
                "param_json": np.array(repr({k: v for k, v in case.items()})),

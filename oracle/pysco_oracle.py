@@ -922,6 +922,58 @@ def sum_of_hessian(x, ij1, ij2) -> np.ndarray:  # fourier.py:842-904
     return ((c * x.real) + 1j * (c * x.imag)).astype(np.complex64)
 
 
+def diff_of_hessian(x, ij1, ij2) -> np.ndarray:  # fourier.py:907-961
+    kk = _kvec(x.shape[0])
+    c = -(kk[ij1[0]] * kk[ij1[1]] - kk[ij2[0]] * kk[ij2[1]]) * np.float32(4 * np.pi**2)
+    return ((c * x.real) + 1j * (c * x.imag)).astype(np.complex64)
+
+
+def _hr(phi_k, ij):
+    return ifft_3D_real(hessian(phi_k, ij))
+
+
+def compute_3a_rhs(phi_1_k) -> np.ndarray:  # initial_conditions.py:1042-1121 (no de-aliasing)
+    one, two = np.float32(1), np.float32(2)
+    out = _hr(phi_1_k, (0, 0))
+    out = out * (one * _hr(phi_1_k, (1, 1)))
+    out = out * (one * _hr(phi_1_k, (2, 2)))
+    out = out + two * _hr(phi_1_k, (0, 1)) * _hr(phi_1_k, (0, 2)) * _hr(phi_1_k, (1, 2))
+    for off, diag in (((1, 2), (0, 0)), ((0, 2), (1, 1)), ((0, 1), (2, 2))):
+        t1 = _hr(phi_1_k, off)
+        out = out + (-one) * t1 * t1 * _hr(phi_1_k, diag)
+    return out.astype(np.float32)
+
+
+def compute_3b_rhs(phi_1_k, phi_2_k) -> np.ndarray:  # initial_conditions.py:1162-1246
+    one, half = np.float32(1), np.float32(0.5)
+    out = _hr(phi_1_k, (0, 0))
+    out = out * (half * ifft_3D_real(sum_of_hessian(phi_2_k, (1, 1), (2, 2))))
+    out = out + half * _hr(phi_1_k, (1, 1)) * ifft_3D_real(sum_of_hessian(phi_2_k, (0, 0), (2, 2)))
+    out = out + half * _hr(phi_1_k, (2, 2)) * ifft_3D_real(sum_of_hessian(phi_2_k, (0, 0), (1, 1)))
+    for ij in ((0, 1), (0, 2), (1, 2)):
+        out = out + (-one) * _hr(phi_1_k, ij) * _hr(phi_2_k, ij)
+    return out.astype(np.float32)
+
+
+# 3c: the three components of the transverse part (initial_conditions.py:1290-1361, 1405-1476, 1520-1591): per
+# component (first term's two Hessians of phi_1 / phi_2, the pair of the second term, and the (off-diagonal,
+# difference of diagonals) pair of the last two)
+_3C = {"Ax": (((0, 2), (0, 1)), ((0, 2), (0, 1)), (1, 2), ((1, 1), (2, 2))),
+       "Ay": (((0, 1), (1, 2)), ((0, 1), (1, 2)), (0, 2), ((2, 2), (0, 0))),
+       "Az": (((1, 2), (0, 2)), ((1, 2), (0, 2)), (0, 1), ((0, 0), (1, 1)))}
+
+
+def compute_3c_rhs(phi_1_k, phi_2_k, which: str) -> np.ndarray:
+    one = np.float32(1)
+    (a1, a2), (b2, b1), off, (d1, d2) = _3C[which]
+    out = _hr(phi_1_k, a1)
+    out = out * (one * _hr(phi_2_k, a2))
+    out = out + (-one) * _hr(phi_2_k, b2) * _hr(phi_1_k, b1)
+    out = out + one * _hr(phi_1_k, off) * ifft_3D_real(diff_of_hessian(phi_2_k, d1, d2))
+    out = out + (-one) * _hr(phi_2_k, off) * ifft_3D_real(diff_of_hessian(phi_1_k, d1, d2))
+    return out.astype(np.float32)
+
+
 def compute_2ndorder_rhs(phi_1_k) -> np.ndarray:  # initial_conditions.py:976-1039 (no de-aliasing)
     phi_2 = ifft_3D_real(hessian(phi_1_k, (0, 0)))
     phi_2 = phi_2 * ifft_3D_real(sum_of_hessian(phi_1_k, (1, 1), (2, 2)))
@@ -949,7 +1001,7 @@ def lpt_particles(density_k_half, order: str, position_ics: str, scalars):
     lattice = np.stack(np.meshgrid(q, q, q, indexing="ij"), axis=-1)
     position = (lattice + dplus_1 * (-psi)).astype(np.float32)
     velocity = ((dplus_1 * fH_1) * (-psi)).astype(np.float32)
-    if order.casefold() == "2lpt":
+    if order.casefold() in ("2lpt", "3lpt"):
         rho2_k = fft_3D_real(compute_2ndorder_rhs(pot1))
         with np.errstate(all="ignore"):
             inverse_laplacian(rho2_k)
@@ -958,6 +1010,20 @@ def lpt_particles(density_k_half, order: str, position_ics: str, scalars):
         fH_2 = np.float32(scalars["f2"] * Hz)
         position = (position + dplus_2 * psi2).astype(np.float32)
         velocity = (velocity + (dplus_2 * fH_2) * psi2).astype(np.float32)
+    if order.casefold() == "3lpt":  # initial_conditions.py:159-198: every term through grad(inverse Laplacian)
+        def add(rhs, d, f):
+            nonlocal position, velocity
+            psi3 = ifft_3D_real_grad(gradient_inverse_laplacian(fft_3D_real(rhs)))
+            dplus = -np.float32(d / scalars["d1_z0"] ** 3)
+            fH = np.float32(f * Hz)
+            position = (position + dplus * psi3).astype(np.float32)
+            velocity = (velocity + (dplus * fH) * psi3).astype(np.float32)
+
+        with np.errstate(all="ignore"):
+            add(compute_3a_rhs(pot1), scalars["d3a"], scalars["f3a"])
+            add(compute_3b_rhs(pot1, rho2_k), scalars["d3b"], scalars["f3b"])
+            for which in ("Ax", "Ay", "Az"):
+                add(compute_3c_rhs(pot1, rho2_k, which), scalars["d3c"], scalars["f3c"])
     position, velocity = np.ascontiguousarray(position.reshape(-1, 3)), np.ascontiguousarray(velocity.reshape(-1, 3))
     periodic_wrap(position)
     return position, velocity

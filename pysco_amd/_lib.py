@@ -53,6 +53,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_kspace_gradient": (_vp, _vp, _vp, _vp),
     "pm_kspace_hessian": (_vp, _vp, _vp, _vp, _i, _i, _i, _i),
     "pm_addcmul": (_vp, _vp, _f, _vp, _vp, _i64, _i),
+    "pm_addcmul3": (_vp, _vp, _f, _vp, _vp, _vp, _i64),
     "pm_lpt_displace": (_vp, _vp, _f, _f, _i, _vp, _vp),
     "pm_pk": (_vp, _i, _vp, _vp, _vp, _vp, _vp),
     "pm_poisson_fft": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),

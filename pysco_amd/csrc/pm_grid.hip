@@ -640,6 +640,8 @@ __global__ __launch_bounds__(BLK) void kspace_hessian_kernel(const float2 *__res
         float c;
         if (a2 < 0)
             c = (-kk[a1] * kk[b1]) * fourpi2;  // hessian: -kn * km * fourpi2
+        else if (a2 >= 4)
+            c = -(kk[a1] * kk[b1] - kk[a2 - 4] * kk[b2 - 4]) * fourpi2;  // diff_of_hessian (fourier.py:907)
         else
             c = -(kk[a1] * kk[b1] + kk[a2] * kk[b2]) * fourpi2;  // sum_of_hessian
         const float2 v = x[t];
@@ -661,7 +663,9 @@ extern "C" int pm_kspace_gradient(pm_ctx *c, const void *d_xk, void *d_out3, con
 extern "C" int pm_kspace_hessian(pm_ctx *c, const void *d_xk, void *d_out, const float *h_kfreq, int a1, int b1, int a2,
                                  int b2) {
     PM_REQUIRE(c && d_xk && d_out && h_kfreq, "NULL argument");
-    PM_REQUIRE(a1 >= 0 && a1 < 3 && b1 >= 0 && b1 < 3 && a2 < 3 && b2 < 3 && (a2 < 0) == (b2 < 0), "axes are 0, 1, 2 (second pair -1, -1: off)");
+    PM_REQUIRE(a1 >= 0 && a1 < 3 && b1 >= 0 && b1 < 3 && a2 < 7 && a2 != 3 && b2 < 7 && b2 != 3 && (a2 < 0) == (b2 < 0) &&
+                   (a2 >= 4) == (b2 >= 4),
+               "axes are 0, 1, 2 (second pair -1, -1: off; 4 + axis, 4 + axis: subtracted)");
     const int n = c->n;
     PM_HIP(hipMemcpyAsync(c->d_tab, h_kfreq, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     const int64_t total = (int64_t)n * n * (n / 2 + 1);
@@ -678,6 +682,24 @@ __global__ __launch_bounds__(BLK) void addcmul_kernel(float *__restrict__ y, flo
         const float p = f * a[t] * b[t];
         y[t] = accumulate ? y[t] + p : p;
     }
+}
+
+// y += f * a * b * c (utils.add_vector_vector_vector_inplace, utils.py:368)
+__global__ __launch_bounds__(BLK) void addcmul3_kernel(float *__restrict__ y, float f, const float *__restrict__ a,
+                                                       const float *__restrict__ b, const float *__restrict__ c3,
+                                                       int64_t count) {
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < count; t += (int64_t)gridDim.x * BLK)
+        y[t] = y[t] + f * a[t] * b[t] * c3[t];
+}
+
+extern "C" int pm_addcmul3(pm_ctx *c, float *d_y, float f, const float *d_a, const float *d_b, const float *d_c,
+                           int64_t count) {
+    PM_REQUIRE(c && d_y && d_a && d_b && d_c && count >= 0, "bad argument");
+    if (count == 0) return PM_OK;
+    hipLaunchKernelGGL(addcmul3_kernel, dim3(pm_stream_blocks(count, BLK)), dim3(BLK), 0, c->stream, d_y, f, d_a, d_b, d_c,
+                       count);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
 }
 
 extern "C" int pm_addcmul(pm_ctx *c, float *d_y, float f, const float *d_a, const float *d_b, int64_t count, int accumulate) {

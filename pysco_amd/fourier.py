@@ -162,6 +162,11 @@ def sum_of_hessian(x, ij1, ij2):
     return _hessian(x, int(ij1[0]), int(ij1[1]), int(ij2[0]), int(ij2[1]))
 
 
+def diff_of_hessian(x, ij1, ij2):
+    """-(k_i1 k_j1 - k_i2 k_j2) 4 pi^2 x (fourier.py:907)."""
+    return _hessian(x, int(ij1[0]), int(ij1[1]), 4 + int(ij2[0]), 4 + int(ij2[1]))
+
+
 def fourier_grid_to_Pk(density_k, p: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """(k, P(k), Nmodes) in grid units; also zeroes density_k[0,0,0] like the reference."""
     torch = L.require_gpu()

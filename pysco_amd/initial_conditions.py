@@ -2,8 +2,8 @@
 
 Rows f2 / f3 of SURVEY.md section 8: restart from a snapshot this library (or PySCo) wrote -- `initial_conditions` an
 integer -- in either format, with the snapshot's parameters taking over the run's (initial_conditions.py:79-107); and
-first / second order Lagrangian perturbation theory from a power spectrum table (`1LPT`, `2LPT`: pysco_amd/lpt.py,
-grid operations on the GPU).  3LPT, RayGal and Gadget inputs are not built.
+first / second / third order Lagrangian perturbation theory from a power spectrum table (`1LPT`, `2LPT`, `3LPT`:
+pysco_amd/lpt.py, grid operations on the GPU).  RayGal and Gadget inputs are not built.
 """
 from __future__ import annotations
 

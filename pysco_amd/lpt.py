@@ -6,7 +6,7 @@ with NumPy's generator exactly as the reference draws it (same seed -> same fiel
 the grid -> inverse Laplacian -> displacement = gradient -> particles displaced from the lattice; second order from
 the Hessian products of the first-order potential.  The random numbers and the transfer table are host work (a few
 NumPy calls); every grid operation -- Green's function, k-space gradient / Hessians, FFTs, products, the particle
-displacement -- is a HIP kernel behind the C ABI (include/pmstep.h).  3LPT and de-aliasing are not built.
+displacement -- is a HIP kernel behind the C ABI (include/pmstep.h).  1LPT, 2LPT and 3LPT; de-aliasing is not built.
 """
 from __future__ import annotations
 
@@ -137,13 +137,84 @@ def compute_2ndorder_rhs(potential_1_k, param):
     return phi_2
 
 
+def _no_dealiasing(param):
+    if param.get("dealiased_ICS", False):
+        raise NotImplementedError("dealiased_ICS (Orszag 3/2 padding) is not built")
+
+
+def _mul(ctx, y, f, x):  # utils.prod_vector_vector[_scalar]_inplace: y *= f * x
+    ctx.call("pm_addcmul", L.ptr(y), float(f), L.ptr(y), L.ptr(x), y.numel(), 0)
+
+
+def _addmul(ctx, y, f, a, b):  # utils.add_vector_vector_inplace: y += f * a * b
+    ctx.call("pm_addcmul", L.ptr(y), float(f), L.ptr(a), L.ptr(b), y.numel(), 1)
+
+
+def compute_3a_rhs(potential_1_k, param):
+    """phi,xx phi,yy phi,zz + 2 phi,xy phi,xz phi,yz - phi,yz^2 phi,xx - phi,xz^2 phi,yy - phi,xy^2 phi,zz
+    (initial_conditions.py:1042-1121, Scoccimarro 1998 B.2)."""
+    _no_dealiasing(param)
+    ctx = L.context(potential_1_k.shape[0])
+    out = _hessian_real(potential_1_k, (0, 0))
+    _mul(ctx, out, 1.0, _hessian_real(potential_1_k, (1, 1)))
+    _mul(ctx, out, 1.0, _hessian_real(potential_1_k, (2, 2)))
+    t1, t2, t3 = (_hessian_real(potential_1_k, ij) for ij in ((0, 1), (0, 2), (1, 2)))
+    ctx.call("pm_addcmul3", L.ptr(out), 2.0, L.ptr(t1), L.ptr(t2), L.ptr(t3), out.numel())
+    del t1, t2, t3
+    for off, diag in (((1, 2), (0, 0)), ((0, 2), (1, 1)), ((0, 1), (2, 2))):
+        t1, t2 = _hessian_real(potential_1_k, off), _hessian_real(potential_1_k, diag)
+        ctx.call("pm_addcmul3", L.ptr(out), -1.0, L.ptr(t1), L.ptr(t1), L.ptr(t2), out.numel())
+    return out
+
+
+def compute_3b_rhs(potential_1_k, potential_2_k, param):
+    """Half the mixed products of the diagonal Hessians of phi_1 and phi_2 minus the off-diagonal ones
+    (initial_conditions.py:1162-1246)."""
+    _no_dealiasing(param)
+    ctx = L.context(potential_1_k.shape[0])
+    out = _hessian_real(potential_1_k, (0, 0))
+    _mul(ctx, out, 0.5, _hessian_real(potential_2_k, (1, 1), (2, 2)))
+    _addmul(ctx, out, 0.5, _hessian_real(potential_1_k, (1, 1)), _hessian_real(potential_2_k, (0, 0), (2, 2)))
+    _addmul(ctx, out, 0.5, _hessian_real(potential_1_k, (2, 2)), _hessian_real(potential_2_k, (0, 0), (1, 1)))
+    for ij in ((0, 1), (0, 2), (1, 2)):
+        _addmul(ctx, out, -1.0, _hessian_real(potential_1_k, ij), _hessian_real(potential_2_k, ij))
+    return out
+
+
+# the transverse part, component by component (initial_conditions.py:1290-1361, 1405-1476, 1520-1591): Hessian
+# components of (phi_1, phi_2) in the first product, of (phi_2, phi_1) in the second, then the off-diagonal one that
+# multiplies the difference of two diagonal ones
+_3C = {"Ax": (((0, 2), (0, 1)), ((0, 2), (0, 1)), (1, 2), ((1, 1), (2, 2))),
+       "Ay": (((0, 1), (1, 2)), ((0, 1), (1, 2)), (0, 2), ((2, 2), (0, 0))),
+       "Az": (((1, 2), (0, 2)), ((1, 2), (0, 2)), (0, 1), ((0, 0), (1, 1)))}
+
+
+def compute_3c_rhs(potential_1_k, potential_2_k, which: str, param):
+    _no_dealiasing(param)
+    ctx = L.context(potential_1_k.shape[0])
+    (a1, a2), (b2, b1), off, (d1, d2) = _3C[which]
+    diff = lambda pot: _hessian_real(pot, d1, (4 + d2[0], 4 + d2[1]))  # noqa: E731  (fourier.diff_of_hessian)
+    out = _hessian_real(potential_1_k, a1)
+    _mul(ctx, out, 1.0, _hessian_real(potential_2_k, a2))
+    _addmul(ctx, out, -1.0, _hessian_real(potential_2_k, b2), _hessian_real(potential_1_k, b1))
+    _addmul(ctx, out, 1.0, _hessian_real(potential_1_k, off), diff(potential_2_k))
+    _addmul(ctx, out, -1.0, _hessian_real(potential_2_k, off), diff(potential_1_k))
+    return out
+
+
+def _displacement_from_density(density):
+    """psi = ifft(grad(inverse Laplacian(fft(density)))) as [n, n, n, 3]: the form the third-order terms use
+    (initial_conditions.py:1152-1157: fourier.gradient_inverse_laplacian + ifft_3D_real_grad)."""
+    return fourier.ifft_3D_real_grad(fourier.gradient_inverse_laplacian(fourier.fft_3D_real(density)))
+
+
 def generate(param, tables):
-    """(position, velocity) [Np, 3] float32 device tensors from 1LPT or 2LPT (initial_conditions.py:108-158), wrapped
+    """(position, velocity) [Np, 3] float32 device tensors from 1LPT, 2LPT or 3LPT (initial_conditions.py:108-205), wrapped
     into the box and written as snapshot 0 like finalise_initial_conditions (:216-279)."""
     torch = L.require_gpu()
     order = param["initial_conditions"].casefold()
-    if order not in ("1lpt", "2lpt"):
-        raise NotImplementedError(f"{param['initial_conditions']=}: 1LPT and 2LPT are built (3LPT is not)")
+    if order not in ("1lpt", "2lpt", "3lpt"):
+        raise ValueError(f"{param['initial_conditions']=}, should be 1LPT, 2LPT or 3LPT")
     lna_start = np.log(1.0 / (1 + param["z_start"]))
     logging.warning(f"{param['z_start']=}")
     Hz = float(tables[2](lna_start)) * param["unit_t"] / (1e3 * _PC)  # km/s/Mpc -> box units
@@ -164,7 +235,7 @@ def generate(param, tables):
     ctx.call("pm_lpt_displace", L.ptr(psi), float(dplus_1), float(dplus_1 * fH_1), 0 if POSITION == "center" else 1,
              L.ptr(position), L.ptr(velocity))
     del psi
-    if order == "2lpt":
+    if order in ("2lpt", "3lpt"):
         logging.warning("Compute 2LPT contribution")
         density_2 = compute_2ndorder_rhs(potential_1_k, param)
         density_2_k = fourier.fft_3D_real(density_2)
@@ -175,6 +246,20 @@ def generate(param, tables):
         fH_2 = np.float32(float(tables[6](lna_start)) * Hz)
         ctx.call("pm_lpt_displace", L.ptr(psi_2), float(dplus_2), float(dplus_2 * fH_2), 2, L.ptr(position), L.ptr(velocity))
         del psi_2
+    if order == "3lpt":  # initial_conditions.py:159-198
+        potential_2_k = density_2_k
+
+        def add(label, density_3, i_d):
+            logging.warning(f"Compute 3LPT {label} contribution")
+            psi_3 = _displacement_from_density(density_3)
+            dplus_3 = -np.float32(float(tables[i_d](lna_start)) / d1_z0**3)
+            fH_3 = np.float32(float(tables[i_d + 1](lna_start)) * Hz)
+            ctx.call("pm_lpt_displace", L.ptr(psi_3), float(dplus_3), float(dplus_3 * fH_3), 2, L.ptr(position), L.ptr(velocity))
+
+        add("a)", compute_3a_rhs(potential_1_k, param), 7)
+        add("b)", compute_3b_rhs(potential_1_k, potential_2_k, param), 9)
+        for which in ("Ax", "Ay", "Az"):
+            add(f"c) {which}", compute_3c_rhs(potential_1_k, potential_2_k, which, param), 11)
     position, velocity = position.view(-1, 3), velocity.view(-1, 3)
     utils.periodic_wrap(position)
     if "base" in param:  # finalise_initial_conditions: the initial snapshot

@@ -117,7 +117,8 @@ def test_restart_reproduces_the_uninterrupted_run(tmp_path, fmt):
     assert np.abs(final_a[1] - final_b[1]).max() < 1e-4 * np.abs(final_a[1]).max()
 
 
-LPT_CASES = ["1lpt_center_n16", "2lpt_center_n16", "2lpt_edge_fixed_paired_n16", "2lpt_center_n32"]
+LPT_CASES = ["1lpt_center_n16", "2lpt_center_n16", "2lpt_edge_fixed_paired_n16", "2lpt_center_n32", "3lpt_center_n16",
+             "3lpt_edge_n32"]
 
 
 @pytest.mark.parametrize("tag", LPT_CASES)
@@ -135,6 +136,7 @@ def test_lpt_initial_conditions_vs_reference(golden, tag, tmp_path):
     lna = np.log(sc["aexp"])
     const = lambda at_start, at_zero=None: (lambda x: at_start if abs(x - lna) < 1e-9 else at_zero)  # noqa: E731
     tables = [None, None, const(sc["Hz"]), const(sc["d1"], sc["d1_z0"]), const(sc["f1"]), const(sc["d2"]), const(sc["f2"])]
+    tables += [const(sc[k]) for k in ("d3a", "f3a", "d3b", "f3b", "d3c", "f3c") if k in sc]
     param = dict(case, power_spectrum_file=str(f), boxlen=100.0, z_start=1.0 / sc["aexp"] - 1, unit_t=sc["unit_t"],
                  dealiased_ICS=False)
     pos, vel = lpt.generate(param, tables)
@@ -144,14 +146,15 @@ def test_lpt_initial_conditions_vs_reference(golden, tag, tmp_path):
     assert np.abs(vel - g["velocity"]).max() < 2e-5 * np.abs(g["velocity"]).max()
 
 
-def test_lpt_against_the_oracle_at_128(tmp_path):
-    """2LPT at 128^3 (beyond the goldens): the device pipeline against the oracle's, fed the same Fourier density."""
+@pytest.mark.parametrize("order", ["2LPT", "3LPT"])
+def test_lpt_against_the_oracle_at_128(tmp_path, order):
+    """2LPT / 3LPT at 128^3 (beyond the goldens): the device pipeline against the oracle's, fed the same Fourier density."""
     import torch
 
     from pysco_amd import cosmotable, lpt, utils
 
     n = 128
-    param = _example_param(tmp_path, initial_conditions="2LPT", npart=n**3,
+    param = _example_param(tmp_path, initial_conditions=order, npart=n**3,
                            power_spectrum_file=os.path.join(ROOT, "examples", "pk_example.dat"))
     del param["base"]  # (no snapshot from this call)
     tables = cosmotable.generate(dict(param, base=str(tmp_path), extra="t"))
@@ -161,7 +164,8 @@ def test_lpt_against_the_oracle_at_128(tmp_path):
     lna = np.log(param["aexp"])
     sc = {"Hz": float(tables[2](lna)), "d1_z0": float(tables[3](0)), "d1": float(tables[3](lna)), "f1": float(tables[4](lna)),
           "d2": float(tables[5](lna)), "f2": float(tables[6](lna)), "unit_t": param["unit_t"]}
-    p_ref, v_ref = orc.lpt_particles(lpt.generate_density_fourier(param), "2LPT", "center", sc)
+    sc.update({k: float(tables[7 + i](lna)) for i, k in enumerate(("d3a", "f3a", "d3b", "f3b", "d3c", "f3c"))})
+    p_ref, v_ref = orc.lpt_particles(lpt.generate_density_fourier(param), order, "center", sc)
     d = np.abs(pos.cpu().numpy() - p_ref)
     assert np.minimum(d, 1 - d).max() < 3e-6
     assert np.abs(vel.cpu().numpy() - v_ref).max() < 2e-5 * np.abs(v_ref).max()

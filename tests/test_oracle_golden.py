@@ -344,7 +344,8 @@ def test_oracle_pm_parametrized(golden, tag):
     np.testing.assert_allclose(acc, g["acc"], rtol=0, atol=4 * tol * np.abs(g["acc"]).max())
 
 
-LPT_CASES = ["1lpt_center_n16", "2lpt_center_n16", "2lpt_edge_fixed_paired_n16", "2lpt_center_n32"]
+LPT_CASES = ["1lpt_center_n16", "2lpt_center_n16", "2lpt_edge_fixed_paired_n16", "2lpt_center_n32", "3lpt_center_n16",
+             "3lpt_edge_n32"]
 
 
 @pytest.mark.parametrize("tag", LPT_CASES)
