@@ -309,6 +309,9 @@ int pm_lap_vcycle(pm_ctx *ctx, float *d_x, const float *d_b, int n, int npre, in
 /* on (default): pm_lap_vcycle runs every level from 16^3 down (22 launches) in one workgroup with the grids in LDS,
  * same expressions in the same order (same bits); off: level by level. */
 int pm_set_fused_coarse(pm_ctx *ctx, int on);
+/* on (default): the f(R) smoothers (pm_cubic / pm_quartic_gauss_seidel, pm_fr_vcycle) run their row kernels for
+ * n >= 16 -- eight consecutive k-cells per thread, 16-byte accesses, same expression per cell; off: a cell per thread. */
+int pm_set_fr_rows_sweep(pm_ctx *ctx, int on);
 int pm_set_vcycle_graphs(pm_ctx *ctx, int mode);
 int pm_vcycle_graph_stats(pm_ctx *ctx, unsigned *replayed, unsigned *captured);
 /* laplacian.gauss_seidel :844: one red + one black sweep with over-relaxation f_relax, in place */

@@ -1022,6 +1022,21 @@ __device__ __forceinline__ double cubic_root(float pf, float d1f) {
     const double d1 = (double)d1f, p = (double)pf;
     double d = d1 * d1 + 108.0 * (p * p * p);
     if (d > 0.0) {
+        // One real root, -(C - 3p / C) / 3 with C^3 = (d1 + sqrt(d)) / 2.  Where that is positive -- d1 >= 0, or p > 0:
+        // the scalaron's regime, q h^2 of order 10^2 -- the fp32 evaluation (for d1 < 0 in the form 54 p^3 / (sqrt(d) -
+        // d1), which does not cancel) polished by one Newton step of t^3 + p t + d1 / 27 in fp64 is the fp64 formula to
+        // 1e-12: no fp64 sqrt, cube root or second division.  Elsewhere (C^3 <= 0: the reference's NaN) the formula itself.
+        if (d1 >= 0.0 || p > 0.0) {
+            const float sf = sqrtf((float)d);
+            const float hf = d1f >= 0.0f ? 0.5f * (d1f + sf) : 54.0f * (pf * pf * pf) / (sf - d1f);
+            if (hf > 1.0e-30f && hf < 1.0e30f) {
+                const float Cf = cbrtf(hf);
+                double t = (double)(-0.33333334f * (Cf - 3.0f * pf / Cf));
+                const double q = d1 * (1.0 / 27);
+                t -= ((t * t + p) * t + q) / (3.0 * (t * t) + p);
+                return t;
+            }
+        }
         d = d1 + sqrt(d);
         if (d == 0.0) return -inv3 * pow(d1, inv3);
         // x^(1/3) of a positive x is cbrt (a third of pow's cost); a negative x keeps pow and its NaN, as the reference
@@ -1029,6 +1044,19 @@ __device__ __forceinline__ double cubic_root(float pf, float d1f) {
         const double C = hd > 0.0 ? cbrt(hd) : pow(hd, inv3);
         return -inv3 * (C - 3.0 * p / C);
     } else if (d < 0.0) {
+        // Three real roots; the reference takes -(2/3) sqrt(-3p) cos((acos(d) + 2 pi) / 3).  Away from a double root
+        // (|d| < 7/8) the same root comes from the fp32 evaluation of that formula polished by one Newton step of
+        // t^3 + p t + d1 / 27 in fp64 -- 1e-13 of the fp64 formula, i.e. the same float but for one case in 10^6 on a
+        // rounding boundary -- for a third of the instructions (fp64 acos + cos + sqrt + divide).
+        {
+            const float d0f = -3.0f * pf, sd0f = sqrtf(d0f), df = d1f / (2.0f * (d0f * sd0f));
+            if (fabsf(df) < 0.875f) {
+                double t = (double)(-0.66666667f * sd0f * cosf(0.33333333f * (acosf(df) + 6.2831853f)));
+                const double q = d1 * (1.0 / 27);
+                t -= ((t * t + p) * t + q) / (3.0 * (t * t) + p);
+                return (double)(float)t;
+            }
+        }
         const double d0 = -3.0 * p;  // > 0 here (d < 0 needs p < 0)
         const double sd0 = sqrt(d0);
         d = d1 / (2.0 * (d0 * sd0));  // d0^1.5 without pow
@@ -1242,6 +1270,75 @@ __global__ __launch_bounds__(BLK) void cubic_gauss_seidel_kernel(float *__restri
 }
 
 // colours: 3 = red then black (the whole sweep), 1 = red only, 0 = black only (slabs: ghosts refreshed between)
+// Row form of the same half-sweep for n >= 16, as lap_gauss_seidel_rows_kernel: a thread owns 8 consecutive k-cells of
+// one (i, j) row and updates the four of the launch's colour; the row, its four neighbour rows, the density term (and
+// the right-hand side) are 16-byte accesses, where the cell-per-thread kernel above touches every other float of
+// every line it loads (measured at 512^3: 1.19 ms of its 1.53 ms sweep are those accesses, 0.34 the fp64 root).
+// Same expression per cell: cubic_p's sum in its order, the same root, the same relaxation.
+template <int COLOUR, bool WITH_RHS, int FRN>
+__global__ __launch_bounds__(BLK) void cubic_gauss_seidel_rows_kernel(float *__restrict__ x, const float *__restrict__ b,
+                                                                      float d1_q, const float *__restrict__ rhs, int log2n,
+                                                                      float h2, float invsix, float f_relax, XRange xr,
+                                                                      int gpar) {
+    const int n = 1 << log2n, m = n - 1, lseg = log2n - 3;
+    const int64_t total = ((int64_t)xr.ni << log2n) << lseg;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k0 = (int)(t & ((1 << lseg) - 1)) << 3;
+        const int64_t row0 = t >> lseg;
+        const int j = (int)(row0 & m), il = xr.i0 + (int)(row0 >> log2n), i = il + gpar;  // i: parity of the global plane
+        const int64_t row = ((int64_t)il << log2n) + j;
+        auto rowp = [&](int ii, int jj) -> const float * {
+            return x + ((((int64_t)(ii & xr.xmask) << log2n) + (jj & m)) << log2n);
+        };
+        float *mine = x + (row << log2n);
+        float v[10], xm[8], xp[8], ym[8], yp[8], bb[8], rr[8];
+        auto ld8 = [&](const float *p, float *d) {
+            const float4 q0 = *reinterpret_cast<const float4 *>(p + k0), q1 = *reinterpret_cast<const float4 *>(p + k0 + 4);
+            d[0] = q0.x, d[1] = q0.y, d[2] = q0.z, d[3] = q0.w, d[4] = q1.x, d[5] = q1.y, d[6] = q1.z, d[7] = q1.w;
+        };
+        ld8(mine, v + 1);
+        v[0] = mine[(k0 - 1) & m], v[9] = mine[(k0 + 8) & m];
+        ld8(rowp(il - 1, j), xm), ld8(rowp(il + 1, j), xp), ld8(rowp(il, j - 1), ym), ld8(rowp(il, j + 1), yp);
+        ld8(b + (row << log2n), bb);
+        if (WITH_RHS) ld8(rhs + (row << log2n), rr);
+        const int o = (COLOUR + i + j) & 1;  // k parity of this row's cells of the launch's colour
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int l = 2 * q + o;
+            // cubic_p: h2 b - (1/6) (x- , y-, z-, z+, y+, x+ powers summed in that order)
+            const float p = h2 * bb[l] - invsix * (fr_pw<FRN>(xm[l]) + fr_pw<FRN>(ym[l]) + fr_pw<FRN>(v[l]) + fr_pw<FRN>(v[l + 2]) +
+                                                   fr_pw<FRN>(yp[l]) + fr_pw<FRN>(xp[l]));
+            float sol;
+            if (FRN == 1) {
+                const float d1 = WITH_RHS ? d1_q - 27.0f * rr[l] : d1_q;
+                sol = (float)cubic_root(p, d1);
+            } else {
+                const float qq = WITH_RHS ? d1_q - rr[l] : d1_q;
+                sol = (float)quartic_root(p, qq);
+            }
+            const float xc = v[l + 1];
+            v[l + 1] = xc + f_relax * (sol - xc);
+        }
+        *reinterpret_cast<float4 *>(mine + k0) = make_float4(v[1], v[2], v[3], v[4]);
+        *reinterpret_cast<float4 *>(mine + k0 + 4) = make_float4(v[5], v[6], v[7], v[8]);
+    }
+}
+
+template <int COLOUR, bool WITH_RHS, int FRN>
+static void fr_gauss_seidel_launch(pm_ctx *c, bool rows, float *d_x, const float *d_b, float c_q, const float *d_rhs, int l2,
+                                   float h2, float invsix, float f_relax, XRange xr, int gpar) {
+    const int n = 1 << l2;
+    if (rows) {
+        const int64_t threads = (int64_t)xr.ni * n * (n / 8);
+        hipLaunchKernelGGL((cubic_gauss_seidel_rows_kernel<COLOUR, WITH_RHS, FRN>), dim3(pm_stream_blocks(threads, BLK)), dim3(BLK),
+                           0, c->stream, d_x, d_b, c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
+    } else {
+        const int64_t total = (int64_t)xr.ni * n * (n / 2);
+        hipLaunchKernelGGL((cubic_gauss_seidel_kernel<COLOUR, WITH_RHS, FRN>), dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0,
+                           c->stream, d_x, d_b, c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
+    }
+}
+
 template <int FRN>
 static int fr_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, const float *d_rhs, int n, float f_relax,
                            XRange xr, int gpar, int colours) {
@@ -1259,22 +1356,23 @@ static int fr_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, con
     else
         c_q = (float)(27.0 * (double)h2 * (double)q);  // cubic.py:305 (int * f4 -> f8, then f4)
     const bool red = colours == 3 || colours == 1, black = colours == 3 || colours == 0;
+    const bool rows = c->fr_rows_sweep && n >= 16 && pm_aligned16(d_x) && pm_aligned16(d_b) && (!d_rhs || pm_aligned16(d_rhs));
+    (void)total, (void)blocks;
     if (d_rhs) {
-        if (red)
-            hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, true, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
-                               c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
-        if (black)
-            hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, true, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
-                               c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
+        if (red) fr_gauss_seidel_launch<1, true, FRN>(c, rows, d_x, d_b, c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
+        if (black) fr_gauss_seidel_launch<0, true, FRN>(c, rows, d_x, d_b, c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
     } else {
-        if (red)
-            hipLaunchKernelGGL((cubic_gauss_seidel_kernel<1, false, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
-                               c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
-        if (black)
-            hipLaunchKernelGGL((cubic_gauss_seidel_kernel<0, false, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b,
-                               c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
+        if (red) fr_gauss_seidel_launch<1, false, FRN>(c, rows, d_x, d_b, c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
+        if (black) fr_gauss_seidel_launch<0, false, FRN>(c, rows, d_x, d_b, c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
     }
     PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// 1 (default): the f(R) smoothers use the row kernels for n >= 16; 0: one cell per thread (comparison)
+extern "C" int pm_set_fr_rows_sweep(pm_ctx *c, int on) {
+    PM_REQUIRE(c, "NULL argument");
+    c->fr_rows_sweep = on ? 1 : 0;
     return PM_OK;
 }
 

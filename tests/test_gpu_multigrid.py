@@ -460,3 +460,31 @@ def test_fused_coarse_levels_are_the_launches(amd, n):
     assert np.isfinite(ref).all() and np.abs(ref - x0.cpu().numpy()).max() > 0
     for key, val in out.items():
         np.testing.assert_array_equal(val, ref, err_msg=str(key))
+
+
+@pytest.mark.parametrize("n,fr_n,with_rhs", [(16, 1, False), (64, 1, True), (64, 2, False), (32, 2, True), (128, 1, False)])
+def test_fr_row_sweep_is_the_cell_sweep(amd, n, fr_n, with_rhs):
+    """cubic / quartic Gauss-Seidel sweeps with the row kernels (eight consecutive k-cells per thread, 16-byte
+    accesses) against the cell-per-thread kernels: bit for bit, with and without a right-hand side."""
+    torch = amd.torch
+    from pysco_amd import _lib as L
+
+    ctx = L.context(4)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n + 10 * fr_n)
+    b = torch.rand((n, n, n), generator=g, device="cuda") * 0.5 + 0.2
+    x0 = torch.rand((n, n, n), generator=g, device="cuda") * 0.2 + 0.9
+    rhs = (torch.rand((n, n, n), generator=g, device="cuda") - 0.5) * 1e-3 if with_rhs else None
+    name = "pm_cubic_gauss_seidel" if fr_n == 1 else "pm_quartic_gauss_seidel"
+    out = {}
+    try:
+        for rows in (0, 1):
+            ctx.call("pm_set_fr_rows_sweep", rows)
+            x = x0.clone()
+            for _ in range(3):
+                ctx.call(name, L.ptr(x), L.ptr(b), -0.1, L.ptr(rhs), n, 1.25)
+            out[rows] = x.cpu().numpy()
+    finally:
+        ctx.call("pm_set_fr_rows_sweep", 1)
+    assert np.isfinite(out[0]).all() and np.abs(out[0] - x0.cpu().numpy()).max() > 0
+    np.testing.assert_array_equal(out[0], out[1])
