@@ -261,7 +261,7 @@ int pm_gradient_interp_kick_rebucket_slab(pm_ctx *ctx, int order, int scheme, co
 int pm_set_predicted_dt(pm_ctx *ctx, float dt_next);
 /* ... and of the growth of the accelerations over the coming step: the filing uses scale * a_old for the
  * acceleration it does not know yet (1, the default: a_old itself).  pm_last_acc_meanabs gives the caller what to
- * extrapolate: the mean |a_x| over a sample of particles (every 64th tile) of the last fused gather, fetched by the same read-back as pm_last_maxabs (call that first; host value, no synchronisation). */
+ * extrapolate: the mean |a_x| over a sample of particles (every 64th tile of a large launch, every tile of a small one; 0 below 1024 particles) of the last fused gather, fetched by the same read-back as pm_last_maxabs (call that first; host value, no synchronisation). */
 int pm_set_predicted_acc_scale(pm_ctx *ctx, float scale);
 int pm_last_acc_meanabs(pm_ctx *ctx, double *h_meanabs);
 /* utils.max_abs of the acc / vel arrays written by the last pm_interp_kick (syncs).  *h_max_vel is 0

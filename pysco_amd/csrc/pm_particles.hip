@@ -2077,12 +2077,15 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     // gather, second kick (utils.py:297, y += a*x) and the CFL maxima in one pass: the acceleration never
     // leaves its registers (PMC: re-reading it in a separate coalesced pass cost a further 12.9 GB of fetch)
     unsigned ma = 0, mv = 0;  // bit patterns of max|a|, max|v| (integer order == float order, NaN on top)
-    // every lane also sums |a_x| over the particles it serves and every 64th workgroup adds its sums to a
+    // every lane also sums |a_x| over the particles it serves and a subset of the workgroups (below) add their sums to a
     // global one: the mean |a_x| of a sample, whose step-to-step ratio the caller extrapolates for the re-sort's
     // prediction (pm_set_predicted_acc_scale).  Summed unconditionally -- two VALU operations per particle: a
     // branch on `sample` inside the particle loop splits its body and the compiler then drains the prefetch
     // queues every iteration (the kernel took 29 ms instead of 17).
-    const bool sample = (blockIdx.x & 63u) == 0u;
+    // (every 64th workgroup of a large launch -- the atomics of more would queue up --, every 8th of a medium one, all of a
+    // small one: a 16-plane slab of a 64^3 mesh has 32 tiles, and one of them is no sample)
+    const unsigned smask = gridDim.x >= 8192u ? 63u : (gridDim.x >= 512u ? 7u : 0u);
+    const bool sample = (blockIdx.x & smask) == 0u;
     float sabs = 0.f, scnt = 0.f;
     __shared__ float s_sum[2][BLK / 64];
     // (o, w, p): where the particle's acceleration and velocity go -- the range's own base with a 32-bit
@@ -2600,11 +2603,11 @@ extern "C" int pm_last_maxabs(pm_ctx *c, float *h_max_acc, float *h_max_vel) {
     double sum;
     memcpy(&sum, &bits[PM_SAMPLE_WORD], sizeof(double));
     const unsigned cnt = bits[PM_SAMPLE_WORD + 2];
-    c->last_acc_meanabs = cnt ? sum / (double)cnt : 0.0;  // (came with the same copy: no second round trip)
+    c->last_acc_meanabs = cnt >= 1024u ? sum / (double)cnt : 0.0;  // (came with the same copy; a handful of particles is no sample)
     return PM_OK;
 }
 
-// Mean |a_x| over the sample of particles the last fused gather summed (every 64th tile), as read back by the
+// Mean |a_x| over the sample of particles the last fused gather summed (every 64th tile of a large launch, every tile of a small one; 0 below 1024 particles), as read back by the
 // last pm_last_maxabs; 0 if that gather took no sample.  Host value, no synchronisation.
 extern "C" int pm_last_acc_meanabs(pm_ctx *c, double *h_meanabs) {
     PM_REQUIRE(c && h_meanabs, "NULL argument");
