@@ -488,3 +488,28 @@ def test_fr_row_sweep_is_the_cell_sweep(amd, n, fr_n, with_rhs):
         ctx.call("pm_set_fr_rows_sweep", 1)
     assert np.isfinite(out[0]).all() and np.abs(out[0] - x0.cpu().numpy()).max() > 0
     np.testing.assert_array_equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("kind,alpha", [(0, 1.0), (1, 2.0), (2, 1.3), (3, 1.3), (4, 1.3)])
+def test_mond_rhs_rows_is_the_cell_kernel(amd, kind, alpha):
+    """pm_mond_rhs with four k-cells per thread (nine float4 rows + ten scalars for four cells) against the
+    cell-per-thread kernel: bit for bit, every interpolating-function family."""
+    torch = amd.torch
+    from pysco_amd import _lib as L
+
+    n = 64
+    ctx = L.context(4)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(kind)
+    pot = torch.randn((n, n, n), generator=g, device="cuda") * 1e-3
+    out = {}
+    try:
+        for rows in (0, 1):
+            ctx.call("pm_set_fr_rows_sweep", rows)
+            o = torch.empty_like(pot)
+            ctx.call("pm_mond_rhs", L.ptr(pot), L.ptr(o), n, 1e-2, kind, alpha)
+            out[rows] = o.cpu().numpy()
+    finally:
+        ctx.call("pm_set_fr_rows_sweep", 1)
+    assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 0
+    np.testing.assert_array_equal(out[0], out[1])
