@@ -1169,6 +1169,12 @@ struct PosQueue {
         base = range_base, last = count - 1u;
         load(0, r0), load(1, r0 + BLK), load(2, r0 + 2 * BLK), load(3, r0 + 3 * BLK);
     }
+    template <int N>
+    __device__ __forceinline__ void prime_slots(const float *range_base, unsigned r0, unsigned count) {  // the first N only
+        base = range_base, last = count - 1u;
+#pragma unroll
+        for (int u = 0; u < N; ++u) load(u, r0 + u * BLK);
+    }
     __device__ __forceinline__ void pop(unsigned r, float &px, float &py, float &pz) {  // r = particle being popped
         px = x[0], py = y[0], pz = z[0];
         x[0] = x[1], y[0] = y[1], z[0] = z[1];
@@ -1990,8 +1996,8 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     PosQueue q;
     VelQueue qv;
     if (ORDER == 0 && has_range) {
-        q.prime(pos + 3 * s, tid, (unsigned)(e - s));
-        if (KICK) qv.prime(vel + 3 * s, tid, (unsigned)(e - s));
+        q.prime_slots<2>(pos + 3 * s, tid, (unsigned)(e - s));  // (two slots in use: the range loop below)
+        if (KICK) qv.q.prime_slots<2>(vel + 3 * s, tid, (unsigned)(e - s));
     }
     if constexpr (ORDER == 0) {
         // tile fill, float-granular: consecutive lanes read consecutive floats of a tile row (18 cells x 3
@@ -2063,8 +2069,8 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         // the particle queues are primed only now: held across the fill and the differentiation their 24
         // registers pushed the kernel into scratch (20 bytes per lane written and read back by every thread)
         if (has_range) {
-            q.prime(pos + 3 * s, tid, (unsigned)(e - s));
-            if (KICK) qv.prime(vel + 3 * s, tid, (unsigned)(e - s));
+            q.prime_slots<2>(pos + 3 * s, tid, (unsigned)(e - s));
+            if (KICK) qv.q.prime_slots<2>(vel + 3 * s, tid, (unsigned)(e - s));
         }
         __syncthreads();  // every stencil has read its potential: the buffer becomes the force tile
 #pragma unroll
@@ -2188,21 +2194,22 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     if (has_range) {
         float *const o = out + 3 * s, *const w3 = KICK ? vel + 3 * s : nullptr;
         const unsigned cnt = (unsigned)(e - s);
-        // four particles per trip, one per queue slot: slot u is consumed and refilled in place, where popping the head
+        // QD particles per trip, one per queue slot: slot u is consumed and refilled in place, where popping the head
         // and shifting the queue cost 18 register moves per particle (gather 17.2 -> 16.5 ms at 1024^3).  (The
         // destination codes are NOT queued alongside: loaded inside serve() they are the youngest load in flight and the
         // wait for them drains the queue -- yet four codes prefetched per lane measured 17.0 ms.)
+        constexpr int QD = 2;  // slots in use (measured at 1024^3: 4 slots 16.3 ms, 3: 16.3, 2: 15.95, 1: 16.4)
 #pragma unroll 1
-        for (unsigned r0 = tid; r0 < cnt; r0 += 4 * BLK) {
+        for (unsigned r0 = tid; r0 < cnt; r0 += QD * BLK) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < QD; ++u) {
                 const unsigned r = r0 + u * BLK;
                 if (r < cnt) {
                     const float x = q.x[u], y = q.y[u], z = q.z[u];
                     float v[3] = {0.f, 0.f, 0.f};
                     if (KICK) v[0] = qv.q.x[u], v[1] = qv.q.y[u], v[2] = qv.q.z[u];
-                    q.load(u, r + 4 * BLK);
-                    if (KICK) qv.q.load(u, r + 4 * BLK);
+                    q.load(u, r + QD * BLK);
+                    if (KICK) qv.q.load(u, r + QD * BLK);
                     serve(o, w3, r, x, y, z, v, true, s + r, -1);
                 }
             }
