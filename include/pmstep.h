@@ -252,6 +252,11 @@ int pm_set_destination_codes(pm_ctx *ctx, unsigned char *d_codes);
 int pm_rebucket_prepare(pm_ctx *ctx, const float *d_pos, int64_t np, unsigned char *d_codes);
 /* pm_tile_lists + pm_rebucket_prepare in one pass over the positions (what the slab step calls after its migration) */
 int pm_tile_lists_codes(pm_ctx *ctx, const float *d_pos, int64_t np, unsigned char *d_codes);
+/* The caller changed the particle count of the stream the last re-bucketing gather wrote (refilled leavers' slots,
+ * appended or dropped the surplus): the tile offsets on file are clamped to the new count, so that the next
+ * pm_tile_lists[_codes] / pm_kick_drift_wrap_deposit on d_pos keeps using them (the surplus past the old count is
+ * filed under the last tile of the tile window in force at this call).  No-op for any other array. */
+int pm_sorted_stream_resized(pm_ctx *ctx, const float *d_pos, int64_t np_new);
 int pm_gradient_interp_kick_rebucket_slab(pm_ctx *ctx, int order, int scheme, const float *d_phi, int nx_phi, int x0_phi,
                                           const float *d_pos, const float *d_vel, int64_t np, float half_dt,
                                           float *d_pos_out, float *d_vel_out, float *d_acc_out, const unsigned *d_id,

@@ -82,6 +82,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_set_destination_codes": (_vp, _vp),
     "pm_rebucket_prepare": (_vp, _vp, _i64, _vp),
     "pm_tile_lists_codes": (_vp, _vp, _i64, _vp),
+    "pm_sorted_stream_resized": (_vp, _vp, _i64),
     "pm_set_predicted_dt": (_vp, _f),
     "pm_set_predicted_acc_scale": (_vp, _f),
     "pm_last_acc_meanabs": (_vp, C.POINTER(C.c_double)),

@@ -811,18 +811,20 @@ static int rebucket_bufs(pm_ctx *c, unsigned ntiles, int64_t np, RbBufs *b) {
     const size_t need = 2 * t32 + w32 + 3 * t64 + up(tmp) + dbytes;
     if (c->rb_buf_bytes < need) {
         if (c->rb_buf) PM_HIP(hipFree(c->rb_buf));
-        c->rb_buf = nullptr, c->rb_buf_bytes = 0, c->sorted_pos = nullptr, c->stay_valid = 0;
+        c->rb_buf = nullptr, c->rb_buf_bytes = 0, c->sorted_pos = nullptr, c->sorted_table = nullptr, c->stay_valid = 0;
         const size_t roomy = need + need / 16;  // (a slab's particle count creeps up and down with the migration)
         PM_HIP(hipMalloc(&c->rb_buf, roomy));
         c->rb_buf_bytes = roomy;
     }
+    // the parts whose size depends on the tiles only come first: the tile-offset tables stay where they are when the
+    // particle count changes (a slab's migration), so the table of one step can be read while the next is written
     char *p = (char *)c->rb_buf;
-    b->tile_count = (unsigned *)p, b->wg_hist = (unsigned *)(p + t32);
-    b->fill = (unsigned *)(p + t32 + w32);
-    b->cnt = (int64_t *)(p + 2 * t32 + w32);
-    b->table[0] = (int64_t *)(p + 2 * t32 + w32 + t64), b->table[1] = (int64_t *)(p + 2 * t32 + w32 + 2 * t64);
-    b->scan_tmp = p + 2 * t32 + w32 + 3 * t64, b->scan_tmp_bytes = tmp;
-    b->dcode = (unsigned char *)(p + 2 * t32 + w32 + 3 * t64 + up(tmp));
+    b->tile_count = (unsigned *)p, b->fill = (unsigned *)(p + t32);
+    b->cnt = (int64_t *)(p + 2 * t32);
+    b->table[0] = (int64_t *)(p + 2 * t32 + t64), b->table[1] = (int64_t *)(p + 2 * t32 + 2 * t64);
+    b->scan_tmp = p + 2 * t32 + 3 * t64, b->scan_tmp_bytes = tmp;
+    b->wg_hist = (unsigned *)(p + 2 * t32 + 3 * t64 + up(tmp));
+    b->dcode = (unsigned char *)(p + 2 * t32 + 3 * t64 + up(tmp) + w32);
     return PM_OK;
 }
 
@@ -850,12 +852,9 @@ static int tile_ranges(pm_ctx *c, const float *pos, int64_t np, TileWork *out, u
             *xstart = (int64_t *)(base + 3 * bytes);
     void *scan_tmp = base + 4 * bytes;
     const unsigned tb = (ntiles + 1 + BLK - 1) / BLK;
-    if (pos && c->sorted_pos == pos && c->sorted_np == np && c->sorted_ntiles == ntiles && c->rb_buf) {
+    if (pos && c->sorted_pos == pos && c->sorted_np == np && c->sorted_ntiles == ntiles && c->rb_buf && c->sorted_table) {
         // this stream was written tile by tile (pm_gradient_interp_kick_rebucket): its offsets are on file
-        RbBufs rb;
-        int rc = rebucket_bufs(c, ntiles, np, &rb);
-        if (rc) return rc;
-        start = rb.table[c->rb_cur];
+        start = c->sorted_table;
     } else {
         hipLaunchKernelGGL(tile_bounds_kernel, dim3(tb), dim3(BLK), 0, c->stream, pos, np, n, ntiles, raw);
         PM_LAUNCH_CHECK();
@@ -2567,7 +2566,7 @@ static int gradient_interp_kick_rebucket(pm_ctx *c, int order, int scheme, const
     if (rc) return rc;
     tile_lists_drop(c);  // they describe the old layout
     c->rb_cur ^= 1;
-    c->sorted_pos = d_pos_out, c->sorted_np = np, c->sorted_ntiles = ntiles;
+    c->sorted_pos = d_pos_out, c->sorted_np = np, c->sorted_ntiles = ntiles, c->sorted_table = table;
     return PM_OK;
 }
 
@@ -2593,6 +2592,38 @@ extern "C" int pm_gradient_interp_kick_rebucket_slab(pm_ctx *c, int order, int s
     geo.nx = nx_phi, geo.x0 = ((x0_phi % c->n) + c->n) % c->n;
     return gradient_interp_kick_rebucket(c, order, scheme, d_phi, geo, d_pos, d_vel, np, half_dt, d_pos_out, d_vel_out,
                                          d_acc_out, d_id, d_id_out);
+}
+
+// A slab's migration changes the particle count of a stream that was written tile by tile: leavers' slots are refilled
+// (by arrivals or from the tail) and the surplus arrivals appended.  The tile offsets on file stay a partition of the
+// stream if they are clamped to the new count and the last one set to it -- the few particles that changed slots are
+// strangers in their ranges, which the lists take care of -- where finding ranges again from the positions (a running
+// maximum of the tile keys along the stream) lets ONE arrival with a high key in an early slot file a tenth of the
+// rank's particles under its tile.
+// (the surplus at the end must belong to a tile some workgroup serves: every offset past the last tile of the rank's
+// window -- ti_max < 0: no window, the last tile of the mesh -- becomes the new count)
+__global__ __launch_bounds__(BLK) void table_resize_kernel(int64_t *__restrict__ table, unsigned ntiles, int64_t np_new,
+                                                           int ti_max, int tj_max, int tk_max) {
+    const unsigned t = blockIdx.x * BLK + threadIdx.x;
+    if (t > ntiles) return;
+    const unsigned kmax = ti_max < 0 ? ntiles - 1u : tile_key(ti_max, tj_max, tk_max);
+    table[t] = t > kmax ? np_new : min(table[t], np_new);
+}
+
+extern "C" int pm_sorted_stream_resized(pm_ctx *c, const float *d_pos, int64_t np_new) {
+    PM_REQUIRE(c && d_pos && np_new > 0, "bad argument");
+    if (c->sorted_pos != d_pos || !c->sorted_table || !c->rb_buf) return PM_OK;  // nothing on file for this stream
+    if (c->sorted_np == np_new) return PM_OK;
+    TileWork w;
+    tile_window(c, &w);  // (the window in force now: the one the caller's tile-range calls will run with)
+    const bool windowed = w.nlaunch != w.ntiles;
+    hipLaunchKernelGGL(table_resize_kernel, dim3((c->sorted_ntiles + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->sorted_table,
+                       c->sorted_ntiles, np_new, windowed ? w.ti0 + (1 << w.lnti) - 1 : -1, (c->n >> PM_LJ) - 1,
+                       (c->n >> PM_LK) - 1);
+    PM_LAUNCH_CHECK();
+    c->sorted_np = np_new;
+    tile_lists_drop(c);
+    return PM_OK;
 }
 
 // The caller's guess of the NEXT step's dt, used by pm_kick_drift_wrap_deposit[_khalo] to count and by

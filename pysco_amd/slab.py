@@ -19,12 +19,15 @@ inject their own provider built on the oracle -- nothing in this package falls b
 from __future__ import annotations
 
 import ctypes as C
+import logging
 from typing import List, Optional
 
 import numpy as np
 
 from . import _lib as L
 from . import fourier, utils
+
+_log = logging.getLogger(__name__)
 
 _REACH = {2: 1, 3: 1, 5: 2, 7: 3}
 _SCHEME = {"cic": L.CIC, "tsc": L.TSC}
@@ -181,6 +184,15 @@ class HipOps:
         self.ctx.call("pm_last_acc_meanabs", C.byref(m))
         self.last_meanabs = float(m.value) or None
         return float(a.value), float(v.value)
+
+    def sorted_stream_resized(self, pos):
+        """The migration changed the particle count of the stream the last re-bucketing gather wrote: keep its tile
+        offsets on file (pmstep.h: pm_sorted_stream_resized)."""
+        self._window(True)
+        try:
+            self.ctx.call("pm_sorted_stream_resized", L.ptr(pos), pos.shape[0])
+        finally:
+            self._window(False)
 
     def tile_lists(self, pos, codes=None):
         """Tile ranges + straggler lists for these positions (pmstep.h: pm_tile_lists); None drops them.  `codes`:
@@ -983,11 +995,17 @@ class Slab:
             advance_clock()
             self._migrate_leavers(leave)
             position, velocity = self._views()
+            if codes is not None and hasattr(ops, "sorted_stream_resized") and position.shape[0] > 0:
+                ops.sorted_stream_resized(position)
             self._rebucketed = False
             acceleration, potential, additional_field = self.pm(position, param, potential, additional_field, tables,
                                                                 kick=(velocity, half_dt))
             if self._rebucketed:  # the gather wrote the other set of arrays
                 position, velocity = self._views()
+            if _log.isEnabledFor(logging.DEBUG):
+                _log.debug("slab step: rank %d dt %.5g guess of the next %s acceleration scale %s leavers %d held %d "
+                           "re-bucketed %s", self.rank, float(dt), param.get("_dt_pred"), param.get("_acc_scale_pred"),
+                           int(leave.numel()), position.shape[0], self._rebucketed)
         else:
             # drift with the old velocity, then kick with the old acceleration (integration.py:178-183)
             leave = ops.kick_drift_wrap(position, velocity, acceleration, np.float32(0), np.float32(dt), x_lo, x_hi)

@@ -13,6 +13,11 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if os.environ.get("PMSTEP_SLAB_LOG"):
+        import logging
+
+        logging.basicConfig(level=logging.DEBUG)
+
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pysco_amd import slab
     from tests.helpers import synth_tables, zeldovich_particles

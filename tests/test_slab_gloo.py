@@ -166,7 +166,9 @@ def test_slab_ranks_keep_their_streams_tile_sorted(tmp_path, world):
     check_against_reference(ranks, reference_run(n, steps), n, world)
     for r in ranks:
         assert int(r["rebucketed"]) == steps
-        assert r["stragglers"][-1] < 0.5 * max(r["stragglers"][0], 0.02) or r["stragglers"][-1] < 0.03, r["stragglers"]
+        # (every step, not the last alone: the envelope of running-maximum tile keys that used to stand in for the
+        # table after a migration let one arrival file a tenth of a rank's particles under its tile, now and then)
+        assert max(r["stragglers"]) < 0.03, r["stragglers"]
 
 
 @pytest.mark.gpu
