@@ -111,6 +111,16 @@ int pm_kspace_gradient(pm_ctx *ctx, const void *d_xk, void *d_out3, const float 
 /* fourier.hessian (:784; a2 = b2 = -1): -k_a1 k_b1 4 pi^2 x;  fourier.sum_of_hessian (:842): -(k_a1 k_b1 + k_a2 k_b2) 4 pi^2 x;
  * fourier.diff_of_hessian (:907; second pair given as 4 + axis): -(k_a1 k_b1 - k_a2 k_b2) 4 pi^2 x */
 int pm_kspace_hessian(pm_ctx *ctx, const void *d_xk, void *d_out, const float *h_kfreq, int a1, int b1, int a2, int b2);
+/* dealiased_ICS (Orszag's 3/2 rule, initial_conditions.py:1008, 1034-1038 and the same lines of every n-LPT source
+ * term): the products of Hessians are formed on a grid of m = 3 n / 2 cells per side.  pm_dealias_resize is
+ * initial_conditions.pad (:1859-1894; up = 1: half-spectrum [n, n, n/2+1] -> [m, m, m/2+1]) and trim (:1897-1928;
+ * up = 0: the way back): zeros, then the four low / high corner blocks in x and y times kz < n/2 (the Nyquist planes
+ * of the n grid are dropped both ways); d_in != d_out.  The _padded entry points are pm_kspace_hessian (h_kfreq: m
+ * signed frequencies), pm_fft_r2c and pm_fft_c2r (1/m^3) on the m grid. */
+int pm_dealias_resize(pm_ctx *ctx, const void *d_in, void *d_out, int up);
+int pm_kspace_hessian_padded(pm_ctx *ctx, const void *d_xk, void *d_out, const float *h_kfreq, int a1, int b1, int a2, int b2);
+int pm_fft_r2c_padded(pm_ctx *ctx, const float *d_x, void *d_xk);
+int pm_fft_c2r_padded(pm_ctx *ctx, void *d_xk, float *d_x);
 /* y = f a b (accumulate 0: utils.prod_vector_vector_inplace, utils.py:500) or y += f a b (1: add_vector_vector_inplace, :330) */
 int pm_addcmul(pm_ctx *ctx, float *d_y, float f, const float *d_a, const float *d_b, int64_t count, int accumulate);
 /* y += f a b c (utils.add_vector_vector_vector_inplace, utils.py:368) */

@@ -48,6 +48,13 @@ CASES = {
     "2lpt_center_n32": dict(npart=32**3, initial_conditions="2LPT", position_ICS="center", fixed_ICS=False, paired_ICS=False, seed=11),
     "3lpt_center_n16": dict(npart=16**3, initial_conditions="3LPT", position_ICS="center", fixed_ICS=False, paired_ICS=False, seed=5),
     "3lpt_edge_n32": dict(npart=32**3, initial_conditions="3LPT", position_ICS="edge", fixed_ICS=False, paired_ICS=False, seed=13),
+    # Orszag's 3/2 rule for the products (initial_conditions.py:1008, 1034-1038, 1859-1928: pad / trim)
+    "2lpt_dealiased_n16": dict(npart=16**3, initial_conditions="2LPT", position_ICS="center", fixed_ICS=False, paired_ICS=False, seed=17,
+                               dealiased_ICS=True),
+    "3lpt_dealiased_n16": dict(npart=16**3, initial_conditions="3LPT", position_ICS="edge", fixed_ICS=False, paired_ICS=False, seed=19,
+                               dealiased_ICS=True),
+    "2lpt_dealiased_n32": dict(npart=32**3, initial_conditions="2LPT", position_ICS="center", fixed_ICS=True, paired_ICS=False, seed=23,
+                               dealiased_ICS=True),
 }
 ONLY = [a for a in sys.argv[1:] if a in CASES]  # regenerate a subset: python oracle/gen_golden_lpt.py 3lpt_center_n16 ...
 
@@ -60,7 +67,8 @@ for tag, case in CASES.items():
         np.savetxt(pk_file, np.c_[k_tab, pk_tab])
         param = dict(theory="newton", H0=72.0, Om_m=0.25733, T_cmb=2.726, N_eff=3.044, w0=-1.0, wa=0.0, boxlen=100.0,
                      z_start=49.0, dealiased_ICS=False, power_spectrum_file=pk_file, base=tmp, extra="golden",
-                     output_snapshot_format="parquet", nthreads=1, **case)
+                     output_snapshot_format="parquet", nthreads=1)
+        param.update(case)
         tables = cosmotable.generate(dict(param))  # (the Series below gets Om_r / Om_lambda from its own call)
         p = pd.Series(param, dtype=object)
         cosmotable.generate(p)

@@ -932,7 +932,35 @@ def _hr(phi_k, ij):
     return ifft_3D_real(hessian(phi_k, ij))
 
 
-def compute_3a_rhs(phi_1_k) -> np.ndarray:  # initial_conditions.py:1042-1121 (no de-aliasing)
+def _corner_blocks(x, n_out) -> np.ndarray:
+    """initial_conditions.py:1859-1928 (pad: n -> 3n/2, trim: 3n/2 -> n): zeros, then the four low/high corner blocks
+    of the x and y axes and the low block of z, `middle` = half the SMALLER size (the Nyquist planes are dropped)."""
+    middle = min(x.shape[0], n_out) // 2
+    out = np.zeros((n_out, n_out, n_out // 2 + 1), dtype=x.dtype)
+    out[:middle, :middle, :middle] = x[:middle, :middle, :middle]
+    out[-middle + 1:, :middle, :middle] = x[-middle + 1:, :middle, :middle]
+    out[:middle, -middle + 1:, :middle] = x[:middle, -middle + 1:, :middle]
+    out[-middle + 1:, -middle + 1:, :middle] = x[-middle + 1:, -middle + 1:, :middle]
+    return out
+
+
+def pad(x) -> np.ndarray:  # initial_conditions.py:1859-1894
+    return _corner_blocks(x, 3 * x.shape[0] // 2)
+
+
+def trim(x) -> np.ndarray:  # initial_conditions.py:1897-1928
+    return _corner_blocks(x, 2 * x.shape[0] // 3)
+
+
+def _dealiased(rhs_fn, factor, *phis_k):
+    """Orszag's 3/2 rule as the reference applies it to every product of Hessians (initial_conditions.py:1008,
+    1034-1038): pad the potentials, form the products on the 3n/2 grid, transform, trim, transform back, times
+    `factor` (1.5^3; 1.5^6 for the cubic term, :1120)."""
+    out = rhs_fn(*[pad(p) for p in phis_k])
+    return (ifft_3D_real(trim(fft_3D_real(out))) * np.float32(factor)).astype(np.float32)
+
+
+def compute_3a_rhs(phi_1_k) -> np.ndarray:  # initial_conditions.py:1042-1121 (de-aliasing: _dealiased)
     one, two = np.float32(1), np.float32(2)
     out = _hr(phi_1_k, (0, 0))
     out = out * (one * _hr(phi_1_k, (1, 1)))
@@ -974,7 +1002,7 @@ def compute_3c_rhs(phi_1_k, phi_2_k, which: str) -> np.ndarray:
     return out.astype(np.float32)
 
 
-def compute_2ndorder_rhs(phi_1_k) -> np.ndarray:  # initial_conditions.py:976-1039 (no de-aliasing)
+def compute_2ndorder_rhs(phi_1_k) -> np.ndarray:  # initial_conditions.py:976-1039 (de-aliasing: _dealiased)
     phi_2 = ifft_3D_real(hessian(phi_1_k, (0, 0)))
     phi_2 = phi_2 * ifft_3D_real(sum_of_hessian(phi_1_k, (1, 1), (2, 2)))
     phi_2 = phi_2 + np.float32(1) * ifft_3D_real(hessian(phi_1_k, (1, 1))) * ifft_3D_real(hessian(phi_1_k, (2, 2)))
@@ -984,7 +1012,7 @@ def compute_2ndorder_rhs(phi_1_k) -> np.ndarray:  # initial_conditions.py:976-10
     return phi_2.astype(np.float32)
 
 
-def lpt_particles(density_k_half, order: str, position_ics: str, scalars):
+def lpt_particles(density_k_half, order: str, position_ics: str, scalars, dealiased: bool = False):
     """The grid part of initial_conditions.generate (initial_conditions.py:108-158, 1688-1856) from the Fourier-space
     density: inverse Laplacian -> displacement -> particles; `scalars`: Hz [km/s/Mpc], d1_z0, d1, f1, d2, f2, unit_t."""
     pc = 3.0856775814913674e16
@@ -1002,7 +1030,13 @@ def lpt_particles(density_k_half, order: str, position_ics: str, scalars):
     position = (lattice + dplus_1 * (-psi)).astype(np.float32)
     velocity = ((dplus_1 * fH_1) * (-psi)).astype(np.float32)
     if order.casefold() in ("2lpt", "3lpt"):
-        rho2_k = fft_3D_real(compute_2ndorder_rhs(pot1))
+        if dealiased:
+            rhs2, rhs3a = (lambda p1: _dealiased(compute_2ndorder_rhs, 1.5**3, p1)), (lambda p1: _dealiased(compute_3a_rhs, 1.5**6, p1))
+            rhs3b = lambda p1, p2: _dealiased(compute_3b_rhs, 1.5**3, p1, p2)  # noqa: E731
+            rhs3c = lambda p1, p2, which: _dealiased(lambda a, b: compute_3c_rhs(a, b, which), 1.5**3, p1, p2)  # noqa: E731
+        else:
+            rhs2, rhs3a, rhs3b, rhs3c = compute_2ndorder_rhs, compute_3a_rhs, compute_3b_rhs, compute_3c_rhs
+        rho2_k = fft_3D_real(rhs2(pot1))
         with np.errstate(all="ignore"):
             inverse_laplacian(rho2_k)
         psi2 = ifft_3D_real_grad(gradient(rho2_k))
@@ -1020,10 +1054,10 @@ def lpt_particles(density_k_half, order: str, position_ics: str, scalars):
             velocity = (velocity + (dplus * fH) * psi3).astype(np.float32)
 
         with np.errstate(all="ignore"):
-            add(compute_3a_rhs(pot1), scalars["d3a"], scalars["f3a"])
-            add(compute_3b_rhs(pot1, rho2_k), scalars["d3b"], scalars["f3b"])
+            add(rhs3a(pot1), scalars["d3a"], scalars["f3a"])
+            add(rhs3b(pot1, rho2_k), scalars["d3b"], scalars["f3b"])
             for which in ("Ax", "Ay", "Az"):
-                add(compute_3c_rhs(pot1, rho2_k, which), scalars["d3c"], scalars["f3c"])
+                add(rhs3c(pot1, rho2_k, which), scalars["d3c"], scalars["f3c"])
     position, velocity = np.ascontiguousarray(position.reshape(-1, 3)), np.ascontiguousarray(velocity.reshape(-1, 3))
     periodic_wrap(position)
     return position, velocity

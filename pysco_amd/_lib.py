@@ -54,6 +54,10 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_kspace_hessian": (_vp, _vp, _vp, _vp, _i, _i, _i, _i),
     "pm_addcmul": (_vp, _vp, _f, _vp, _vp, _i64, _i),
     "pm_addcmul3": (_vp, _vp, _f, _vp, _vp, _vp, _i64),
+    "pm_dealias_resize": (_vp, _vp, _vp, _i),
+    "pm_kspace_hessian_padded": (_vp, _vp, _vp, _vp, _i, _i, _i, _i),
+    "pm_fft_r2c_padded": (_vp, _vp, _vp),
+    "pm_fft_c2r_padded": (_vp, _vp, _vp),
     "pm_lpt_displace": (_vp, _vp, _f, _f, _i, _vp, _vp),
     "pm_pk": (_vp, _i, _vp, _vp, _vp, _vp, _vp),
     "pm_poisson_fft": (_vp, _i, _i, _vp, _vp, _vp, _vp, _f),

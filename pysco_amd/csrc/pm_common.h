@@ -133,6 +133,10 @@ struct pm_ctx {
     rocfft_execution_info info_r2c, info_c2r;
     void *fft_work;
     size_t fft_work_bytes;
+    // the same pair on the 3n/2 grid of the de-aliased initial conditions (pm_fft_r2c_padded / pm_fft_c2r_padded)
+    rocfft_plan pad_r2c, pad_c2r;
+    rocfft_execution_info pad_info_r2c, pad_info_c2r;
+    void *pad_work;
     void *d_spec;  // lazily allocated half-spectrum scratch for pm_poisson_fft
     void *fp_B, *fp_C, *fp_tw;  // fused FFT Poisson solve: two transposed half-spectra + twiddle table
     size_t fp_B_bytes, fp_C_bytes;

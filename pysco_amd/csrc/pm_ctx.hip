@@ -82,6 +82,11 @@ extern "C" int pm_ctx_destroy(pm_ctx *c) {
     if (c->info_r2c) rocfft_execution_info_destroy(c->info_r2c);
     if (c->info_c2r) rocfft_execution_info_destroy(c->info_c2r);
     if (c->fft_work) hipFree(c->fft_work);
+    if (c->pad_r2c) rocfft_plan_destroy(c->pad_r2c);
+    if (c->pad_c2r) rocfft_plan_destroy(c->pad_c2r);
+    if (c->pad_info_r2c) rocfft_execution_info_destroy(c->pad_info_r2c);
+    if (c->pad_info_c2r) rocfft_execution_info_destroy(c->pad_info_c2r);
+    if (c->pad_work) hipFree(c->pad_work);
     if (c->d_spec) hipFree(c->d_spec);
     if (c->fp_B) hipFree(c->fp_B);
     if (c->fp_C) hipFree(c->fp_C);
@@ -116,6 +121,10 @@ extern "C" int pm_ctx_set_stream(pm_ctx *c, void *stream) {
     if (c->info_r2c) {
         PM_FFT(rocfft_execution_info_set_stream(c->info_r2c, c->stream));
         PM_FFT(rocfft_execution_info_set_stream(c->info_c2r, c->stream));
+    }
+    if (c->pad_info_r2c) {
+        PM_FFT(rocfft_execution_info_set_stream(c->pad_info_r2c, c->stream));
+        PM_FFT(rocfft_execution_info_set_stream(c->pad_info_c2r, c->stream));
     }
     for (int i = 0; i < 4; ++i)
         if (c->info_s[i]) PM_FFT(rocfft_execution_info_set_stream(c->info_s[i], c->stream));
@@ -181,6 +190,57 @@ extern "C" int pm_fft_c2r(pm_ctx *c, void *d_xk, float *d_x) {
     void *in[1] = {d_xk};
     void *out[1] = {d_x};
     PM_FFT(rocfft_execute(c->plan_c2r, in, out, c->info_c2r));
+    return PM_OK;
+}
+
+// The pair of plans on the padded grid of Orszag's 3/2 rule (initial_conditions.py:1859-1928: m = 3 n / 2, not a power
+// of two -- rocFFT takes any length; the hand-written LDS FFT passes are radix-2 and stay on the mesh sizes).
+static int build_padded_plans(pm_ctx *c) {
+    if (c->pad_r2c) return PM_OK;
+    std::call_once(g_fft_once, [] { rocfft_setup(); });
+    const size_t m = (size_t)c->n * 3 / 2;
+    const size_t len[3] = {m, m, m};
+    PM_FFT(rocfft_plan_create(&c->pad_r2c, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                              rocfft_precision_single, 3, len, 1, nullptr));
+    rocfft_plan_description d = nullptr;
+    PM_FFT(rocfft_plan_description_create(&d));
+    PM_FFT(rocfft_plan_description_set_scale_factor(d, 1.0 / ((double)m * m * m)));  // ifft_3D_real's 1/m^3
+    PM_FFT(rocfft_plan_create(&c->pad_c2r, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                              rocfft_precision_single, 3, len, 1, d));
+    PM_FFT(rocfft_plan_description_destroy(d));
+    size_t w1 = 0, w2 = 0;
+    PM_FFT(rocfft_plan_get_work_buffer_size(c->pad_r2c, &w1));
+    PM_FFT(rocfft_plan_get_work_buffer_size(c->pad_c2r, &w2));
+    const size_t w = w1 > w2 ? w1 : w2;
+    if (w) PM_HIP(hipMalloc(&c->pad_work, w));
+    PM_FFT(rocfft_execution_info_create(&c->pad_info_r2c));
+    PM_FFT(rocfft_execution_info_create(&c->pad_info_c2r));
+    if (w) {
+        PM_FFT(rocfft_execution_info_set_work_buffer(c->pad_info_r2c, c->pad_work, w));
+        PM_FFT(rocfft_execution_info_set_work_buffer(c->pad_info_c2r, c->pad_work, w));
+    }
+    PM_FFT(rocfft_execution_info_set_stream(c->pad_info_r2c, c->stream));
+    PM_FFT(rocfft_execution_info_set_stream(c->pad_info_c2r, c->stream));
+    return PM_OK;
+}
+
+extern "C" int pm_fft_r2c_padded(pm_ctx *c, const float *d_x, void *d_xk) {
+    PM_REQUIRE(c && d_x && d_xk, "NULL argument");
+    int rc = build_padded_plans(c);
+    if (rc) return rc;
+    void *in[1] = {const_cast<float *>(d_x)};
+    void *out[1] = {d_xk};
+    PM_FFT(rocfft_execute(c->pad_r2c, in, out, c->pad_info_r2c));
+    return PM_OK;
+}
+
+extern "C" int pm_fft_c2r_padded(pm_ctx *c, void *d_xk, float *d_x) {
+    PM_REQUIRE(c && d_x && d_xk, "NULL argument");
+    int rc = build_padded_plans(c);
+    if (rc) return rc;
+    void *in[1] = {d_xk};
+    void *out[1] = {d_x};
+    PM_FFT(rocfft_execute(c->pad_c2r, in, out, c->pad_info_c2r));
     return PM_OK;
 }
 

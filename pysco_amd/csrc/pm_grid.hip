@@ -675,6 +675,53 @@ extern "C" int pm_kspace_hessian(pm_ctx *c, const void *d_xk, void *d_out, const
     return PM_OK;
 }
 
+// The same on the padded grid of the de-aliased initial conditions: m = 3 n / 2 (h_kfreq has m entries; the table of
+// the context holds 3 n floats)
+extern "C" int pm_kspace_hessian_padded(pm_ctx *c, const void *d_xk, void *d_out, const float *h_kfreq, int a1, int b1,
+                                        int a2, int b2) {
+    PM_REQUIRE(c && d_xk && d_out && h_kfreq, "NULL argument");
+    PM_REQUIRE(a1 >= 0 && a1 < 3 && b1 >= 0 && b1 < 3 && a2 < 7 && a2 != 3 && b2 < 7 && b2 != 3 && (a2 < 0) == (b2 < 0) &&
+                   (a2 >= 4) == (b2 >= 4),
+               "axes are 0, 1, 2 (second pair -1, -1: off; 4 + axis, 4 + axis: subtracted)");
+    const int m = c->n * 3 / 2;
+    PM_HIP(hipMemcpyAsync(c->d_tab, h_kfreq, m * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const int64_t total = (int64_t)m * m * (m / 2 + 1);
+    hipLaunchKernelGGL(kspace_hessian_kernel, dim3(pm_stream_blocks(total, BLK * 2)), dim3(BLK), 0, c->stream,
+                       reinterpret_cast<const float2 *>(d_xk), m, c->d_tab, a1, b1, a2, b2, reinterpret_cast<float2 *>(d_out));
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// initial_conditions.pad (:1859-1894, up = 1: [n, n, n/2+1] -> [m, m, m/2+1], m = 3 n / 2) and trim (:1897-1928,
+// up = 0, the way back): zeros, then the four corner blocks of the x and y axes (indices below n/2, and the n/2 - 1
+// highest ones) times the kz below n/2 -- the Nyquist planes of the small grid are dropped, both ways.
+__global__ __launch_bounds__(BLK) void spectrum_blocks_kernel(const float2 *__restrict__ in, int n_in, float2 *__restrict__ out,
+                                                              int n_out) {
+    const int mid = min(n_in, n_out) >> 1, nh_in = (n_in >> 1) + 1, nh_out = (n_out >> 1) + 1;
+    const int64_t total = (int64_t)n_out * n_out * nh_out;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t % nh_out);
+        const int64_t ij = t / nh_out;
+        const int i = (int)(ij / n_out), j = (int)(ij % n_out);
+        // low block: the same index; high block: the same distance from the end
+        const int si = i < mid ? i : (i > n_out - mid ? i - n_out + n_in : -1);
+        const int sj = j < mid ? j : (j > n_out - mid ? j - n_out + n_in : -1);
+        float2 v = make_float2(0.f, 0.f);
+        if (si >= 0 && sj >= 0 && k < mid) v = in[((int64_t)si * n_in + sj) * nh_in + k];
+        out[t] = v;
+    }
+}
+
+extern "C" int pm_dealias_resize(pm_ctx *c, const void *d_in, void *d_out, int up) {
+    PM_REQUIRE(c && d_in && d_out && d_in != d_out, "bad argument");
+    const int n = c->n, m = n * 3 / 2, n_in = up ? n : m, n_out = up ? m : n;
+    const int64_t total = (int64_t)n_out * n_out * (n_out / 2 + 1);
+    hipLaunchKernelGGL(spectrum_blocks_kernel, dim3(pm_stream_blocks(total, BLK * 2)), dim3(BLK), 0, c->stream,
+                       reinterpret_cast<const float2 *>(d_in), n_in, reinterpret_cast<float2 *>(d_out), n_out);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
 // y = (accumulate ? y : 0) + f * a * b (utils.prod_vector_vector_inplace :500, add_vector_vector_inplace :330)
 __global__ __launch_bounds__(BLK) void addcmul_kernel(float *__restrict__ y, float f, const float *__restrict__ a,
                                                       const float *__restrict__ b, int64_t count, int accumulate) {

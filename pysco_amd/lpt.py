@@ -107,78 +107,110 @@ def _displacement(potential_k):
     return fourier._ifft_grad_planar(planar)
 
 
-def _hessian_real(potential_k, ij, ij2=(-1, -1)):
-    torch = L.require_gpu()
-    n = potential_k.shape[0]
-    ctx = L.context(n)
-    tmp = torch.empty_like(potential_k)
-    ctx.call("pm_kspace_hessian", L.ptr(potential_k), L.ptr(tmp), L.hptr(fourier._kfreq(n)), ij[0], ij[1], ij2[0], ij2[1])
-    out = torch.empty((n, n, n), dtype=torch.float32, device=potential_k.device)
-    ctx.call("pm_fft_c2r", L.ptr(tmp), L.ptr(out))
-    return out
+class _ProductGrid:
+    """Where the products of Hessians are formed: the potential's own grid, or -- dealiased_ICS, Orszag's 3/2 rule
+    (initial_conditions.py:1008, 1034-1038 and the same lines of every source term) -- one of 3 n / 2 cells per side:
+    lift() pads the potential (initial_conditions.pad, :1859), hessian_real() is fourier.hessian / sum_of_hessian /
+    diff_of_hessian + ifft_3D_real there, finish() transforms the product, trims it (:1897), transforms back and
+    multiplies by the reference's factor."""
+
+    def __init__(self, n, param):
+        self.torch = L.require_gpu()
+        self.n, self.ctx = n, L.context(n)
+        self.dealiased = bool(param.get("dealiased_ICS", False))
+        self.m = 3 * n // 2 if self.dealiased else n
+        self.suffix = "_padded" if self.dealiased else ""
+        self.kfreq = fourier._kfreq(self.m)
+
+    def _spectrum(self, m, like):
+        return self.torch.empty((m, m, m // 2 + 1), dtype=self.torch.complex64, device=like.device)
+
+    def lift(self, potential_k):
+        if not self.dealiased:
+            return potential_k
+        out = self._spectrum(self.m, potential_k)
+        self.ctx.call("pm_dealias_resize", L.ptr(potential_k), L.ptr(out), 1)
+        return out
+
+    def hessian_real(self, potential_k, ij, ij2=(-1, -1)):
+        m = self.m
+        tmp = self.torch.empty_like(potential_k)
+        self.ctx.call("pm_kspace_hessian" + self.suffix, L.ptr(potential_k), L.ptr(tmp), L.hptr(self.kfreq), ij[0], ij[1],
+                      ij2[0], ij2[1])
+        out = self.torch.empty((m, m, m), dtype=self.torch.float32, device=potential_k.device)
+        self.ctx.call("pm_fft_c2r" + self.suffix, L.ptr(tmp), L.ptr(out))
+        return out
+
+    def diff_real(self, potential_k, d1, d2):  # fourier.diff_of_hessian: second pair given as 4 + axis
+        return self.hessian_real(potential_k, d1, (4 + d2[0], 4 + d2[1]))
+
+    def mul(self, y, f, x):  # utils.prod_vector_vector[_scalar]_inplace: y *= f * x
+        self.ctx.call("pm_addcmul", L.ptr(y), float(f), L.ptr(y), L.ptr(x), y.numel(), 0)
+
+    def addmul(self, y, f, a, b):  # utils.add_vector_vector_inplace: y += f * a * b
+        self.ctx.call("pm_addcmul", L.ptr(y), float(f), L.ptr(a), L.ptr(b), y.numel(), 1)
+
+    def addmul3(self, y, f, a, b, c):  # utils.add_vector_vector_vector_inplace: y += f * a * b * c
+        self.ctx.call("pm_addcmul3", L.ptr(y), float(f), L.ptr(a), L.ptr(b), L.ptr(c), y.numel())
+
+    def finish(self, product, factor=1.5**3):
+        if not self.dealiased:
+            return product
+        n = self.n
+        spec = self._spectrum(self.m, product)
+        self.ctx.call("pm_fft_r2c_padded", L.ptr(product), L.ptr(spec))
+        del product
+        small = self._spectrum(n, spec)
+        self.ctx.call("pm_dealias_resize", L.ptr(spec), L.ptr(small), 0)
+        del spec
+        out = self.torch.empty((n, n, n), dtype=self.torch.float32, device=small.device)
+        self.ctx.call("pm_fft_c2r", L.ptr(small), L.ptr(out))
+        self.ctx.call("pm_scale", L.ptr(out), float(np.float32(factor)), out.numel())
+        return out
 
 
 def compute_2ndorder_rhs(potential_1_k, param):
     """phi,xx (phi,yy + phi,zz) + phi,yy phi,zz - phi,xy^2 - phi,xz^2 - phi,yz^2 (initial_conditions.py:976-1039)."""
-    if param.get("dealiased_ICS", False):
-        raise NotImplementedError("dealiased_ICS (Orszag 3/2 padding) is not built")
-    n = potential_1_k.shape[0]
-    ctx = L.context(n)
-    cells = n**3
-    phi_2 = _hessian_real(potential_1_k, (0, 0))
-    tmp = _hessian_real(potential_1_k, (1, 1), (2, 2))
-    ctx.call("pm_addcmul", L.ptr(phi_2), 1.0, L.ptr(phi_2), L.ptr(tmp), cells, 0)
-    t1, t2 = _hessian_real(potential_1_k, (1, 1)), _hessian_real(potential_1_k, (2, 2))
-    ctx.call("pm_addcmul", L.ptr(phi_2), 1.0, L.ptr(t1), L.ptr(t2), cells, 1)
-    del t1, t2
+    g = _ProductGrid(potential_1_k.shape[0], param)
+    p1 = g.lift(potential_1_k)
+    phi_2 = g.hessian_real(p1, (0, 0))
+    g.mul(phi_2, 1.0, g.hessian_real(p1, (1, 1), (2, 2)))
+    g.addmul(phi_2, 1.0, g.hessian_real(p1, (1, 1)), g.hessian_real(p1, (2, 2)))
     for ij in ((0, 1), (0, 2), (1, 2)):
-        tmp = _hessian_real(potential_1_k, ij)
-        ctx.call("pm_addcmul", L.ptr(phi_2), -1.0, L.ptr(tmp), L.ptr(tmp), cells, 1)
-    return phi_2
-
-
-def _no_dealiasing(param):
-    if param.get("dealiased_ICS", False):
-        raise NotImplementedError("dealiased_ICS (Orszag 3/2 padding) is not built")
-
-
-def _mul(ctx, y, f, x):  # utils.prod_vector_vector[_scalar]_inplace: y *= f * x
-    ctx.call("pm_addcmul", L.ptr(y), float(f), L.ptr(y), L.ptr(x), y.numel(), 0)
-
-
-def _addmul(ctx, y, f, a, b):  # utils.add_vector_vector_inplace: y += f * a * b
-    ctx.call("pm_addcmul", L.ptr(y), float(f), L.ptr(a), L.ptr(b), y.numel(), 1)
+        tmp = g.hessian_real(p1, ij)
+        g.addmul(phi_2, -1.0, tmp, tmp)
+    return g.finish(phi_2)
 
 
 def compute_3a_rhs(potential_1_k, param):
     """phi,xx phi,yy phi,zz + 2 phi,xy phi,xz phi,yz - phi,yz^2 phi,xx - phi,xz^2 phi,yy - phi,xy^2 phi,zz
-    (initial_conditions.py:1042-1121, Scoccimarro 1998 B.2)."""
-    _no_dealiasing(param)
-    ctx = L.context(potential_1_k.shape[0])
-    out = _hessian_real(potential_1_k, (0, 0))
-    _mul(ctx, out, 1.0, _hessian_real(potential_1_k, (1, 1)))
-    _mul(ctx, out, 1.0, _hessian_real(potential_1_k, (2, 2)))
-    t1, t2, t3 = (_hessian_real(potential_1_k, ij) for ij in ((0, 1), (0, 2), (1, 2)))
-    ctx.call("pm_addcmul3", L.ptr(out), 2.0, L.ptr(t1), L.ptr(t2), L.ptr(t3), out.numel())
+    (initial_conditions.py:1042-1121, Scoccimarro 1998 B.2); de-aliased, the cubic term carries 1.5^6 (:1120)."""
+    g = _ProductGrid(potential_1_k.shape[0], param)
+    p1 = g.lift(potential_1_k)
+    out = g.hessian_real(p1, (0, 0))
+    g.mul(out, 1.0, g.hessian_real(p1, (1, 1)))
+    g.mul(out, 1.0, g.hessian_real(p1, (2, 2)))
+    t1, t2, t3 = (g.hessian_real(p1, ij) for ij in ((0, 1), (0, 2), (1, 2)))
+    g.addmul3(out, 2.0, t1, t2, t3)
     del t1, t2, t3
     for off, diag in (((1, 2), (0, 0)), ((0, 2), (1, 1)), ((0, 1), (2, 2))):
-        t1, t2 = _hessian_real(potential_1_k, off), _hessian_real(potential_1_k, diag)
-        ctx.call("pm_addcmul3", L.ptr(out), -1.0, L.ptr(t1), L.ptr(t1), L.ptr(t2), out.numel())
-    return out
+        t1, t2 = g.hessian_real(p1, off), g.hessian_real(p1, diag)
+        g.addmul3(out, -1.0, t1, t1, t2)
+    return g.finish(out, 1.5**6)
 
 
 def compute_3b_rhs(potential_1_k, potential_2_k, param):
     """Half the mixed products of the diagonal Hessians of phi_1 and phi_2 minus the off-diagonal ones
     (initial_conditions.py:1162-1246)."""
-    _no_dealiasing(param)
-    ctx = L.context(potential_1_k.shape[0])
-    out = _hessian_real(potential_1_k, (0, 0))
-    _mul(ctx, out, 0.5, _hessian_real(potential_2_k, (1, 1), (2, 2)))
-    _addmul(ctx, out, 0.5, _hessian_real(potential_1_k, (1, 1)), _hessian_real(potential_2_k, (0, 0), (2, 2)))
-    _addmul(ctx, out, 0.5, _hessian_real(potential_1_k, (2, 2)), _hessian_real(potential_2_k, (0, 0), (1, 1)))
+    g = _ProductGrid(potential_1_k.shape[0], param)
+    p1, p2 = g.lift(potential_1_k), g.lift(potential_2_k)
+    out = g.hessian_real(p1, (0, 0))
+    g.mul(out, 0.5, g.hessian_real(p2, (1, 1), (2, 2)))
+    g.addmul(out, 0.5, g.hessian_real(p1, (1, 1)), g.hessian_real(p2, (0, 0), (2, 2)))
+    g.addmul(out, 0.5, g.hessian_real(p1, (2, 2)), g.hessian_real(p2, (0, 0), (1, 1)))
     for ij in ((0, 1), (0, 2), (1, 2)):
-        _addmul(ctx, out, -1.0, _hessian_real(potential_1_k, ij), _hessian_real(potential_2_k, ij))
-    return out
+        g.addmul(out, -1.0, g.hessian_real(p1, ij), g.hessian_real(p2, ij))
+    return g.finish(out)
 
 
 # the transverse part, component by component (initial_conditions.py:1290-1361, 1405-1476, 1520-1591): Hessian
@@ -190,16 +222,15 @@ _3C = {"Ax": (((0, 2), (0, 1)), ((0, 2), (0, 1)), (1, 2), ((1, 1), (2, 2))),
 
 
 def compute_3c_rhs(potential_1_k, potential_2_k, which: str, param):
-    _no_dealiasing(param)
-    ctx = L.context(potential_1_k.shape[0])
+    g = _ProductGrid(potential_1_k.shape[0], param)
+    p1, p2 = g.lift(potential_1_k), g.lift(potential_2_k)
     (a1, a2), (b2, b1), off, (d1, d2) = _3C[which]
-    diff = lambda pot: _hessian_real(pot, d1, (4 + d2[0], 4 + d2[1]))  # noqa: E731  (fourier.diff_of_hessian)
-    out = _hessian_real(potential_1_k, a1)
-    _mul(ctx, out, 1.0, _hessian_real(potential_2_k, a2))
-    _addmul(ctx, out, -1.0, _hessian_real(potential_2_k, b2), _hessian_real(potential_1_k, b1))
-    _addmul(ctx, out, 1.0, _hessian_real(potential_1_k, off), diff(potential_2_k))
-    _addmul(ctx, out, -1.0, _hessian_real(potential_2_k, off), diff(potential_1_k))
-    return out
+    out = g.hessian_real(p1, a1)
+    g.mul(out, 1.0, g.hessian_real(p2, a2))
+    g.addmul(out, -1.0, g.hessian_real(p2, b2), g.hessian_real(p1, b1))
+    g.addmul(out, 1.0, g.hessian_real(p1, off), g.diff_real(p2, d1, d2))
+    g.addmul(out, -1.0, g.hessian_real(p2, off), g.diff_real(p1, d1, d2))
+    return g.finish(out)
 
 
 def _displacement_from_density(density):

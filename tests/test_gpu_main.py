@@ -118,7 +118,7 @@ def test_restart_reproduces_the_uninterrupted_run(tmp_path, fmt):
 
 
 LPT_CASES = ["1lpt_center_n16", "2lpt_center_n16", "2lpt_edge_fixed_paired_n16", "2lpt_center_n32", "3lpt_center_n16",
-             "3lpt_edge_n32"]
+             "3lpt_edge_n32", "2lpt_dealiased_n16", "3lpt_dealiased_n16", "2lpt_dealiased_n32"]
 
 
 @pytest.mark.parametrize("tag", LPT_CASES)
@@ -138,7 +138,7 @@ def test_lpt_initial_conditions_vs_reference(golden, tag, tmp_path):
     tables = [None, None, const(sc["Hz"]), const(sc["d1"], sc["d1_z0"]), const(sc["f1"]), const(sc["d2"]), const(sc["f2"])]
     tables += [const(sc[k]) for k in ("d3a", "f3a", "d3b", "f3b", "d3c", "f3c") if k in sc]
     param = dict(case, power_spectrum_file=str(f), boxlen=100.0, z_start=1.0 / sc["aexp"] - 1, unit_t=sc["unit_t"],
-                 dealiased_ICS=False)
+                 dealiased_ICS=case.get("dealiased_ICS", False))
     pos, vel = lpt.generate(param, tables)
     pos, vel = pos.cpu().numpy(), vel.cpu().numpy()
     d = np.abs(pos - g["position"])
@@ -146,15 +146,36 @@ def test_lpt_initial_conditions_vs_reference(golden, tag, tmp_path):
     assert np.abs(vel - g["velocity"]).max() < 2e-5 * np.abs(g["velocity"]).max()
 
 
-@pytest.mark.parametrize("order", ["2LPT", "3LPT"])
-def test_lpt_against_the_oracle_at_128(tmp_path, order):
-    """2LPT / 3LPT at 128^3 (beyond the goldens): the device pipeline against the oracle's, fed the same Fourier density."""
+@pytest.mark.parametrize("up", [1, 0])
+@pytest.mark.parametrize("n", [16, 64])
+def test_dealias_pad_and_trim_bit_exact(n, up):
+    """pm_dealias_resize against initial_conditions.pad / trim as the oracle restates them (pinned through the
+    de-aliased LPT goldens): a copy of corner blocks into zeros, so bit for bit -- Nyquist planes dropped both ways."""
+    import torch
+
+    from pysco_amd import _lib as L
+
+    m = 3 * n // 2
+    n_in = n if up else m
+    rng = np.random.default_rng(n + up)
+    x = (rng.standard_normal((n_in, n_in, n_in // 2 + 1)) + 1j * rng.standard_normal((n_in, n_in, n_in // 2 + 1))).astype(np.complex64)
+    want = orc.pad(x) if up else orc.trim(x)
+    out = torch.full(want.shape, float("nan"), dtype=torch.complex64, device="cuda")
+    L.context(n).call("pm_dealias_resize", L.ptr(torch.from_numpy(x).cuda()), L.ptr(out), up)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    assert not want[n // 2].any() and not want[:, n // 2].any() and not want[:, :, n // 2].any()
+
+
+@pytest.mark.parametrize("order,dealiased", [("2LPT", False), ("3LPT", False), ("3LPT", True)])
+def test_lpt_against_the_oracle_at_128(tmp_path, order, dealiased):
+    """2LPT / 3LPT at 128^3 (beyond the goldens; de-aliased: products on a 192^3 grid, rocFFT lengths 2^6 x 3): the
+    device pipeline against the oracle's, fed the same Fourier density."""
     import torch
 
     from pysco_amd import cosmotable, lpt, utils
 
     n = 128
-    param = _example_param(tmp_path, initial_conditions=order, npart=n**3,
+    param = _example_param(tmp_path, initial_conditions=order, npart=n**3, dealiased_ICS=dealiased,
                            power_spectrum_file=os.path.join(ROOT, "examples", "pk_example.dat"))
     del param["base"]  # (no snapshot from this call)
     tables = cosmotable.generate(dict(param, base=str(tmp_path), extra="t"))
@@ -165,7 +186,7 @@ def test_lpt_against_the_oracle_at_128(tmp_path, order):
     sc = {"Hz": float(tables[2](lna)), "d1_z0": float(tables[3](0)), "d1": float(tables[3](lna)), "f1": float(tables[4](lna)),
           "d2": float(tables[5](lna)), "f2": float(tables[6](lna)), "unit_t": param["unit_t"]}
     sc.update({k: float(tables[7 + i](lna)) for i, k in enumerate(("d3a", "f3a", "d3b", "f3b", "d3c", "f3c"))})
-    p_ref, v_ref = orc.lpt_particles(lpt.generate_density_fourier(param), order, "center", sc)
+    p_ref, v_ref = orc.lpt_particles(lpt.generate_density_fourier(param), order, "center", sc, dealiased=dealiased)
     d = np.abs(pos.cpu().numpy() - p_ref)
     assert np.minimum(d, 1 - d).max() < 3e-6
     assert np.abs(vel.cpu().numpy() - v_ref).max() < 2e-5 * np.abs(v_ref).max()

@@ -345,7 +345,7 @@ def test_oracle_pm_parametrized(golden, tag):
 
 
 LPT_CASES = ["1lpt_center_n16", "2lpt_center_n16", "2lpt_edge_fixed_paired_n16", "2lpt_center_n32", "3lpt_center_n16",
-             "3lpt_edge_n32"]
+             "3lpt_edge_n32", "2lpt_dealiased_n16", "3lpt_dealiased_n16", "2lpt_dealiased_n32"]
 
 
 @pytest.mark.parametrize("tag", LPT_CASES)
@@ -356,7 +356,8 @@ def test_oracle_lpt_vs_reference(golden, tag):
 
     g = golden("lpt_" + tag)
     case, sc = ast.literal_eval(str(g["param_json"])), ast.literal_eval(str(g["scalars_json"]))
-    pos, vel = orc.lpt_particles(g["density_k_half"], case["initial_conditions"], case["position_ICS"], sc)
+    pos, vel = orc.lpt_particles(g["density_k_half"], case["initial_conditions"], case["position_ICS"], sc,
+                                 dealiased=case.get("dealiased_ICS", False))
     d = np.abs(pos - g["position"])
     assert np.minimum(d, 1 - d).max() < 2e-6
     assert np.abs(vel - g["velocity"]).max() < 1e-5 * np.abs(g["velocity"]).max()
