@@ -663,11 +663,12 @@ def test_fused_fft_poisson_large_lines(amd, n):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("n,nseg", [(64, 2), (64, 4), (512, 2)])
+@pytest.mark.parametrize("n,nseg", [(64, 2), (64, 4), (512, 2), (64, 8), (128, 8), (1024, 8)])
 def test_fftp_stages_on_slabs_match_fused(amd, n, nseg):
     """The slab form of the LDS-FFT passes (forward on x-slabs -> segmented x pass -> inverse on x-slabs),
     with the all-to-all emulated by index shuffles on one GPU, reproduces pm_poisson_fft_fused bit for bit
-    (512: the x pass's register hand-over on segmented lines)."""
+    (512: the x pass's register hand-over on segmented lines; 8 segments -- 1024 / 8 is the shape of
+    `bench.py --gpus 8` -- cannot be rehearsed with processes on one GPU: the box allows six)."""
     import pysco_amd._lib as L
     from pysco_amd import fourier
 
@@ -699,9 +700,13 @@ def test_fftp_stages_on_slabs_match_fused(amd, n, nseg):
         ctx.call("pm_fftp_inverse", L.ptr(back), nx, L.ptr(out))
         phi[r * nx:(r + 1) * nx] = out
     assert torch.equal(phi, ref)
+    if n >= 512:
+        del cs, outs, phi, ref, rhs
+        L._ctxs.pop((torch.cuda.current_device(), n), None)
+        torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("nseg", [2, 4])
+@pytest.mark.parametrize("nseg", [2, 4, 8])
 def test_fftp_kz_chunked_stages_match_fused(amd, nseg):
     """The stage-wise entry points a slab driver pipelines against its all-to-alls (z forward; y forward, x pass
     and y inverse per kz chunk; z inverse), with uneven kz chunks and the all-to-all emulated on one GPU:
@@ -799,16 +804,17 @@ def test_run_nbody_loop_vs_oracle(amd):
     assert np.minimum(d, 1 - d).max() < 2e-5
 
 
-def test_tile_window_restricts_workgroups_not_results(amd):
+@pytest.mark.parametrize("x_lo,nx", [(16, 32), (0, 16), (8, 8), (56, 8)])
+def test_tile_window_restricts_workgroups_not_results(amd, x_lo, nx):
     """pm_set_tile_window (slabs: only the tiles of the rank's planes get a workgroup): particles confined to the
-    window give the same density and accelerations with and without it; straggler lists included."""
+    window give the same density and accelerations with and without it; straggler lists included.  (8 planes: one
+    row of tiles, a rank of an 8-way split at 64^3 -- the second and the last.)"""
     from pysco_amd import _lib as L
 
     n = 64
     t = amd.torch
     rng = np.random.default_rng(31)
     pos, _ = zeldovich_particles(n, seed=6, rms_cells=0.7)
-    x_lo, nx = 16, 32
     inside = (np.floor(pos[:, 0] * n).astype(np.int64) >= x_lo) & (np.floor(pos[:, 0] * n).astype(np.int64) < x_lo + nx)
     pos = amd.utils.reorder_particles(np.ascontiguousarray(pos[inside]))
     pos[:, 1:] = np.mod(pos[:, 1:] + (0.4 / n) * rng.normal(size=(len(pos), 2)), 1.0).astype(np.float32)  # stragglers in y, z

@@ -124,6 +124,15 @@ def test_four_rank_slab_step(tmp_path):
     check_against_reference(ranks, reference_run(n, steps), n, world)
 
 
+def test_eight_rank_slab_step(tmp_path):
+    """The shape of `bench.py --gpus 8` in the host logic: eight ranks (gloo), 8 planes each at 64^3 (the fewest a slab
+    may own: one row of tiles) -- ring neighbours, eight-way all-to-all splits in the migration and in the FFT
+    transposes, three ghost planes out of eight owned."""
+    n, steps, world = 64, 1, 8
+    ranks = run_ranks(world, tmp_path, "oracle", n, steps)
+    check_against_reference(ranks, reference_run(n, steps), n, world)
+
+
 @pytest.mark.parametrize("theory", ["newton_mg", "mond", "mond_fft7pt", "fr"])
 def test_two_rank_grid_solvers_cpu(tmp_path, theory):
     """The halo-exchange multigrid / FAS / QUMOND orchestration of slab_multigrid.py on the CPU: 2 gloo ranks
