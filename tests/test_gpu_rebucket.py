@@ -273,6 +273,84 @@ def test_rebucket_from_codes_alone(fused_scan):
         assert torch.equal(vel_out.cpu(), ref_vel.cpu()[perm])
 
 
+@pytest.mark.parametrize("change", [+500, -300, 0])
+def test_sorted_stream_resized_after_a_migration(change):
+    """What a slab rank does between two gathers, on one GPU: the re-bucketing gather leaves a tile-sorted stream and
+    its offsets on file; a "migration" then overwrites some particles in place (arrivals in the leavers' holes) and
+    appends a surplus / drops the tail.  pm_sorted_stream_resized keeps the offsets (clamped; the surplus filed under
+    the LAST TILE OF THE WINDOW, which is not the last tile of the mesh here): the next scan finds the strangers one by
+    one -- not a large part of the stream, as the bisected envelope of the keys did whenever a probe landed on an
+    arrival (change != 0 here; the same count keeps the offsets anyway) -- and the next gather serves every particle,
+    appended ones included."""
+    import ctypes as C
+
+    import torch
+
+    from pysco_amd import _lib as L
+    from pysco_amd import mesh, utils
+
+    n, npart, holes = 64, 120_000, 64
+    x_lo, nx = 16, 16  # two rows of tiles out of eight
+    L._ctxs.clear()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(17 + change)
+
+    def in_window(count):
+        p = torch.rand((count, 3), generator=g, device="cuda")
+        p[:, 0] = (x_lo + p[:, 0] * nx) / n
+        return p.clamp_(0, 1 - 2.0**-24)
+
+    pos, _ = utils.reorder_particles(in_window(npart), torch.zeros((npart, 3), device="cuda"))
+    vel = torch.rand((npart, 3), generator=g, device="cuda") - 0.5
+    phi = torch.rand((n, n, n), generator=g, device="cuda")
+    ctx = L.context(n)
+    cap = npart + 1000
+    half_dt = float(np.float32(0.01))
+
+    def gather(p, v, count, codes):
+        po, vo, ao = (torch.empty((cap, 3), device="cuda") for _ in range(3))
+        ids = torch.arange(count, dtype=torch.int32, device="cuda")
+        ids_out = torch.empty_like(ids)
+        ctx.call("pm_tile_lists_codes", L.ptr(p), count, L.ptr(codes))
+        s, c, ok = L._i64(0), L._i64(0), L._i(0)
+        ctx.call("pm_tile_lists_info", C.byref(s), C.byref(c), C.byref(ok))
+        assert ok.value == 1 and c.value == count
+        ctx.call("pm_gradient_interp_kick_rebucket_slab", 5, L.TSC, L.ptr(phi), n, 0, L.ptr(p), L.ptr(v), count, half_dt,
+                 L.ptr(po), L.ptr(vo), L.ptr(ao), L.ptr(ids), L.ptr(ids_out))
+        return po, vo, ao, ids_out.long(), int(s.value)
+
+    ctx.call("pm_set_tile_window", x_lo, nx)
+    try:
+        codes = torch.full((cap,), 13, dtype=torch.uint8, device="cuda")
+        p1, v1, _, _, s0 = gather(pos, vel, npart, codes)
+        assert s0 == 0
+        # the migration: arrivals in holes (one of them, in the last tile of the window, exactly where the bisection
+        # over the keys of the new count probes first: without the offsets on file every search for a tile of the
+        # upper half turns left there), then the surplus appended / the tail dropped
+        n_new = npart + change
+        where = torch.randperm(npart - 400, generator=g, device="cuda")[:holes] + 50
+        where[where == n_new >> 1] += 1
+        where[0] = n_new >> 1
+        arrivals = in_window(holes)
+        arrivals[0] = torch.tensor([(x_lo + nx - 0.5) / n, 1 - 0.5 / n, 1 - 0.5 / n], device="cuda")
+        p1[where] = arrivals
+        if change > 0:
+            p1[npart:n_new] = in_window(change)
+            v1[npart:n_new] = 0.25
+        want_v = v1[:n_new].clone()
+        want_a = mesh.derivative_interp_vec_kick("tsc", phi, 5, p1[:n_new].clone(), want_v, half_dt)
+        ctx.call("pm_sorted_stream_resized", L.ptr(p1), n_new)
+        p2, v2, a2, perm, s1 = gather(p1, v1, n_new, codes)
+        assert s1 <= holes + max(change, 0), s1          # strangers one by one
+        assert s1 >= holes // 2                          # ... and they are found
+        assert torch.equal(torch.sort(perm).values, torch.arange(n_new, device="cuda"))
+        assert torch.equal(p2[:n_new], p1[:n_new][perm])
+        assert torch.equal(a2[:n_new], want_a[perm]) and torch.equal(v2[:n_new], want_v[perm])
+    finally:
+        ctx.call("pm_set_tile_window", 0, n)
+        ctx.call("pm_tile_lists", None, 0)
+
+
 def test_bench_size_rebucket_matches_inplace():
     """BASELINE config 3 size (1024^3 / 1024^3), where the oracle cannot go: three leapfrog steps with the incremental
     re-sort (prediction on: the product's loop) against the same steps in place, compared particle by particle through

@@ -175,8 +175,8 @@ def test_slab_ranks_keep_their_streams_tile_sorted(tmp_path, world):
     check_against_reference(ranks, reference_run(n, steps), n, world)
     for r in ranks:
         assert int(r["rebucketed"]) == steps
-        # (every step, not the last alone: the envelope of running-maximum tile keys that used to stand in for the
-        # table after a migration let one arrival file a tenth of a rank's particles under its tile, now and then)
+        # (every step, not the last alone: the bisection over the keys that used to stand in for the table after a
+        # migration filed a tenth of a rank's particles under the wrong tiles whenever a probe landed on an arrival)
         assert max(r["stragglers"]) < 0.03, r["stragglers"]
 
 
