@@ -155,6 +155,7 @@ int pm_fftp_forward(pm_ctx *ctx, const float *d_rhs, int nx, void *d_C);
  * and the x pass take a kz range [kz0, kz0 + nkz) and work on a spectrum chunk [n (ky), nkz, nx] (after the
  * all-to-all: [nseg][nky][nkz][nx]); the z passes go through the context's internal B buffer (all kz). */
 int pm_fftp_z_forward(pm_ctx *ctx, const float *d_rhs, int nx);
+int pm_fftp_z_forward_khalo(pm_ctx *ctx, const float *d_rhs, int nx, const float *d_khalo); /* see pm_kick_drift_wrap_deposit_slab_khalo */
 int pm_fftp_y_forward(pm_ctx *ctx, int nx, int kz0, int nkz, void *d_C);
 int pm_fftp_xgreen_kz(pm_ctx *ctx, int kind, int p, void *d_C, int nx, int nky, int ky0, int kz0, int nkz,
                       const float *h_k2, const float *h_s, float c0);
@@ -221,6 +222,18 @@ int64_t pm_khalo_floats(int n);
 int pm_kick_drift_wrap_deposit_slab(pm_ctx *ctx, int scheme, float *d_pos, float *d_vel, const float *d_acc,
                                     float half_dt, float dt, int64_t np, float *d_rho, float x_lo, float x_hi,
                                     int64_t *d_leave_idx, int cap, int *h_count);
+/* ... with the halo buffer of pm_kick_drift_wrap_deposit_khalo.  d_rho = the tile window's planes + the same number
+ * (>= 1) of ghost planes either side; d_khalo = pm_khalo_floats_slab(n, nx_window) floats, the window's rows of tiles
+ * only.  The owners store the window's planes (not cleared first); the ghost planes are cleared here and receive, with
+ * atomics, what leaves the window through its x faces: the outward halo cells of its first and last row of tiles and
+ * the clouds of particles in tiles outside it (leavers).  After the caller has folded the ghost planes into the
+ * neighbours' edge planes, pm_fftp_z_forward_khalo adds the buffer to the density lines it loads (no atomics: every
+ * line of planes 1 .. nx - 2 takes its neighbours' entries as on one GPU, the first and last plane only those of
+ * their own column of tiles). */
+int pm_kick_drift_wrap_deposit_slab_khalo(pm_ctx *ctx, int scheme, float *d_pos, float *d_vel, const float *d_acc,
+                                          float half_dt, float dt, int64_t np, float *d_rho, float x_lo, float x_hi,
+                                          int64_t *d_leave_idx, int cap, int *h_count, float *d_khalo);
+int64_t pm_khalo_floats_slab(int n, int nx_window);
 /* mesh.derivative (mesh.py:2072, orders 2/3/5/7) + pm_interp_kick in one kernel: every workgroup stages the
  * potential of its tile in LDS, differentiates it there with the reference's stencil and gathers from the
  * result, so the [n,n,n,3] force grid is never written or read.  Same bits as pm_gradient followed by

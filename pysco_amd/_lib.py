@@ -79,6 +79,9 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_kick_drift_wrap_deposit_khalo": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _vp),
     "pm_khalo_apply": (_vp, _vp, _vp),
     "pm_khalo_floats": (_i,),
+    "pm_khalo_floats_slab": (_i, _i),
+    "pm_kick_drift_wrap_deposit_slab_khalo": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _f, _f, _vp, _i, C.POINTER(_i), _vp),
+    "pm_fftp_z_forward_khalo": (_vp, _vp, _i, _vp),
     "pm_kick_drift_wrap_deposit_slab": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _f, _f, _vp, _i, C.POINTER(_i)),
     "pm_gradient_interp_kick": (_vp, _i, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _f),
     "pm_gradient_interp_kick_rebucket": (_vp, _i, _i, _vp, _vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp),
@@ -139,7 +142,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_fft1d_x": (_vp, _vp, _i64, _i),
     "pm_greens_slab": (_vp, _i, _i, _vp, _vp, _vp, _f, _i, _i),
 }
-_RESTYPES = {"pm_last_error": C.c_char_p, "pm_khalo_floats": C.c_int64}
+_RESTYPES = {"pm_last_error": C.c_char_p, "pm_khalo_floats": C.c_int64, "pm_khalo_floats_slab": C.c_int64}
 
 _lib = None
 

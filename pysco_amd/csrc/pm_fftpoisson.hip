@@ -351,9 +351,12 @@ __device__ __forceinline__ void lds_store_lines(const float2 *buf, float2 *__res
 
 // ---- P1: z r2c, two real lines per complex FFT, transposed write ---------------------------------
 // workgroup = 16 real lines (x fixed, y0..y0+15) = 8 complex lines
+// (khalo on a slab: `nti` rows of tiles -- the planes of this launch -- and `slab_edges` set: the first and the last
+// plane take nothing from a neighbouring column in x; what the neighbouring RANK's tiles add there came in through
+// the ghost planes of the density)
 __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho, float2 *__restrict__ B,
                                                    const float2 *__restrict__ g_tw, int n, int log2n, int nx,
-                                                   const float *__restrict__ khalo) {
+                                                   const float *__restrict__ khalo, int nti, int slab_edges) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *buf = lds, *tw = lds + 8 * NP(n);
     const int nh = (n >> 1) + 1;
@@ -395,12 +398,12 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
     //  * K as before.
     auto front = [&](auto with_iface) {
         constexpr bool IFACE = decltype(with_iface)::value;
-        const int Ti = n >> 3, nq = n >> 2;
+        const int Ti = nti, nq = n >> 2;
         const int x = (int)(line0 >> log2n), y0 = (int)(line0 & (n - 1));
         const int ti = x >> 3, tj = y0 >> 4, xi = x & 7;
         const int di = xi == 0 ? -1 : 1, iside = xi == 0 ? 1 : 0;  // the neighbour's high plane (li = 9) or low one (li = 0)
         const int tin = (ti + di + Ti) % Ti, lin = xi + 1 - 8 * di;
-        const int64_t nk = ((int64_t)n * n * n >> 11) * 360;
+        const int64_t nk = (int64_t)Ti * kT * kT * 360;
         const float *hi = khalo + nk, *hj = hi + (int64_t)Ti * kT * 36 * n;
         float kraw[KH_PER_THREAD][IFACE ? 4 : 2];  // own tile column, its j-face neighbour[, the i-face one, the edge one]
 #pragma unroll
@@ -466,9 +469,10 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
             __syncthreads();
         }
     };
+    const int xplane = (int)(line0 >> log2n);
     if (!khalo)
         fill();
-    else if ((((int)(line0 >> log2n)) & 7) == 0 || (((int)(line0 >> log2n)) & 7) == 7)
+    else if (((xplane & 7) == 0 || (xplane & 7) == 7) && !(slab_edges && (xplane == 0 || xplane == nx - 1)))
         front(std::true_type{});
     else
         front(std::false_type{});
@@ -828,7 +832,7 @@ static int fftp_z_forward(pm_ctx *c, const float *d_rhs, int nx, const float *d_
     int rc = ensure_fused_buffers(c, (size_t)nh * nx * n * sizeof(float2), 0);
     if (rc) return rc;
     hipLaunchKernelGGL(fftp_z_r2c, dim3((unsigned)((int64_t)nx * n / 16)), dim3(FBLK), fftp_lds_bytes(n), c->stream,
-                       d_rhs, (float2 *)c->fp_B, (const float2 *)c->fp_tw, n, log2n, nx, d_khalo);
+                       d_rhs, (float2 *)c->fp_B, (const float2 *)c->fp_tw, n, log2n, nx, d_khalo, nx >> 3, nx < n ? 1 : 0);
     PM_LAUNCH_CHECK();
     return PM_OK;
 }
@@ -871,6 +875,13 @@ static int fftp_z_inverse(pm_ctx *c, int nx, float *d_phi) {
 }
 
 extern "C" int pm_fftp_z_forward(pm_ctx *c, const float *d_rhs, int nx) { return fftp_z_forward(c, d_rhs, nx); }
+// ... of a density whose halo contributions are still in the buffer pm_kick_drift_wrap_deposit_slab_khalo filled
+// (pm_khalo_floats_slab(n, nx) floats: the nx / 8 rows of tiles of these planes)
+extern "C" int pm_fftp_z_forward_khalo(pm_ctx *c, const float *d_rhs, int nx, const float *d_khalo) {
+    PM_REQUIRE(d_khalo, "NULL argument");
+    PM_REQUIRE(c && c->n >= 16, "the halo buffer needs n >= 16");
+    return fftp_z_forward(c, d_rhs, nx, d_khalo);
+}
 extern "C" int pm_fftp_y_forward(pm_ctx *c, int nx, int kz0, int nkz, void *d_C) {
     return fftp_y_pass(c, true, d_C, nx, kz0, nkz, 0);
 }

@@ -1262,16 +1262,24 @@ constexpr int PM_SCAP = 256;
 //   Hi [tile column (ti, tj)][low | high][lj 0..17][k 0..n)         the i-halo planes (li = 0, 9), lk = 1..16
 //   Hj [tile column (ti, tj)][low | high][li 1..8][k 0..n)          the j-halo rows (lj = 0, 17), li and lk inside
 // Hi and Hj are whole lines along k, so that the FFT's z pass adds them to the density lines it loads.
+// On a slab (multi-GPU) the buffer holds the rows of tiles of the rank's window only (ti0 .. ti0 + nti - 1, tile
+// columns numbered from ti0), and the halo cells that leave the window through its two x faces are not kept in it:
+// they belong to ghost planes of the density slab, which the neighbours receive (halo_dest below).
 constexpr int PM_KHALO_TILE = 2 * PM_HI * PM_HJ;  // floats per tile in K
 struct HaloBuf {
     float *k, *hi, *hj;
+    int ti0, nti;   // rows of tiles the buffer covers
+    int windowed;   // nti < n / 8: a slab
 };
-__host__ __device__ inline int64_t halo_k_floats(int n) { return ((int64_t)n * n * n >> (PM_LI + PM_LJ + PM_LK)) * PM_KHALO_TILE; }
-__host__ __device__ inline int64_t halo_i_floats(int n) { return (int64_t)(n >> PM_LI) * (n >> PM_LJ) * 2 * PM_HJ * n; }
-__host__ __device__ inline int64_t halo_j_floats(int n) { return (int64_t)(n >> PM_LI) * (n >> PM_LJ) * 2 * PM_TI * n; }
-static HaloBuf halo_parts(float *base, int n) {
+__host__ __device__ inline int64_t halo_k_floats(int n, int nti) { return (int64_t)nti * (n >> PM_LJ) * (n >> PM_LK) * PM_KHALO_TILE; }
+__host__ __device__ inline int64_t halo_i_floats(int n, int nti) { return (int64_t)nti * (n >> PM_LJ) * 2 * PM_HJ * n; }
+__host__ __device__ inline int64_t halo_j_floats(int n, int nti) { return (int64_t)nti * (n >> PM_LJ) * 2 * PM_TI * n; }
+__host__ __device__ inline int64_t halo_floats(int n, int nti) { return halo_k_floats(n, nti) + halo_i_floats(n, nti) + halo_j_floats(n, nti); }
+static HaloBuf halo_parts(float *base, int n, int ti0 = 0, int nti = -1) {
     HaloBuf h;
-    h.k = base, h.hi = base ? base + halo_k_floats(n) : nullptr, h.hj = base ? h.hi + halo_i_floats(n) : nullptr;
+    if (nti < 0) nti = n >> PM_LI;
+    h.k = base, h.hi = base ? base + halo_k_floats(n, nti) : nullptr, h.hj = base ? h.hi + halo_i_floats(n, nti) : nullptr;
+    h.ti0 = ti0, h.nti = nti, h.windowed = nti < (n >> PM_LI);
     return h;
 }
 
@@ -1280,12 +1288,28 @@ static HaloBuf halo_parts(float *base, int n) {
 __device__ __forceinline__ float *halo_cell(int c, const TileId &t, const HaloBuf &halo, const pm_geom &geo, float *rho) {
     const int n_ = geo.n, T_ = n_ >> PM_LJ;
     const int lij = c / PM_HK, lk = c - lij * PM_HK, li = lij / PM_HJ, lj = lij - li * PM_HJ;
-    const int64_t col = (int64_t)t.ti * T_ + t.tj;
+    const int64_t col = (int64_t)(t.ti - halo.ti0) * T_ + t.tj;
     if (lk == 0 || lk == PM_HK - 1) return halo.k + ((((col * PM_HI + li) * 2 + (lk ? 1 : 0)) * T_ + t.tk) * PM_HJ + lj);
     if (li == 0 || li == PM_HI - 1) return halo.hi + (((col * 2 + (li ? 1 : 0)) * PM_HJ + lj) * n_ + t.tk * PM_TK + lk - 1);
     if (lj == 0 || lj == PM_HJ - 1)
         return halo.hj + (((col * 2 + (lj ? 1 : 0)) * PM_TI + (li - 1)) * n_ + t.tk * PM_TK + lk - 1);
     return rho + pm_cell(geo, t.ti * PM_TI - 1 + li, t.tj * PM_TJ - 1 + lj, t.tk * PM_TK - 1 + lk);
+}
+
+// On a slab: does cell c of the haloed tile t have an address the halo buffer scheme owns -- the tile is one of the
+// window's, and the cell does not leave the window through an x face?  If not, the contribution goes to the cell
+// itself with an atomic (ghost planes of the slab are cleared beforehand; own planes hold the owners' stores of an
+// earlier launch, or -- the owners' own outward halo cells -- are ghost planes).
+__device__ __forceinline__ bool halo_owns(int c, const TileId &t, const HaloBuf &halo) {
+    if (!halo.windowed) return true;
+    const int r = t.ti - halo.ti0;
+    if (r < 0 || r >= halo.nti) return false;
+    const int li = c / (PM_HJ * PM_HK);
+    return !((li == 0 && r == 0) || (li == PM_HI - 1 && r == halo.nti - 1));
+}
+// where a contribution to cell c of tile t is ADDED (atomically) under the halo buffer scheme
+__device__ __forceinline__ float *halo_dest(int c, const TileId &t, const HaloBuf &halo, const pm_geom &geo, float *rho) {
+    return halo_owns(c, t, halo) ? halo_cell(c, t, halo, geo, rho) : rho + tile_cell_global(c, t, geo);
 }
 
 // Destination tile of the incremental re-sort.  A particle is FILED under the tile it is expected to be in after
@@ -1356,7 +1380,13 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
     const bool owner = halo.k && (blockIdx.x + work.boff) < work.nlaunch;
     TileId t0{0, 0, 0};
     if (owner) t0 = tile_of_key(tile_key_of_block(blockIdx.x + work.boff, work));
-    auto halo_store = [&](int c, float v) { *halo_cell(c, t0, halo, geo, rho) = v; };
+    // (a slab's outward halo cells: ghost planes, cleared by the launcher and added to)
+    auto halo_store = [&](int c, float v) {
+        if (halo_owns(c, t0, halo))
+            *halo_cell(c, t0, halo, geo, rho) = v;
+        else if (v != 0.f)
+            unsafeAtomicAdd(rho + tile_cell_global(c, t0, geo), v);
+    };
     if (!tile_work_item(work, key, s, e)) {
         if (owner)
             for (int c = threadIdx.x; c < PM_TILE; c += BLK) halo_store(c, 0.f);
@@ -1505,15 +1535,15 @@ __global__ __launch_bounds__(BLK) void deposit_list_kernel(const float *__restri
             deposit_global<SCHEME>(x, y, z, geo, rho);
     }
     __syncthreads();
-    if (halo.k && le - ls < 128) {
+    if (halo.k && (halo.windowed || le - ls < 128)) {
         // a short list (the usual case once the stream is re-bucketed every step: ~10 particles per tile) touches a
         // few hundred cells: fire-and-forget atomics on the tile's own addresses, no load to wait for (the
         // read-modify-write form below cost 2.6 ms at 0.5 % stragglers, the atomics 0.4 ms)
         for (int c = tid; c < PM_TILE; c += BLK) {
             const pm_acc_t w = tile[c];
-            if (w != 0) unsafeAtomicAdd(halo_cell(c, t, halo, geo, rho), weight_of_acc(w));
+            if (w != 0) unsafeAtomicAdd(halo_dest(c, t, halo, geo, rho), weight_of_acc(w));
         }
-    } else if (halo.k) {
+    } else if (halo.k) {  // (single GPU only: on a slab a leaver's tile adds to own cells of the window's edge tiles)
         // read-modify-write of the touched cells, all the loads of a thread in flight before its first store (one
         // dependent load -> store per cell made the kernel latency-bound: 5.4 ms at 4 % stragglers, 1024^3)
         constexpr int NQ = (PM_TILE + BLK - 1) / BLK;
@@ -1621,7 +1651,7 @@ __global__ __launch_bounds__(BLK) void deposit_list_flat_kernel(const float *__r
         }
         if (on) {
             if (halo.k)
-                unsafeAtomicAdd(halo_cell(c0 + (di * PM_HJ + dj) * PM_HK + dk, t, halo, geo, rho), w);
+                unsafeAtomicAdd(halo_dest(c0 + (di * PM_HJ + dj) * PM_HK + dk, t, halo, geo, rho), w);
             else
                 unsafeAtomicAdd(rho + pm_cell(geo, i + di, j + dj, k + dk), w);
         }
@@ -1654,8 +1684,22 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
         dcount.dcode = c->codes_user;  // pm_set_destination_codes: the codes only, counted later (pm_rebucket_prepare)
     }
     const size_t cells = (size_t)c->slab_nx * c->n * c->n;
-    const HaloBuf halo = halo_parts(khalo, c->n);
-    if (!khalo) PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));  // owners store every cell otherwise
+    const bool windowed = work.nlaunch != ntiles;
+    const HaloBuf halo = windowed ? halo_parts(khalo, c->n, work.ti0, 1 << work.lnti) : halo_parts(khalo, c->n);
+    const size_t halo_bytes = (size_t)halo_floats(c->n, halo.nti) * sizeof(float);
+    if (!khalo) {
+        PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));  // owners store every cell otherwise
+    } else if (windowed) {
+        // a slab: the owners store every cell of the window's planes; the ghost planes either side only receive
+        // additions (the edge tiles' outward halo cells, leavers' clouds)
+        const int ghosts = (c->slab_nx - c->tile_nx) / 2;
+        PM_REQUIRE(ghosts >= 1 && c->slab_nx == c->tile_nx + 2 * ghosts &&
+                       c->slab_x0 == ((c->tile_x_lo - ghosts) % c->n + c->n) % c->n,
+                   "halo buffer on a slab: the density slab must be the tile window + the same ghost planes either side");
+        const size_t plane = (size_t)c->n * c->n * sizeof(float);
+        PM_HIP(hipMemsetAsync(rho, 0, ghosts * plane, c->stream));
+        PM_HIP(hipMemsetAsync(rho + (size_t)(ghosts + c->tile_nx) * c->n * c->n, 0, ghosts * plane, c->stream));
+    }
     PM_HIP(hipMemsetAsync(b.counts, 0, PM_NSUB * PM_SUB_STRIDE * sizeof(unsigned), c->stream));
     if (!khalo) {
         hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME>), dim3(blocks), dim3(BLK), 0, c->stream, pos, vel, acc, -half_dt, dt,
@@ -1685,9 +1729,7 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
         // updated; deposit them again from scratch with the kernels that serve stragglers themselves.
         c->lists_pos = nullptr;
         PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));
-        if (khalo)
-            PM_HIP(hipMemsetAsync(khalo, 0, (size_t)(halo_k_floats(c->n) + halo_i_floats(c->n) + halo_j_floats(c->n)) * sizeof(float),
-                                  c->stream));
+        if (khalo) PM_HIP(hipMemsetAsync(khalo, 0, halo_bytes, c->stream));
         hipLaunchKernelGGL((deposit_tiled_kernel<SCHEME>), dim3((unsigned)((np + PM_CHUNK - 1) / PM_CHUNK)), dim3(BLK), 0,
                            c->stream, pos, np, pm_ctx_geom(c), rho);
         PM_LAUNCH_CHECK();
@@ -1742,7 +1784,7 @@ extern "C" int pm_kick_drift_wrap_deposit_khalo(pm_ctx *c, int scheme, float *d_
 // other than pm_poisson_fft_fused_khalo (one global atomic per non-zero entry, as the flush would have done)
 __global__ __launch_bounds__(BLK) void khalo_apply_kernel(HaloBuf halo, pm_geom geo, float *__restrict__ rho) {
     const int n = geo.n, T = n >> PM_LJ;
-    const int64_t nk = halo_k_floats(n), ni = halo_i_floats(n), nj = halo_j_floats(n);
+    const int64_t nk = halo_k_floats(n, n >> PM_LI), ni = halo_i_floats(n, n >> PM_LI), nj = halo_j_floats(n, n >> PM_LI);
     for (int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x; e < nk + ni + nj; e += (int64_t)gridDim.x * BLK) {
         float v;
         int gi, gj, gk;
@@ -1779,7 +1821,7 @@ __global__ __launch_bounds__(BLK) void khalo_apply_kernel(HaloBuf halo, pm_geom 
 extern "C" int pm_khalo_apply(pm_ctx *c, float *d_rho, const float *d_khalo) {
     PM_REQUIRE(c && d_rho && d_khalo, "NULL argument");
     PM_REQUIRE(c->n >= 16 && c->slab_nx == c->n, "pm_khalo_apply is the single-GPU form");
-    const int64_t total = halo_k_floats(c->n) + halo_i_floats(c->n) + halo_j_floats(c->n);
+    const int64_t total = halo_floats(c->n, c->n >> PM_LI);
     hipLaunchKernelGGL(khalo_apply_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream,
                        halo_parts(const_cast<float *>(d_khalo), c->n), pm_ctx_geom(c), d_rho);
     PM_LAUNCH_CHECK();
@@ -1787,7 +1829,7 @@ extern "C" int pm_khalo_apply(pm_ctx *c, float *d_rho, const float *d_khalo) {
 }
 
 extern "C" int64_t pm_khalo_floats(int n) {
-    return n >= 16 ? halo_k_floats(n) + halo_i_floats(n) + halo_j_floats(n) : 0;
+    return n >= 16 ? halo_floats(n, n >> PM_LI) : 0;
 }
 
 // The same on a slab (pm_set_slab: d_rho is [nx_slab, n, n] starting at global plane x0, wide enough for
@@ -1795,19 +1837,49 @@ extern "C" int64_t pm_khalo_floats(int n) {
 // width) plus the list of the particles whose new x left [x_lo, x_hi), as pm_kick_drift_wrap_slab returns it.
 // The deposit of the leavers is done here, by their old owner; the prepared tile lists are dropped (the
 // migration that follows renumbers the particles).
-extern "C" int pm_kick_drift_wrap_deposit_slab(pm_ctx *c, int scheme, float *d_pos, float *d_vel, const float *d_acc,
-                                               float half_dt, float dt, int64_t np, float *d_rho, float x_lo,
-                                               float x_hi, int64_t *d_leave_idx, int cap, int *h_count) {
+static int kdw_deposit_slab(pm_ctx *c, int scheme, float *d_pos, float *d_vel, const float *d_acc, float half_dt, float dt,
+                            int64_t np, float *d_rho, float x_lo, float x_hi, int64_t *d_leave_idx, int cap, int *h_count,
+                            float *d_khalo) {
     PM_REQUIRE(c && d_pos && d_vel && d_acc && d_rho && np > 0 && d_leave_idx && h_count && cap > 0, "bad argument");
     PM_REQUIRE(c->n >= 16 && np < 4294967296LL, "pm_kick_drift_wrap_deposit_slab needs n >= 16 and np < 2^32");
     int *d_count = reinterpret_cast<int *>(c->d_scratch + 16);
     PM_HIP(hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
     int rc = kdw_deposit_scheme(c, scheme, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho,
-                                Leavers{x_lo, x_hi, d_leave_idx, cap, d_count});
+                                Leavers{x_lo, x_hi, d_leave_idx, cap, d_count}, d_khalo);
     tile_lists_drop(c);
     if (rc) return rc;
     if (int rb_rc = pm_read_back(c, h_count, d_count, sizeof(int))) return rb_rc;
     return PM_OK;
+}
+
+extern "C" int pm_kick_drift_wrap_deposit_slab(pm_ctx *c, int scheme, float *d_pos, float *d_vel, const float *d_acc,
+                                               float half_dt, float dt, int64_t np, float *d_rho, float x_lo,
+                                               float x_hi, int64_t *d_leave_idx, int cap, int *h_count) {
+    return kdw_deposit_slab(c, scheme, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, x_lo, x_hi, d_leave_idx, cap, h_count,
+                            nullptr);
+}
+
+// ... with the halo buffer (pm_kick_drift_wrap_deposit_khalo on a slab): needs a tile window (pm_set_tile_window) and
+// the density slab = the window's planes + the same number (>= 1) of ghost planes either side.  The buffer holds the
+// window's rows of tiles only (pm_khalo_floats_slab(n, nx_window) floats); the owners STORE the window's planes
+// (d_rho is not cleared there), the ghost planes are cleared and receive the additions that leave the window through
+// its x faces: the edge tiles' outward halo cells and the clouds of particles in tiles outside it (leavers).  The
+// buffer is consumed by pm_fftp_z_forward_khalo once the caller has folded the ghost planes into the neighbours.
+extern "C" int pm_kick_drift_wrap_deposit_slab_khalo(pm_ctx *c, int scheme, float *d_pos, float *d_vel, const float *d_acc,
+                                                     float half_dt, float dt, int64_t np, float *d_rho, float x_lo,
+                                                     float x_hi, int64_t *d_leave_idx, int cap, int *h_count,
+                                                     float *d_khalo) {
+    PM_REQUIRE(d_khalo, "NULL argument");
+    PM_REQUIRE(c && c->tile_nx < c->n, "pm_kick_drift_wrap_deposit_slab_khalo needs a tile window (pm_set_tile_window)");
+    TileWork w;
+    tile_window(c, &w);
+    PM_REQUIRE(w.nlaunch != w.ntiles, "the tile window must be a power-of-two number of tile rows, aligned to a row");
+    return kdw_deposit_slab(c, scheme, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, x_lo, x_hi, d_leave_idx, cap, h_count,
+                            d_khalo);
+}
+
+extern "C" int64_t pm_khalo_floats_slab(int n, int nx_window) {
+    return (n >= 16 && nx_window >= PM_TI && nx_window % PM_TI == 0) ? halo_floats(n, nx_window >> PM_LI) : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -84,9 +85,21 @@ class HipOps:
             return torch.nonzero((x < x_lo) | (x >= x_hi), as_tuple=False).squeeze(1)
         return torch.sort(self._leave_buf[:count.value]).values
 
-    def kick_drift_wrap_deposit(self, scheme, pos, vel, acc, half_dt, dt, x_lo, x_hi, nx, x0):
+    def khalo_buffer(self, nx_window):
+        """The halo buffer of the fused kick + deposit for a window of nx_window planes (pmstep.h:
+        pm_khalo_floats_slab), kept between steps."""
+        buf = getattr(self, "_khalo_buf", None)
+        need = int(L.load_library().pm_khalo_floats_slab(self.n, nx_window))
+        if need <= 0:
+            return None
+        if buf is None or buf.numel() != need:
+            buf = self._khalo_buf = self.torch.zeros(need, dtype=self.torch.float32, device="cuda")
+        return buf
+
+    def kick_drift_wrap_deposit(self, scheme, pos, vel, acc, half_dt, dt, x_lo, x_hi, nx, x0, khalo=None):
         """Fused first kick + drift + wrap + deposit into [nx, n, n] planes starting at x0 (ghosts included);
-        returns (density, sorted leaver indices)."""
+        returns (density, sorted leaver indices).  `khalo`: the halo contributions of the window's tiles stay in that
+        buffer (pm_kick_drift_wrap_deposit_slab_khalo) for fftp_z_forward to add."""
         torch, n, npart = self.torch, self.n, pos.shape[0]
         cap = max(4096, npart // 16)
         if getattr(self, "_leave_buf", None) is None or self._leave_buf.numel() < cap:
@@ -96,9 +109,14 @@ class HipOps:
         self.ctx.call("pm_set_slab", nx, x0)
         self._window(True)
         try:
-            self.ctx.call("pm_kick_drift_wrap_deposit_slab", scheme, L.ptr(pos), L.ptr(vel), L.ptr(acc), float(half_dt),
-                          float(dt), npart, L.ptr(rho), float(x_lo), float(x_hi), L.ptr(self._leave_buf), cap,
-                          C.byref(count))
+            if khalo is not None:
+                self.ctx.call("pm_kick_drift_wrap_deposit_slab_khalo", scheme, L.ptr(pos), L.ptr(vel), L.ptr(acc),
+                              float(half_dt), float(dt), npart, L.ptr(rho), float(x_lo), float(x_hi),
+                              L.ptr(self._leave_buf), cap, C.byref(count), L.ptr(khalo))
+            else:
+                self.ctx.call("pm_kick_drift_wrap_deposit_slab", scheme, L.ptr(pos), L.ptr(vel), L.ptr(acc), float(half_dt),
+                              float(dt), npart, L.ptr(rho), float(x_lo), float(x_hi), L.ptr(self._leave_buf), cap,
+                              C.byref(count))
         finally:
             self.ctx.call("pm_set_slab", n, 0)
             self._window(False)
@@ -271,8 +289,11 @@ class HipOps:
         self.ctx.call("pm_fftp_xgreen", kind, int(p), L.ptr(seg), nx, nky, ky0, L.hptr(k2), L.hptr(s), c0)
 
     # stage-wise forms (pipelined against the all-to-alls)
-    def fftp_z_forward(self, rhs):
-        self.ctx.call("pm_fftp_z_forward", L.ptr(rhs), rhs.shape[0])
+    def fftp_z_forward(self, rhs, khalo=None):
+        if khalo is not None:
+            self.ctx.call("pm_fftp_z_forward_khalo", L.ptr(rhs), rhs.shape[0], L.ptr(khalo))
+        else:
+            self.ctx.call("pm_fftp_z_forward", L.ptr(rhs), rhs.shape[0])
 
     def fftp_y_forward(self, nx, kz0, nkz):
         out = self.torch.empty((self.n, nkz, nx), dtype=self.torch.complex64, device="cuda")
@@ -404,6 +425,7 @@ _FUSE_SLAB_DEPOSIT = True  # False: kick_drift_wrap, migration, then a separate 
 _PIPELINE_FFT = True    # False: the slab FFT exchanges the whole spectrum in one all-to-all each way
 _SLAB_MULTIGRID = True  # False: multigrid / MOND under slabs all-gather the density and solve replicated
 _SLAB_REBUCKET = True   # False: the gather writes in place and the particle stream of a rank is never re-sorted
+_SLAB_KHALO = os.environ.get("PMSTEP_SLAB_KHALO", "1") != "0"  # halo buffer of the fused kick + deposit (Newton FFT steps)
 
 
 class Slab:
@@ -624,15 +646,30 @@ class Slab:
             return None
         return self._codes
 
-    def _deposit_folded(self, position, scheme):
+    def _khalo_applies(self, param) -> bool:
+        """Will the pm() of this step be the Newtonian slab FFT with the pipelined LDS passes (the one consumer of the
+        halo buffer on a slab)?  The same tests as pm() / poisson_fft() make."""
+        ops = self.ops
+        if not (_SLAB_KHALO and _PIPELINE_FFT and hasattr(ops, "khalo_buffer") and hasattr(ops, "fftp_y_forward")):
+            return False
+        save = param["save_power_spectrum"].casefold()
+        save_pk = save == "yes" or (save == "z_out" and bool(param["write_snapshot"]))
+        return (param["theory"].casefold() == "newton" and param["linear_newton_solver"].casefold() in ("fft", "fft_7pt")
+                and not save_pk and bool(getattr(ops, "has_fftp", None)) and ops.has_fftp(self.nx, self.n // self.world))
+
+    def _deposit_folded(self, position, scheme, accept_khalo=False):
         """Density on the owned planes [nx, n, n] (a view into the deposit's [nx + 2W] array): deposit with W
         ghost planes each side (1, or what the fused kick + deposit of integrate() used), ghosts folded into
         the neighbours.  Not normalised."""
         nx, ops = self.nx, self.ops
         pre = getattr(self, "_predeposited", None)
         self._predeposited = None
+        self._khalo_live = None
         if pre is not None:
-            rho_ext, W = pre
+            rho_ext, W, khalo = pre
+            if khalo is not None and not accept_khalo:
+                raise RuntimeError("the fused kick + deposit left a halo buffer for a solve that cannot consume it")
+            self._khalo_live = khalo  # (what the window's tiles add to each other: consumed by fftp_z_forward)
         else:
             rho_ext, W = ops.deposit(scheme, position, nx + 2, self.x_lo - 1), 1
         from_left, from_right = exchange_planes(rho_ext[:W], rho_ext[nx + W:])
@@ -640,12 +677,14 @@ class Slab:
         rho_ext[nx:nx + W] += from_right          # right neighbour's left ghosts are my last planes
         return rho_ext[W:nx + W]                  # contiguous view of the owned planes
 
-    def _deposit_owned(self, position, param, scheme):
+    def _deposit_owned(self, position, param, scheme, accept_khalo=False):
         """The same, normalised to unit mean (solver.py:113)."""
         n, ops = self.n, self.ops
-        rho = self._deposit_folded(position, scheme)
+        rho = self._deposit_folded(position, scheme, accept_khalo)
         if n**3 != param["npart"]:
             ops.scale_inplace(rho, np.float32(n**3 / param["npart"]))
+            if self._khalo_live is not None:
+                ops.scale_inplace(self._khalo_live, np.float32(n**3 / param["npart"]))
         return rho
 
     def _gather(self, phi, position, param, scheme, kick):
@@ -701,11 +740,12 @@ class Slab:
     def _pm_decomposed(self, position, param, scheme, kick):
         import torch
 
-        rho = self._deposit_owned(position, param, scheme)
+        rho = self._deposit_owned(position, param, scheme, accept_khalo=True)
+        khalo, self._khalo_live = self._khalo_live, None
         param["compute_additional_field"] = False
         # solver.rhs_poisson's f1*(rho - 1) is folded into the Green's function (k = 0 is discarded)
         f1 = np.float32(1.5 * param["aexp"] * param["Om_m"] * param["parametrized_mu_z"])
-        phi = self.poisson_fft(rho, param, f1)
+        phi = self.poisson_fft(rho, param, f1, khalo=khalo)
         del rho
         acc = self._gather(phi, position, param, scheme, kick)
         empty = torch.empty(0, dtype=torch.float32, device=position.device)
@@ -862,7 +902,7 @@ class Slab:
         self.local_max = (ma, mv)
         return acc, potential, additional_field
 
-    def poisson_fft(self, rhs, param, scale=None):
+    def poisson_fft(self, rhs, param, scale=None, khalo=None):
         """solver.fft (solver.py:453-522) on slabs: 2-D r2c, transpose, 1-D c2c, Green's function in
         the transposed layout, and back."""
         n, nx, G, ops = self.n, self.nx, self.world, self.ops
@@ -883,7 +923,8 @@ class Slab:
             for i in range(nchunk):
                 ranges.append((k0, base + (1 if i < rem else 0)))
                 k0 += ranges[-1][1]
-            ops.fftp_z_forward(rhs)
+            ops.fftp_z_forward(rhs, khalo) if khalo is not None else ops.fftp_z_forward(rhs)
+            khalo = None
             fwd = [_AllToAllHandle(ops.fftp_y_forward(nx, kz0, nkz)) for kz0, nkz in ranges]   # [n (ky), nkz, nx] each
             bwd = []
             for (kz0, nkz), h in zip(ranges, fwd):
@@ -895,6 +936,8 @@ class Slab:
                 ops.fftp_y_inverse(h.wait(), nx, kz0, nkz)
             del bwd
             return ops.fftp_z_inverse(nx)
+        if khalo is not None:
+            raise RuntimeError("a halo buffer was handed to a slab FFT that cannot consume it")
         if getattr(ops, "has_fftp", None) and ops.has_fftp(nx, ny):
             # LDS-FFT passes: the forward stage already writes [ky][kz][x_local], so both all-to-alls
             # exchange contiguous blocks and the x pass reads its lines as G segments of nx elements
@@ -979,15 +1022,23 @@ class Slab:
                     integration.predict_next_step(dt, dt1, dt2, tables, param, t_snap_next, getattr(ops, "last_meanabs", None))
                     ops.set_prediction(param.get("_dt_pred") or dt, param.get("_acc_scale_pred", 1.0))
                     ops.set_destination_codes(codes)
+                # halo buffer (single-GPU step: DESIGN.md section 4): what the window's tiles add to each other stays
+                # out of the density slab until the FFT's z pass loads its lines -- when that is the solve that follows
+                khalo = ops.khalo_buffer(self.nx) if self._khalo_applies(param) else None
                 try:
-                    rho_ext, leave = ops.kick_drift_wrap_deposit(_SCHEME[MASS_SCHEME], position, velocity, acceleration,
-                                                                 half_dt, np.float32(dt), x_lo, x_hi, self.nx + 2 * W,
-                                                                 self.x_lo - W)
+                    if khalo is not None:
+                        rho_ext, leave = ops.kick_drift_wrap_deposit(_SCHEME[MASS_SCHEME], position, velocity, acceleration,
+                                                                     half_dt, np.float32(dt), x_lo, x_hi, self.nx + 2 * W,
+                                                                     self.x_lo - W, khalo=khalo)
+                    else:
+                        rho_ext, leave = ops.kick_drift_wrap_deposit(_SCHEME[MASS_SCHEME], position, velocity, acceleration,
+                                                                     half_dt, np.float32(dt), x_lo, x_hi, self.nx + 2 * W,
+                                                                     self.x_lo - W)
                 finally:
                     if codes is not None:
                         ops.set_destination_codes(None)
                 param["_dt_last"] = float(dt)
-                self._predeposited = (rho_ext, W)
+                self._predeposited = (rho_ext, W, khalo)
             else:
                 leave = ops.kick_drift_wrap(position, velocity, acceleration, half_dt, np.float32(dt), x_lo, x_hi)
                 if codes is not None:

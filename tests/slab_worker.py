@@ -80,6 +80,7 @@ def main():
             fracs.append(amd_utils.straggler_fraction(n)[0] or 0.0)
     out["rebucketed"], out["stragglers"] = np.int64(rebucketed), np.asarray(fracs, dtype=np.float64)
     out["id"] = s.carry[0].cpu().numpy()
+    out["khalo"] = np.int64(getattr(s.ops, "_khalo_buf", None) is not None)  # the fused kick + deposit used a halo buffer
     out.update(pos=p.cpu().numpy(), vel=v.cpu().numpy(), acc=acc.cpu().numpy(), phi=phi.cpu().numpy(),
                t=param["t"], aexp=param["aexp"])
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)

@@ -750,6 +750,101 @@ def test_fftp_kz_chunked_stages_match_fused(amd, nseg):
     assert torch.equal(phi, ref)
 
 
+@pytest.mark.parametrize("nseg,ghosts", [(2, 2), (4, 3), (8, 2)])
+def test_slab_halo_buffer_deposit_into_the_slab_fft(amd, nseg, ghosts):
+    """The halo buffer on slabs, end to end on one GPU: per window, pm_kick_drift_wrap_deposit_slab_khalo (owners store
+    the window's planes, the tiles' mutual halo cells stay in the window's buffer, what leaves through the x faces --
+    the edge tiles' outward cells and the leavers' clouds -- is added to the ghost planes), the ghost planes folded into
+    the neighbours by hand, then pm_fftp_z_forward_khalo and the rest of the slab FFT.  Against the potential of the
+    plain deposit of the same drifted particles through pm_poisson_fft_fused.  (8 windows: one row of tiles each, both
+    of its x faces are window edges.)"""
+    import ctypes as C
+
+    import pysco_amd._lib as L
+    from pysco_amd import fourier
+
+    torch = amd.torch
+    n = 64
+    nx = ny = n // nseg
+    nh = n // 2 + 1
+    W = ghosts
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100 + nseg)
+    npart = 150_000
+    pos = torch.rand((npart, 3), generator=g, device="cuda")
+    pos[: npart // 3, 1:] = 0.4 + 0.1 * pos[: npart // 3, 1:]          # a dense filament: over-full tiles
+    # (dt = 1: a displacement of at most W - 1.6 cells, so that the cloud of a leaver -- 1.5 cells more -- stays inside
+    # the W ghost planes, as Slab.integrate chooses W)
+    vel = (torch.rand((npart, 3), generator=g, device="cuda") - 0.5) * 2 * (W - 1.6) / n
+    acc = torch.zeros_like(pos)
+    ctx = L.context(n)
+    k2, s, c0 = fourier.green_tables(n, L.GREEN_COMPENSATED)
+    # reference: the same update on the whole box, plain deposit, fused FFT
+    p_ref, v_ref = pos.clone(), vel.clone()
+    rho_ref = torch.empty((n, n, n), dtype=torch.float32, device="cuda")
+    ctx.call("pm_kick_drift_wrap_deposit", L.TSC, L.ptr(p_ref), L.ptr(v_ref), L.ptr(acc), 0.0, 1.0, npart, L.ptr(rho_ref))
+    assert abs(float(rho_ref.sum()) - npart) < 1e-3 * npart
+    phi_ref = torch.empty_like(rho_ref)
+    ctx.call("pm_poisson_fft_fused", L.GREEN_COMPENSATED, 3, L.ptr(rho_ref), L.ptr(phi_ref), L.hptr(k2), L.hptr(s), c0)
+    # windows
+    owner = (pos[:, 0] * nseg).long().clamp_(0, nseg - 1)
+    exts, halos, moved = [], [], 0
+    leave_buf = torch.empty(npart, dtype=torch.int64, device="cuda")
+    for r in range(nseg):
+        pr, vr = amd.utils.reorder_particles(pos[owner == r].clone(), vel[owner == r].clone())
+        swap = torch.randperm(pr.shape[0], generator=g, device="cuda")[: pr.shape[0] // 20]
+        pr[swap], vr[swap] = pr[swap.flip(0)].clone(), vr[swap.flip(0)].clone()   # strangers: served from the lists
+        ar = torch.zeros_like(pr)
+        rho_ext = torch.full((nx + 2 * W, n, n), float("nan"), dtype=torch.float32, device="cuda")
+        kh = torch.full((int(L.load_library().pm_khalo_floats_slab(n, nx)),), float("nan"), dtype=torch.float32, device="cuda")
+        count = C.c_int(0)
+        ctx.call("pm_set_slab", nx + 2 * W, r * nx - W)
+        ctx.call("pm_set_tile_window", r * nx, nx)
+        try:
+            ctx.call("pm_kick_drift_wrap_deposit_slab_khalo", L.TSC, L.ptr(pr), L.ptr(vr), L.ptr(ar), 0.0, 1.0, pr.shape[0],
+                     L.ptr(rho_ext), r / nseg, (r + 1) / nseg, L.ptr(leave_buf), npart, C.byref(count), L.ptr(kh))
+        finally:
+            ctx.call("pm_set_slab", n, 0)
+            ctx.call("pm_set_tile_window", 0, n)
+        moved += count.value
+        assert torch.isfinite(rho_ext).all()   # every plane written: the window's by the owners, the ghosts cleared
+        exts.append(rho_ext), halos.append(kh)
+    assert moved > 100, "the test should have leavers"
+    own = []
+    for r in range(nseg):   # fold the ghost planes (ring)
+        o = exts[r][W:W + nx].clone()
+        o[:W] += exts[(r - 1) % nseg][nx + W:]
+        o[nx - W:] += exts[(r + 1) % nseg][:W]
+        own.append(o.contiguous())
+    total = sum(float(o.sum()) for o in own) + sum(float(torch.nan_to_num(h).sum()) for h in halos)
+    assert abs(total - npart) < 1e-3 * npart   # nothing lost, nothing twice (unread edge entries aside: they are NaN)
+    # slab FFT with the buffers
+    ranges = [(0, 9), (9, 8), (17, 8), (25, 8)]
+    chunks = {}
+    for r in range(nseg):
+        ctx.call("pm_fftp_z_forward_khalo", L.ptr(own[r]), nx, L.ptr(halos[r]))
+        for kz0, nkz in ranges:
+            c = torch.empty((n, nkz, nx), dtype=torch.complex64, device="cuda")
+            ctx.call("pm_fftp_y_forward", nx, kz0, nkz, L.ptr(c))
+            chunks[(r, kz0)] = c
+    segs = {}
+    for kz0, nkz in ranges:
+        for q in range(nseg):
+            seg = torch.stack([chunks[(r, kz0)][q * ny:(q + 1) * ny] for r in range(nseg)], dim=0).contiguous()
+            ctx.call("pm_fftp_xgreen_kz", L.GREEN_COMPENSATED, 3, L.ptr(seg), nx, ny, q * ny, kz0, nkz, L.hptr(k2), L.hptr(s), c0)
+            segs[(q, kz0)] = seg
+    phi = torch.empty_like(phi_ref)
+    for r in range(nseg):
+        for kz0, nkz in ranges:
+            back = torch.cat([segs[(q, kz0)][r] for q in range(nseg)], dim=0).contiguous()
+            ctx.call("pm_fftp_y_inverse", L.ptr(back), nx, kz0, nkz)
+        out = torch.empty((nx, n, n), dtype=torch.float32, device="cuda")
+        ctx.call("pm_fftp_z_inverse", nx, L.ptr(out))
+        phi[r * nx:(r + 1) * nx] = out
+    assert torch.isfinite(phi).all()
+    assert float((phi - phi_ref).abs().max()) < 2e-5 * float(phi_ref.abs().max())
+
+
 def test_run_nbody_loop_vs_oracle(amd):
     """pysco_amd.main.run_nbody (main.py:116-156: first pm, step loop to the last output redshift, snapshot
     clipping of dt, re-ordering every n_reorder steps) against the same loop written with the oracle."""

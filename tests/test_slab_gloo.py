@@ -160,6 +160,19 @@ def test_two_ranks_on_one_gpu_hip(tmp_path):
     n, steps, world = 64, 2, 2
     ranks = run_ranks(world, tmp_path, "hip", n, steps)
     check_against_reference(ranks, reference_run(n, steps), n, world)
+    assert all(int(r["khalo"]) == 1 for r in ranks)  # (the Newtonian FFT step keeps its halo buffer on a slab)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_slab_step_without_the_halo_buffer(tmp_path, world, monkeypatch):
+    """PMSTEP_SLAB_KHALO=0: the fused kick + deposit flushes every tile into the cleared slab with atomics (the form the
+    multigrid / MOND / f(R) slab steps keep): same trajectories."""
+    monkeypatch.setenv("PMSTEP_SLAB_KHALO", "0")
+    n, steps = 64, 2
+    ranks = run_ranks(world, tmp_path, "hip", n, steps)
+    check_against_reference(ranks, reference_run(n, steps), n, world)
+    assert all(int(r["khalo"]) == 0 for r in ranks)
 
 
 @pytest.mark.gpu
@@ -187,6 +200,7 @@ def test_four_ranks_on_one_gpu_hip(tmp_path):
     n, steps, world = 64, 2, 4
     ranks = run_ranks(world, tmp_path, "hip", n, steps)
     check_against_reference(ranks, reference_run(n, steps), n, world)
+    assert all(int(r["khalo"]) == 1 for r in ranks)
 
 
 @pytest.mark.gpu
