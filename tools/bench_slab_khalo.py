@@ -62,6 +62,9 @@ try:
 finally:
     ctx.call("pm_set_slab", n, 0)
     ctx.call("pm_set_tile_window", 0, n)
+# (after the last call, the one with the buffer: every particle's unit of mass is in the slab or in the buffer)
+mass = float(rho.sum(dtype=torch.float64)) + float(khalo.sum(dtype=torch.float64))
+print(f"mass in the slab + buffer / particles - 1 = {mass / npart - 1:.2e}")
 own = own.contiguous()
 t_z = timed(lambda: ctx.call("pm_fftp_z_forward", L.ptr(own), nx))
 t_zh = timed(lambda: ctx.call("pm_fftp_z_forward_khalo", L.ptr(own), nx, L.ptr(khalo)))
