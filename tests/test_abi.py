@@ -38,6 +38,20 @@ def test_binding_covers_header(lib):
     assert lib.pm_version() >= 100
 
 
+def test_halo_buffer_sizes(lib):
+    """Pure size functions (no GPU): a slab's halo buffer holds its rows of tiles only, so the slabs of a G-way split
+    add up to the single-GPU buffer; windows that are not whole rows of tiles have none."""
+    for n in (64, 1024):
+        whole = lib.pm_khalo_floats(n)
+        cells = n**3
+        # K: 2 x 10 x 18 floats per tile of 8 x 16 x 16 cells; Hi: 2 x 18 lines, Hj: 2 x 8 lines of n per tile column
+        assert whole == (cells // 2048) * 360 + (n // 8) * (n // 16) * (36 + 16) * n
+        assert lib.pm_khalo_floats_slab(n, n) == whole
+        for G in (2, 4, 8):
+            assert G * lib.pm_khalo_floats_slab(n, n // G) == whole
+    assert lib.pm_khalo_floats_slab(64, 12) == 0 and lib.pm_khalo_floats_slab(8, 8) == 0 and lib.pm_khalo_floats(8) == 0
+
+
 def test_no_oracle_in_product():
     """The product package must never import the oracle."""
     pkg = os.path.join(ROOT, "pysco_amd")
