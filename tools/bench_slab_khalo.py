@@ -65,6 +65,15 @@ finally:
 # (after the last call, the one with the buffer: every particle's unit of mass is in the slab or in the buffer)
 mass = float(rho.sum(dtype=torch.float64)) + float(khalo.sum(dtype=torch.float64))
 print(f"mass in the slab + buffer / particles - 1 = {mass / npart - 1:.2e}")
+if "--single" in sys.argv:  # the same particles through the single-GPU entry points (full mesh, the other tiles empty)
+    rho_full = torch.empty((n, n, n), dtype=torch.float32, device="cuda")
+    kh_full = torch.zeros(int(L.load_library().pm_khalo_floats(n)), dtype=torch.float32, device="cuda")
+    t_sp = timed(lambda: ctx.call("pm_kick_drift_wrap_deposit", L.TSC, L.ptr(pos), L.ptr(vel), L.ptr(acc), 0.0, dt, npart,
+                                  L.ptr(rho_full)))
+    t_sh = timed(lambda: ctx.call("pm_kick_drift_wrap_deposit_khalo", L.TSC, L.ptr(pos), L.ptr(vel), L.ptr(acc), 0.0, dt,
+                                  npart, L.ptr(rho_full), L.ptr(kh_full)))
+    print(f"single-GPU entry points, same particles: plain {t_sp:.2f} ms, halo buffer {t_sh:.2f} ms")
+    del rho_full, kh_full
 own = own.contiguous()
 t_z = timed(lambda: ctx.call("pm_fftp_z_forward", L.ptr(own), nx))
 t_zh = timed(lambda: ctx.call("pm_fftp_z_forward_khalo", L.ptr(own), nx, L.ptr(khalo)))
