@@ -935,12 +935,13 @@ def _hr(phi_k, ij):
 def _corner_blocks(x, n_out) -> np.ndarray:
     """initial_conditions.py:1859-1928 (pad: n -> 3n/2, trim: 3n/2 -> n): zeros, then the four low/high corner blocks
     of the x and y axes and the low block of z, `middle` = half the SMALLER size (the Nyquist planes are dropped)."""
-    middle = min(x.shape[0], n_out) // 2
+    n_in = x.shape[0]
+    middle = min(n_in, n_out) // 2
+    low = np.arange(middle)                                   # frequencies 0 .. middle - 1
+    keep_in = np.concatenate([low, np.arange(n_in - middle + 1, n_in)])      # ... and -(middle - 1) .. -1
+    keep_out = np.concatenate([low, np.arange(n_out - middle + 1, n_out)])   # the same frequencies in the other grid
     out = np.zeros((n_out, n_out, n_out // 2 + 1), dtype=x.dtype)
-    out[:middle, :middle, :middle] = x[:middle, :middle, :middle]
-    out[-middle + 1:, :middle, :middle] = x[-middle + 1:, :middle, :middle]
-    out[:middle, -middle + 1:, :middle] = x[:middle, -middle + 1:, :middle]
-    out[-middle + 1:, -middle + 1:, :middle] = x[-middle + 1:, -middle + 1:, :middle]
+    out[np.ix_(keep_out, keep_out, low)] = x[np.ix_(keep_in, keep_in, low)]
     return out
 
 
