@@ -384,13 +384,14 @@ def main():
                    "pm_greens_slab": 2.0 * spec, "pm_gradient_slab": 16.0 * cells,
                    "pm_fftp_forward": 16.0 * cells, "pm_fftp_inverse": 16.0 * cells, "pm_fftp_xgreen": 2.0 * spec,
                    # pipelined form: z passes whole, y / x passes per kz chunk (4 chunks)
-                   "pm_fftp_z_forward": 8.0 * cells, "pm_fftp_z_inverse": 8.0 * cells,
+                   "pm_fftp_z_forward": 8.0 * cells, "pm_fftp_z_forward_khalo": 8.0 * cells, "pm_fftp_z_inverse": 8.0 * cells,
                    "pm_fftp_y_forward": 2.0 * spec / 4, "pm_fftp_y_inverse": 2.0 * spec / 4,
                    "pm_fftp_xgreen_kz": 2.0 * spec / 4,
                    "pm_gradient_interp_kick_rebucket_slab": 48.0 * npart / world + 4.0 * cells,
                    "pm_tile_lists_codes": 13.0 * npart / world, "pm_tile_lists": 12.0 * npart / world,
                    "pm_kick_drift_wrap_slab": 60.0 * npart / world,
-                   "pm_kick_drift_wrap_deposit_slab": 60.0 * npart / world + 4.0 * cells})
+                   "pm_kick_drift_wrap_deposit_slab": 60.0 * npart / world + 4.0 * cells,
+                   "pm_kick_drift_wrap_deposit_slab_khalo": 60.0 * npart / world + 4.0 * cells})
     table = []
     for name, (calls, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):
         avg = ms / calls
@@ -444,7 +445,10 @@ def main():
                                   + f"order-5 gradient, leapfrog KDK, Zel'dovich ICs rms {args.rms_cells} cell, "
                                   "Morton-sorted once, then the product loop's order policy inside the timed steps ("
                                   + (f"incremental tile re-sort above {param['rebucket_straggler_fraction']:g} stragglers"
-                                     if "rebucket_straggler_fraction" in param else "in-place steps")
+                                     if "rebucket_straggler_fraction" in param else
+                                     ("every rank's stream re-bucketed by its gather every step"
+                                      + (", halo buffer of the fused kick + deposit on the slab" if slab._SLAB_KHALO else "")
+                                      if world > 1 and slab._SLAB_REBUCKET else "in-place steps"))
                                   + f", full sort above {pm_main.REORDER_FRACTION:g})",
                       "ncells_1d": n, "npart": npart, "vcycles_per_step": cycles,
                       "parallelism": "1 GPU" if world == 1 else f"{world} x-slabs, RCCL all-to-all FFT transposes + ring halos"},
