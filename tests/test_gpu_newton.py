@@ -750,8 +750,8 @@ def test_fftp_kz_chunked_stages_match_fused(amd, nseg):
     assert torch.equal(phi, ref)
 
 
-@pytest.mark.parametrize("nseg,ghosts", [(2, 2), (4, 3), (8, 2)])
-def test_slab_halo_buffer_deposit_into_the_slab_fft(amd, nseg, ghosts):
+@pytest.mark.parametrize("nseg,ghosts,scheme", [(2, 2, "tsc"), (4, 3, "tsc"), (8, 2, "tsc"), (4, 2, "cic"), (2, 2, "ngp")])
+def test_slab_halo_buffer_deposit_into_the_slab_fft(amd, nseg, ghosts, scheme):
     """The halo buffer on slabs, end to end on one GPU: per window, pm_kick_drift_wrap_deposit_slab_khalo (owners store
     the window's planes, the tiles' mutual halo cells stay in the window's buffer, what leaves through the x faces --
     the edge tiles' outward cells and the leavers' clouds -- is added to the ghost planes), the ghost planes folded into
@@ -768,6 +768,7 @@ def test_slab_halo_buffer_deposit_into_the_slab_fft(amd, nseg, ghosts):
     nx = ny = n // nseg
     nh = n // 2 + 1
     W = ghosts
+    mas, p_mas = {"tsc": (L.TSC, 3), "cic": (L.CIC, 2), "ngp": (L.NGP, 1)}[scheme]
     g = torch.Generator(device="cuda")
     g.manual_seed(100 + nseg)
     npart = 150_000
@@ -782,10 +783,10 @@ def test_slab_halo_buffer_deposit_into_the_slab_fft(amd, nseg, ghosts):
     # reference: the same update on the whole box, plain deposit, fused FFT
     p_ref, v_ref = pos.clone(), vel.clone()
     rho_ref = torch.empty((n, n, n), dtype=torch.float32, device="cuda")
-    ctx.call("pm_kick_drift_wrap_deposit", L.TSC, L.ptr(p_ref), L.ptr(v_ref), L.ptr(acc), 0.0, 1.0, npart, L.ptr(rho_ref))
+    ctx.call("pm_kick_drift_wrap_deposit", mas, L.ptr(p_ref), L.ptr(v_ref), L.ptr(acc), 0.0, 1.0, npart, L.ptr(rho_ref))
     assert abs(float(rho_ref.sum()) - npart) < 1e-3 * npart
     phi_ref = torch.empty_like(rho_ref)
-    ctx.call("pm_poisson_fft_fused", L.GREEN_COMPENSATED, 3, L.ptr(rho_ref), L.ptr(phi_ref), L.hptr(k2), L.hptr(s), c0)
+    ctx.call("pm_poisson_fft_fused", L.GREEN_COMPENSATED, p_mas, L.ptr(rho_ref), L.ptr(phi_ref), L.hptr(k2), L.hptr(s), c0)
     # windows
     owner = (pos[:, 0] * nseg).long().clamp_(0, nseg - 1)
     exts, halos, moved = [], [], 0
@@ -801,7 +802,7 @@ def test_slab_halo_buffer_deposit_into_the_slab_fft(amd, nseg, ghosts):
         ctx.call("pm_set_slab", nx + 2 * W, r * nx - W)
         ctx.call("pm_set_tile_window", r * nx, nx)
         try:
-            ctx.call("pm_kick_drift_wrap_deposit_slab_khalo", L.TSC, L.ptr(pr), L.ptr(vr), L.ptr(ar), 0.0, 1.0, pr.shape[0],
+            ctx.call("pm_kick_drift_wrap_deposit_slab_khalo", mas, L.ptr(pr), L.ptr(vr), L.ptr(ar), 0.0, 1.0, pr.shape[0],
                      L.ptr(rho_ext), r / nseg, (r + 1) / nseg, L.ptr(leave_buf), npart, C.byref(count), L.ptr(kh))
         finally:
             ctx.call("pm_set_slab", n, 0)
@@ -831,7 +832,7 @@ def test_slab_halo_buffer_deposit_into_the_slab_fft(amd, nseg, ghosts):
     for kz0, nkz in ranges:
         for q in range(nseg):
             seg = torch.stack([chunks[(r, kz0)][q * ny:(q + 1) * ny] for r in range(nseg)], dim=0).contiguous()
-            ctx.call("pm_fftp_xgreen_kz", L.GREEN_COMPENSATED, 3, L.ptr(seg), nx, ny, q * ny, kz0, nkz, L.hptr(k2), L.hptr(s), c0)
+            ctx.call("pm_fftp_xgreen_kz", L.GREEN_COMPENSATED, p_mas, L.ptr(seg), nx, ny, q * ny, kz0, nkz, L.hptr(k2), L.hptr(s), c0)
             segs[(q, kz0)] = seg
     phi = torch.empty_like(phi_ref)
     for r in range(nseg):
