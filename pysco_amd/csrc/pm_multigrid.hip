@@ -419,11 +419,89 @@ __global__ __launch_bounds__(BLK) void lap_residual_error_rows_kernel(const floa
     block_sum_to(acc, result);
 }
 
+// The same for n >= 512, marching: a workgroup owns 16 rows (j) x 128 cells (k) and walks RM_LX planes along x; a thread
+// keeps its eight cells of planes i - 1, i, i + 1 in registers (every plane of x is loaded once, as "i + 1"), the rows
+// j - 1 / j + 1 and the cells k - 1 / k + 8 come from the other threads through LDS (the two rows and the cells just
+// outside the workgroup's patch: loaded by its edge threads).  The row kernel above asks the L2 for six octets per
+// octet of cells (its neighbours' rows again and again: 11 TB/s of L2 reads at 512^3, 0.29 ms); this one for a little
+// over two.  Same expression per cell; the squares are summed in fp64 (in another order: the last bits of the fp64 sum).
+constexpr int RM_TJ = 16, RM_TK = 128, RM_LX = 32;
+__global__ __launch_bounds__(BLK) void lap_residual_error_march_kernel(const float *__restrict__ x, const float *__restrict__ b,
+                                                                       int log2n, float invh2, double *__restrict__ result,
+                                                                       XRange xr) {
+    __shared__ __attribute__((aligned(16))) float sh[2][RM_TJ + 2][RM_TK + 8];  // [..][row jj + 1][4 + k]: cells k0 - 1 .. k0 + 128
+    const int n = 1 << log2n, m = n - 1, tid = threadIdx.x;
+    const int ncol_k = n / RM_TK, ncol_j = n / RM_TJ;
+    const int col = blockIdx.x % (ncol_k * ncol_j), seg = blockIdx.x / (ncol_k * ncol_j);
+    const int kb = (col % ncol_k) * RM_TK, j0 = (col / ncol_k) * RM_TJ;
+    const int jj = tid >> 4, kq = tid & 15, j = j0 + jj, k0 = kb + 8 * kq;
+    const int ia = xr.i0 + seg * RM_LX, ie = min(ia + RM_LX, xr.i0 + xr.ni);
+    auto row = [&](const float *g, int a, int bb) -> const float * {
+        return g + ((((int64_t)(a & xr.xmask) << log2n) + (bb & m)) << log2n);
+    };
+    auto ld8 = [&](const float *p, float *d) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(p), q1 = *reinterpret_cast<const float4 *>(p + 4);
+        d[0] = q0.x, d[1] = q0.y, d[2] = q0.z, d[3] = q0.w, d[4] = q1.x, d[5] = q1.y, d[6] = q1.z, d[7] = q1.w;
+    };
+    // what a thread brings besides its own octet: a row outside the patch (jj = 0: j0 - 1, jj = 15: j0 + 16), a cell
+    // outside it (kq = 0: kb - 1, kq = 15: kb + 128)
+    const bool edge_j = jj == 0 || jj == RM_TJ - 1, edge_k = kq == 0 || kq == 15;
+    const int jrow = jj == 0 ? j0 - 1 : j0 + RM_TJ, lrow = jj == 0 ? 0 : RM_TJ + 1;
+    const int kcell = kq == 0 ? kb - 1 : kb + RM_TK, lcell = kq == 0 ? 3 : 4 + RM_TK;
+    float prev[8], cur[8], next[8], erow[8], bb8[8], ecell = 0.f;
+    if (ia >= ie) {  // (never with the launch below; keeps the barriers of the loop uniform)
+        block_sum_to(0.0, result);
+        return;
+    }
+    ld8(row(x, ia - 1, j) + k0, prev);
+    ld8(row(x, ia, j) + k0, cur);
+    double acc = 0;
+    for (int i = ia; i < ie; ++i) {
+        float *pl = &sh[i & 1][0][0];
+        constexpr int RS = RM_TK + 8;
+        ld8(row(x, i + 1, j) + k0, next);
+        ld8(row(b, i, j) + k0, bb8);
+        if (edge_j) ld8(row(x, i, jrow) + k0, erow);
+        if (edge_k) ecell = row(x, i, j)[kcell & m];
+        *reinterpret_cast<float4 *>(pl + (jj + 1) * RS + 4 + 8 * kq) = make_float4(cur[0], cur[1], cur[2], cur[3]);
+        *reinterpret_cast<float4 *>(pl + (jj + 1) * RS + 8 + 8 * kq) = make_float4(cur[4], cur[5], cur[6], cur[7]);
+        if (edge_j) {
+            *reinterpret_cast<float4 *>(pl + lrow * RS + 4 + 8 * kq) = make_float4(erow[0], erow[1], erow[2], erow[3]);
+            *reinterpret_cast<float4 *>(pl + lrow * RS + 8 + 8 * kq) = make_float4(erow[4], erow[5], erow[6], erow[7]);
+        }
+        if (edge_k) pl[(jj + 1) * RS + lcell] = ecell;
+        __syncthreads();  // (one barrier per plane: the next plane goes to the other buffer)
+        const float *me = pl + (jj + 1) * RS + 4 + 8 * kq, *ym = me - RS, *yp = me + RS;
+        const float4 a0 = *reinterpret_cast<const float4 *>(ym), a1 = *reinterpret_cast<const float4 *>(ym + 4);
+        const float4 c0 = *reinterpret_cast<const float4 *>(yp), c1 = *reinterpret_cast<const float4 *>(yp + 4);
+        const float aym[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float ayp[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        float v[10];
+        v[0] = me[-1], v[9] = me[8];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) v[c2 + 1] = cur[c2];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+            const float s = +prev[c2] + v[c2] + v[c2 + 2] + aym[c2] - 6.0f * v[c2 + 1] + ayp[c2] + next[c2];
+            const float r = -(s)*invh2 + bb8[c2];
+            acc += (double)(r * r);
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) prev[c2] = cur[c2], cur[c2] = next[c2];
+    }
+    block_sum_to(acc, result);
+}
+
 static int lap_residual_sumsq(pm_ctx *c, const float *d_x, const float *d_b, int n, XRange xr, double *h_sum) {
     PM_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(double), c->stream));
     const int64_t total = (int64_t)xr.ni * n * n;
     int blocks = pm_stream_blocks(total, BLK * 4);
-    if (n >= 16 && pm_aligned16(d_x) && pm_aligned16(d_b))
+    // (from 512^3: at 256^3 the patches x segments are one workgroup per CU and the row kernel is as fast)
+    if (n >= 512 && c->mg_fused_sweep && pm_aligned16(d_x) && pm_aligned16(d_b))
+        hipLaunchKernelGGL(lap_residual_error_march_kernel,
+                           dim3((unsigned)((n / RM_TJ) * (n / RM_TK) * ((xr.ni + RM_LX - 1) / RM_LX))), dim3(BLK), 0, c->stream, d_x,
+                           d_b, ilog2(n), (float)((double)n * n), c->d_hist, xr);
+    else if (n >= 16 && pm_aligned16(d_x) && pm_aligned16(d_b))
         // (2048 workgroups at most: each ends with one same-address fp64 atomic, ~12 ns apiece)
         hipLaunchKernelGGL(lap_residual_error_rows_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n),
                            (float)((double)n * n), c->d_hist, xr);

@@ -287,6 +287,50 @@ def test_native_vcycle_is_the_python_recursion(amd, n):
     assert np.isfinite(out[True]).all()
 
 
+@pytest.mark.parametrize("slab", [False, True])
+def test_marching_residual_norm_is_the_row_kernels(amd, slab):
+    """laplacian.residual_error at 512^3 (the convergence test after every V-cycle): the marching kernel (a plane of x
+    loaded once, neighbours through registers and LDS) against the row kernel it replaces there -- the same per-cell
+    expression, fp64 sums in another order -- and against a float64 evaluation; on a cube and on a slab with ghost
+    planes (pm_lap_residual_sumsq_slab: 40 planes, two segments of the march, the second one short)."""
+    import ctypes as C
+
+    from pysco_amd import _lib as L
+
+    t = amd.torch
+    n, nx = 512, 40
+    g = t.Generator(device="cuda")
+    g.manual_seed(5)
+    shape = (nx + 2, n, n) if slab else (n, n, n)
+    x = t.rand(shape, generator=g, device="cuda")
+    b = t.rand(shape, generator=g, device="cuda")
+    ctx = L.context(4)
+    got = {}
+    for march in (1, 0):
+        ctx.call("pm_set_fused_sweep", march)
+        try:
+            if slab:
+                s = C.c_double(0)
+                ctx.call("pm_lap_residual_sumsq_slab", L.ptr(x), L.ptr(b), n, nx, C.byref(s))
+                got[march] = s.value
+            else:
+                o = C.c_float(0)
+                ctx.call("pm_lap_residual_error", L.ptr(x), L.ptr(b), n, C.byref(o))
+                got[march] = float(o.value) ** 2
+        finally:
+            ctx.call("pm_set_fused_sweep", 1)
+    xd, bd = x.double(), b.double()
+    if slab:   # owned planes 1 .. nx, neighbours in x are the ghost planes
+        c = xd[1:-1]
+        lap = xd[:-2] + xd[2:] + t.roll(c, 1, 1) + t.roll(c, -1, 1) + t.roll(c, 1, 2) + t.roll(c, -1, 2) - 6 * c
+        want = float(((-lap * n * n + bd[1:-1]) ** 2).sum())
+    else:
+        lap = sum(t.roll(xd, sh, ax) for ax in range(3) for sh in (1, -1)) - 6 * xd
+        want = float(((-lap * n * n + bd) ** 2).sum())
+    assert abs(got[1] - got[0]) <= (1e-12 if slab else 3e-7) * got[0]
+    assert abs(got[1] - want) <= 2e-6 * want   # (fp32 residuals per cell against fp64 ones)
+
+
 @pytest.mark.parametrize("n,sweeps", [(256, 1), (256, 2), (256, 3), (512, 2)])
 def test_single_pass_sweep_is_the_two_half_sweeps(amd, n, sweeps):
     """The single-pass red + black sweep (pm_lap_smoothing, n >= 256: one workgroup marching a column through LDS
