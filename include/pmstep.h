@@ -64,6 +64,8 @@ int pm_gradient(pm_ctx *ctx, int order, const float *d_phi, float *d_force);
 /* mesh.derivative_fR :2112 -> derivativeK_fR_n1/n2 :860-2069: grad(phi) + f*grad(u**(fr_n+1)). */
 int pm_gradient_fr(pm_ctx *ctx, int order, int fr_n, float f, const float *d_phi, const float *d_u,
                    float *d_force);
+/* pm_gradient_fr from 128^3 walks x with the stencil's planes in registers, like pm_gradient (same bits); 0: the row kernel */
+int pm_set_fr_march_gradient(pm_ctx *ctx, int on);
 
 /* ---- utils.py ----------------------------------------------------------------------------- */
 int pm_axpy(pm_ctx *ctx, float *d_y, const float *d_x, float a, int64_t count);              /* :264 */

@@ -80,6 +80,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_khalo_apply": (_vp, _vp, _vp),
     "pm_khalo_floats": (_i,),
     "pm_khalo_floats_slab": (_i, _i),
+    "pm_set_fr_march_gradient": (_vp, _i),
     "pm_kick_drift_wrap_deposit_slab_khalo": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _f, _f, _vp, _i, C.POINTER(_i), _vp),
     "pm_fftp_z_forward_khalo": (_vp, _vp, _i, _vp),
     "pm_kick_drift_wrap_deposit_slab": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _f, _f, _vp, _i, C.POINTER(_i)),

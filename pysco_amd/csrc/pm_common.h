@@ -181,6 +181,7 @@ struct pm_ctx {
     const float *sorted_pos;   // positions that were written tile by tile with table rb_cur (a hint: any table that
     int64_t sorted_np;         // partitions [0, np) gives correct results, an exact one saves the bisection)
     unsigned sorted_ntiles;
+    int fr_march_gradient;     // pm_gradient_fr: marching kernel from 128^3 (default on)
     int64_t *sorted_table;     // ... and where those offsets are (inside rb_buf)
     int rb_cur;
     int mg_fused_sweep;  // 1 (default): single-pass red + black sweep for n >= 256 (pm_set_fused_sweep; tests compare)

@@ -328,9 +328,10 @@ __global__ __launch_bounds__(BLK) void gradient_kernel(const float *__restrict__
 // and walks SEG consecutive x-planes with the 2R+1 planes of its x-stencil in registers, so phi
 // comes from HBM once (plus 2R/SEG halo) instead of being re-fetched by 2R+1 different workgroups;
 // the y/z neighbours are L1/L2 hits inside the plane.  Same Stencil::eval, same bits.
-template <int ORDER>
-__global__ __launch_bounds__(BLK) void gradient_march_kernel(const float *__restrict__ phi, float scale, int n,
-                                                             int log2n, int seg, float *__restrict__ out) {
+template <int ORDER, int FRN>
+__global__ __launch_bounds__(BLK) void gradient_march_kernel(const float *__restrict__ phi, const float *__restrict__ u,
+                                                             float f, float scale, int n, int log2n, int seg,
+                                                             float *__restrict__ out) {
     constexpr int R = (ORDER == 2) ? 1 : (ORDER == 3 ? 1 : (ORDER == 5 ? 2 : 3));
     // a workgroup owns a patch of 8 rows x 32 float4 (128 k-cells), so most y/z neighbours are
     // its own threads' loads (L1 hits) rather than lines another XCD's L2 has to fetch again
@@ -339,44 +340,54 @@ __global__ __launch_bounds__(BLK) void gradient_march_kernel(const float *__rest
     const int patch = (int)(blockIdx.x % (pk * pj));
     const int i0 = (int)(blockIdx.x / (pk * pj)) * seg;
     const int kq = (patch % pk) * 32 + (threadIdx.x & 31), j = (patch / pk) * 8 + (threadIdx.x >> 5), k0 = kq << 2;
-    auto ld = [&](int ii, int jj, int kk) -> float4 {
-        return *reinterpret_cast<const float4 *>(phi + ((((int64_t)(ii & mask) << log2n) + (jj & mask)) << log2n) +
-                                                 (kk & mask));
+    auto ld = [&](const float *g, int ii, int jj, int kk) -> float4 {
+        return *reinterpret_cast<const float4 *>(g + ((((int64_t)(ii & mask) << log2n) + (jj & mask)) << log2n) + (kk & mask));
     };
-    float4 w[2 * R + 1];
+    auto put = [](float *d, float4 v) { d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w; };
+    float4 w[2 * R + 1], wu[FRN > 0 ? 2 * R + 1 : 1];
 #pragma unroll
-    for (int o = 0; o < 2 * R; ++o) w[o + 1] = ld(i0 - R + o, j, k0);  // planes i0-R .. i0+R-1 (slot 0 filled below)
+    for (int o = 0; o < 2 * R; ++o) {  // planes i0-R .. i0+R-1 (slot 0 filled below)
+        w[o + 1] = ld(phi, i0 - R + o, j, k0);
+        if (FRN > 0) wu[o + 1] = ld(u, i0 - R + o, j, k0);
+    }
 #pragma unroll 1
     for (int i = i0; i < i0 + seg; ++i) {
 #pragma unroll
-        for (int o = 0; o < 2 * R; ++o) w[o] = w[o + 1];
-        w[2 * R] = ld(i + R, j, k0);
+        for (int o = 0; o < 2 * R; ++o) {
+            w[o] = w[o + 1];
+            if (FRN > 0) wu[o] = wu[o + 1];
+        }
+        w[2 * R] = ld(phi, i + R, j, k0);
+        if (FRN > 0) wu[2 * R] = ld(u, i + R, j, k0);
         float ax[7][4], ay[7][4], az[12];
+        float bx[7][4], by[7][4], bz[12];
 #pragma unroll
         for (int o = -R; o <= R; ++o) {
-            const float4 vx = w[o + R];
-            ax[o + 3][0] = vx.x, ax[o + 3][1] = vx.y, ax[o + 3][2] = vx.z, ax[o + 3][3] = vx.w;
+            put(ax[o + 3], w[o + R]);
+            if (FRN > 0) put(bx[o + 3], wu[o + R]);
             if (ORDER == 2 && o < 0) continue;
-            const float4 vy = (o == 0) ? w[R] : ld(i, j + o, k0);
-            ay[o + 3][0] = vy.x, ay[o + 3][1] = vy.y, ay[o + 3][2] = vy.z, ay[o + 3][3] = vy.w;
+            put(ay[o + 3], (o == 0) ? w[R] : ld(phi, i, j + o, k0));
+            if (FRN > 0) put(by[o + 3], (o == 0) ? wu[R] : ld(u, i, j + o, k0));
         }
-        const float4 zl = ld(i, j, k0 - 4), zr = ld(i, j, k0 + 4);
-        az[0] = zl.x, az[1] = zl.y, az[2] = zl.z, az[3] = zl.w;
+        put(az, ld(phi, i, j, k0 - 4)), put(az + 8, ld(phi, i, j, k0 + 4));
         az[4] = ax[3][0], az[5] = ax[3][1], az[6] = ax[3][2], az[7] = ax[3][3];
-        az[8] = zr.x, az[9] = zr.y, az[10] = zr.z, az[11] = zr.w;
+        if (FRN > 0) {
+            put(bz, ld(u, i, j, k0 - 4)), put(bz + 8, ld(u, i, j, k0 + 4));
+            bz[4] = bx[3][0], bz[5] = bx[3][1], bz[6] = bx[3][2], bz[7] = bx[3][3];
+        }
         float res[12];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float sa[7], sb[7];
 #pragma unroll
-            for (int o = 0; o < 7; ++o) sa[o] = ax[o][c], sb[o] = 0.f;
-            res[3 * c + 0] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+            for (int o = 0; o < 7; ++o) sa[o] = ax[o][c], sb[o] = (FRN > 0) ? bx[o][c] : 0.f;
+            res[3 * c + 0] = Stencil<ORDER, FRN>::eval(sa, sb, f, scale);
 #pragma unroll
-            for (int o = 0; o < 7; ++o) sa[o] = ay[o][c];
-            res[3 * c + 1] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+            for (int o = 0; o < 7; ++o) sa[o] = ay[o][c], sb[o] = (FRN > 0) ? by[o][c] : 0.f;
+            res[3 * c + 1] = Stencil<ORDER, FRN>::eval(sa, sb, f, scale);
 #pragma unroll
-            for (int o = 0; o < 7; ++o) sa[o] = az[4 + c + o - 3];
-            res[3 * c + 2] = Stencil<ORDER, 0>::eval(sa, sb, 0.f, scale);
+            for (int o = 0; o < 7; ++o) sa[o] = az[4 + c + o - 3], sb[o] = (FRN > 0) ? bz[4 + c + o - 3] : 0.f;
+            res[3 * c + 2] = Stencil<ORDER, FRN>::eval(sa, sb, f, scale);
         }
         float4 *o4 = reinterpret_cast<float4 *>(out + 3 * (((((int64_t)i << log2n) + j) << log2n) + k0));
         o4[0] = make_float4(res[0], res[1], res[2], res[3]);
@@ -385,11 +396,11 @@ __global__ __launch_bounds__(BLK) void gradient_march_kernel(const float *__rest
     }
 }
 
-template <int ORDER>
-static int gradient_march_launch(pm_ctx *c, float scale, const float *phi, float *out) {
+template <int ORDER, int FRN = 0>
+static int gradient_march_launch(pm_ctx *c, float scale, const float *phi, float *out, const float *u = nullptr, float f = 0.f) {
     const int n = c->n, seg = 32;
     const int64_t blocks = (int64_t)((n >> 2) >> 5) * (n >> 3) * (n / seg);
-    hipLaunchKernelGGL((gradient_march_kernel<ORDER>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, phi, scale, n,
+    hipLaunchKernelGGL((gradient_march_kernel<ORDER, FRN>), dim3((unsigned)blocks), dim3(BLK), 0, c->stream, phi, u, f, scale, n,
                        c->log2n, seg, out);
     PM_LAUNCH_CHECK();
     return PM_OK;
@@ -475,10 +486,30 @@ extern "C" int pm_gradient_fr(pm_ctx *c, int order, int fr_n, float f, const flo
     PM_REQUIRE(c && d_phi && d_u && d_force, "NULL argument");
     PM_REQUIRE(pm_aligned16(d_phi) && pm_aligned16(d_u) && pm_aligned16(d_force), "grids must be 16-byte aligned");
     PM_REQUIRE(c->n >= 8, "gradient kernels need n >= 8");
+    if (c->n >= 128 && c->fr_march_gradient && (fr_n == 1 || fr_n == 2)) {  // marching form, as pm_gradient (same bits)
+        const int n = c->n;
+#define PM_FR_MARCH(O, SC)                                                                  \
+    return fr_n == 1 ? gradient_march_launch<O, 1>(c, (float)(SC), d_phi, d_force, d_u, f) \
+                     : gradient_march_launch<O, 2>(c, (float)(SC), d_phi, d_force, d_u, f)
+        switch (order) {
+            case 2: PM_FR_MARCH(2, n);
+            case 3: PM_FR_MARCH(3, 0.5 * n);
+            case 5: PM_FR_MARCH(5, n / 12.0);
+            case 7: PM_FR_MARCH(7, n / 60.0);
+        }
+#undef PM_FR_MARCH
+    }
     if (fr_n == 1) return gradient_dispatch<1>(c, order, f, d_phi, d_u, d_force, c->n, 0, c->n, 0);
     if (fr_n == 2) return gradient_dispatch<2>(c, order, f, d_phi, d_u, d_force, c->n, 0, c->n, 0);
     pm_set_error("Only f(R) with n = 1 and 2, currently fR_n=%d", fr_n);
     return PM_ENOSUP;
+}
+
+// off: pm_gradient_fr always takes the row kernel (tests compare the two)
+extern "C" int pm_set_fr_march_gradient(pm_ctx *c, int on) {
+    PM_REQUIRE(c, "NULL argument");
+    c->fr_march_gradient = on ? 1 : 0;
+    return PM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

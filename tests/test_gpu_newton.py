@@ -342,11 +342,25 @@ def test_fused_kick_drift_wrap_deposit_khalo(amd, n, sorted_stream):
 
 @pytest.mark.parametrize("n", [64, 128])
 def test_gradient_marching_kernel_bit_exact(amd, n):
-    """n >= 128 takes the marching (2.5-D) gradient kernel: same bits as the oracle for every order."""
+    """n >= 128 takes the marching (2.5-D) gradient kernel: same bits as the oracle for every order -- the plain
+    gradient and the f(R) force grad(phi) + f grad(u^(n+1)) (mesh.derivative_fR), the latter also against its row
+    kernel (pm_set_fr_march_gradient)."""
+    from pysco_amd import _lib as L
+
     rng = np.random.default_rng(n)
     a = rng.normal(size=(n, n, n)).astype(np.float32)
+    b = (1e-3 * (1 + 0.2 * rng.normal(size=(n, n, n)))).astype(np.float32)
+    f = np.float32(3.7e2)
     for order in (2, 3, 5, 7):
         np.testing.assert_array_equal(amd.mesh.derivative(a, order), orc.derivative(a, order))
+        for frn in (1, 2):
+            got = amd.mesh.derivative_fR(a, b, f, frn, order)
+            np.testing.assert_array_equal(got, orc.derivative_fR(a, b, f, frn, order))
+            L.context(n).call("pm_set_fr_march_gradient", 0)
+            try:
+                np.testing.assert_array_equal(got, amd.mesh.derivative_fR(a, b, f, frn, order))
+            finally:
+                L.context(n).call("pm_set_fr_march_gradient", 1)
 
 
 @pytest.mark.parametrize("n", [16, 32])
