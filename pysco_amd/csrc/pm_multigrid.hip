@@ -1233,6 +1233,92 @@ __global__ __launch_bounds__(BLK) void cubic_operator_kernel(const float *__rest
     if (MODE == 2) block_sum_to(acc, result);
 }
 
+// The same from 512^3, marching (lap_residual_error_march_kernel's scheme: 16 x 128 patch, RM_LX planes, x loaded once per
+// plane, j +- 1 and k +- 1 through a double-buffered LDS plane): the cell-per-thread kernel above asks the L2 for seven
+// scalars of x per cell.  Same expression per cell, in the same order.
+template <int MODE, int FRN>
+__global__ __launch_bounds__(BLK) void cubic_operator_march_kernel(const float *__restrict__ x, const float *__restrict__ b,
+                                                                   float qh2, const float *__restrict__ rhs, int log2n,
+                                                                   float h2, float invsix, float *__restrict__ out,
+                                                                   double *__restrict__ result, XRange xr) {
+    __shared__ __attribute__((aligned(16))) float sh[2][RM_TJ + 2][RM_TK + 8];
+    const int n = 1 << log2n, m = n - 1, tid = threadIdx.x;
+    const int ncol_k = n / RM_TK, ncol_j = n / RM_TJ;
+    const int col = blockIdx.x % (ncol_k * ncol_j), seg = blockIdx.x / (ncol_k * ncol_j);
+    const int kb = (col % ncol_k) * RM_TK, j0 = (col / ncol_k) * RM_TJ;
+    const int jj = tid >> 4, kq = tid & 15, j = j0 + jj, k0 = kb + 8 * kq;
+    const int ia = xr.i0 + seg * RM_LX, ie = min(ia + RM_LX, xr.i0 + xr.ni);
+    auto row = [&](const float *g, int a, int bb) -> const float * {
+        return g + ((((int64_t)(a & xr.xmask) << log2n) + (bb & m)) << log2n);
+    };
+    auto ld8 = [&](const float *p, float *d) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(p), q1 = *reinterpret_cast<const float4 *>(p + 4);
+        d[0] = q0.x, d[1] = q0.y, d[2] = q0.z, d[3] = q0.w, d[4] = q1.x, d[5] = q1.y, d[6] = q1.z, d[7] = q1.w;
+    };
+    const bool edge_j = jj == 0 || jj == RM_TJ - 1, edge_k = kq == 0 || kq == 15;
+    const int jrow = jj == 0 ? j0 - 1 : j0 + RM_TJ, lrow = jj == 0 ? 0 : RM_TJ + 1;
+    const int kcell = kq == 0 ? kb - 1 : kb + RM_TK, lcell = kq == 0 ? 3 : 4 + RM_TK;
+    float prev[8], cur[8], next[8], erow[8], bb8[8], rr8[8], ecell = 0.f;
+    double acc = 0;
+    if (ia < ie) {
+        ld8(row(x, ia - 1, j) + k0, prev);
+        ld8(row(x, ia, j) + k0, cur);
+    }
+    for (int i = ia; i < ie; ++i) {
+        float *pl = &sh[i & 1][0][0];
+        constexpr int RS = RM_TK + 8;
+        ld8(row(x, i + 1, j) + k0, next);
+        ld8(row(b, i, j) + k0, bb8);
+        if (MODE == 1) ld8(rhs + cidx(i, j, k0, log2n), rr8);
+        if (edge_j) ld8(row(x, i, jrow) + k0, erow);
+        if (edge_k) ecell = row(x, i, j)[kcell & m];
+        *reinterpret_cast<float4 *>(pl + (jj + 1) * RS + 4 + 8 * kq) = make_float4(cur[0], cur[1], cur[2], cur[3]);
+        *reinterpret_cast<float4 *>(pl + (jj + 1) * RS + 8 + 8 * kq) = make_float4(cur[4], cur[5], cur[6], cur[7]);
+        if (edge_j) {
+            *reinterpret_cast<float4 *>(pl + lrow * RS + 4 + 8 * kq) = make_float4(erow[0], erow[1], erow[2], erow[3]);
+            *reinterpret_cast<float4 *>(pl + lrow * RS + 8 + 8 * kq) = make_float4(erow[4], erow[5], erow[6], erow[7]);
+        }
+        if (edge_k) pl[(jj + 1) * RS + lcell] = ecell;
+        __syncthreads();
+        const float *me = pl + (jj + 1) * RS + 4 + 8 * kq, *ym = me - RS, *yp = me + RS;
+        const float4 a0 = *reinterpret_cast<const float4 *>(ym), a1 = *reinterpret_cast<const float4 *>(ym + 4);
+        const float4 c0 = *reinterpret_cast<const float4 *>(yp), c1 = *reinterpret_cast<const float4 *>(yp + 4);
+        const float aym[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float ayp[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        float v[10], res[8];
+        v[0] = me[-1], v[9] = me[8];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) v[c2 + 1] = cur[c2];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+            const float xt = v[c2 + 1];
+            const float p = h2 * bb8[c2] - invsix * (fr_pw<FRN>(prev[c2]) + fr_pw<FRN>(aym[c2]) + fr_pw<FRN>(v[c2]) +
+                                                     fr_pw<FRN>(v[c2 + 2]) + fr_pw<FRN>(ayp[c2]) + fr_pw<FRN>(next[c2]));
+            if (MODE == 0) res[c2] = fr_lead<FRN>(xt) + p * xt + qh2;
+            if (MODE == 1) res[c2] = -(fr_lead<FRN>(xt)) - p * xt - qh2 + rr8[c2];
+            if (MODE == 2) {
+                const float r = fr_lead<FRN>(xt) + p * xt + qh2;
+                acc += (double)(r * r);
+            }
+        }
+        if (MODE != 2) {
+            float4 *o4 = reinterpret_cast<float4 *>(out + cidx(i, j, k0, log2n));
+            o4[0] = make_float4(res[0], res[1], res[2], res[3]);
+            o4[1] = make_float4(res[4], res[5], res[6], res[7]);
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) prev[c2] = cur[c2], cur[c2] = next[c2];
+    }
+    if (MODE == 2) block_sum_to(acc, result);
+}
+
+static bool fr_march_applies(const pm_ctx *c, int n, const float *x, const float *b, const float *o1, const float *o2) {
+    return n >= 512 && c->fr_rows_sweep && pm_aligned16(x) && pm_aligned16(b) && pm_aligned16(o1) && pm_aligned16(o2);
+}
+static unsigned fr_march_blocks(int n, XRange xr) {
+    return (unsigned)((n / RM_TJ) * (n / RM_TK) * ((xr.ni + RM_LX - 1) / RM_LX));
+}
+
 template <int FRN>
 static int fr_operator(pm_ctx *c, const float *d_x, const float *d_b, float q, const float *d_rhs, int n, float *d_out,
                        XRange xr) {
@@ -1241,6 +1327,16 @@ static int fr_operator(pm_ctx *c, const float *d_x, const float *d_b, float q, c
     const int64_t total = (int64_t)xr.ni * n * n;
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
     const int blocks = pm_stream_blocks(total, BLK);
+    if (fr_march_applies(c, n, d_x, d_b, d_rhs, d_out)) {
+        if (d_rhs)
+            hipLaunchKernelGGL((cubic_operator_march_kernel<1, FRN>), dim3(fr_march_blocks(n, xr)), dim3(BLK), 0, c->stream, d_x,
+                               d_b, q * h2, d_rhs, ilog2(n), h2, invsix, d_out, (double *)nullptr, xr);
+        else
+            hipLaunchKernelGGL((cubic_operator_march_kernel<0, FRN>), dim3(fr_march_blocks(n, xr)), dim3(BLK), 0, c->stream, d_x,
+                               d_b, q * h2, d_rhs, ilog2(n), h2, invsix, d_out, (double *)nullptr, xr);
+        PM_LAUNCH_CHECK();
+        return PM_OK;
+    }
     if (d_rhs)
         hipLaunchKernelGGL((cubic_operator_kernel<1, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, q * h2,
                            d_rhs, ilog2(n), h2, invsix, d_out, (double *)nullptr, xr);
@@ -1258,8 +1354,12 @@ static int fr_residual_sumsq(pm_ctx *c, const float *d_x, const float *d_b, floa
     PM_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(double), c->stream));
     const int64_t total = (int64_t)xr.ni * n * n;
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
-    hipLaunchKernelGGL((cubic_operator_kernel<2, FRN>), dim3(pm_stream_blocks(total, BLK * 4)), dim3(BLK), 0, c->stream,
-                       d_x, d_b, q * h2, (const float *)nullptr, ilog2(n), h2, invsix, (float *)nullptr, c->d_hist, xr);
+    if (fr_march_applies(c, n, d_x, d_b, nullptr, nullptr))
+        hipLaunchKernelGGL((cubic_operator_march_kernel<2, FRN>), dim3(fr_march_blocks(n, xr)), dim3(BLK), 0, c->stream, d_x,
+                           d_b, q * h2, (const float *)nullptr, ilog2(n), h2, invsix, (float *)nullptr, c->d_hist, xr);
+    else
+        hipLaunchKernelGGL((cubic_operator_kernel<2, FRN>), dim3(pm_stream_blocks(total, BLK * 4)), dim3(BLK), 0, c->stream,
+                           d_x, d_b, q * h2, (const float *)nullptr, ilog2(n), h2, invsix, (float *)nullptr, c->d_hist, xr);
     PM_LAUNCH_CHECK();
     if (int rb_rc = pm_read_back(c, h_sum, c->d_hist, sizeof(double))) return rb_rc;
     return PM_OK;

@@ -287,6 +287,57 @@ def test_native_vcycle_is_the_python_recursion(amd, n):
     assert np.isfinite(out[True]).all()
 
 
+@pytest.mark.parametrize("slab,frn", [(False, 1), (True, 1), (False, 2)])
+def test_marching_fr_operator_is_the_cell_kernels(amd, slab, frn):
+    """cubic / quartic operator, residual with right-hand side and residual norm (cubic.py:23-158, 844-900) at 512^3: the
+    marching kernel against the cell-per-thread one (pm_set_fr_rows_sweep 0) -- grids bit for bit, the fp64 sum of the
+    norm to rounding; on a cube and on a slab level array with ghost planes (40 planes: a short second segment)."""
+    import ctypes as C
+
+    from pysco_amd import _lib as L
+
+    t = amd.torch
+    n, nx = 512, 40
+    g = t.Generator(device="cuda")
+    g.manual_seed(7 + frn)
+    shape = (nx + 2, n, n) if slab else (n, n, n)
+    x = 1e-2 * (1 + 0.3 * t.rand(shape, generator=g, device="cuda"))
+    b = t.rand(shape, generator=g, device="cuda") - 0.5
+    rhs = t.rand(shape, generator=g, device="cuda")
+    q = -0.0123
+    ctx = L.context(4)
+    got = {}
+    for march in (1, 0):
+        ctx.call("pm_set_fr_rows_sweep", march)
+        try:
+            outs = []
+            for r in (None, rhs):
+                o = t.full(shape, float("nan"), device="cuda")
+                if slab:
+                    ctx.call("pm_fr_operator_slab", frn, L.ptr(x), L.ptr(b), q, L.ptr(r) if r is not None else None, n, nx, L.ptr(o))
+                    o = o[1:-1]
+                else:
+                    ctx.call("pm_cubic_operator" if frn == 1 else "pm_quartic_operator", L.ptr(x), L.ptr(b), q,
+                             L.ptr(r) if r is not None else None, n, L.ptr(o))
+                outs.append(o.clone())
+            if slab:
+                sq = C.c_double(0)
+                ctx.call("pm_fr_residual_sumsq_slab", frn, L.ptr(x), L.ptr(b), q, n, nx, C.byref(sq))
+                norm2 = sq.value
+            else:
+                e = C.c_float(0)
+                ctx.call("pm_cubic_residual_error" if frn == 1 else "pm_quartic_residual_error", L.ptr(x), L.ptr(b), q, n, C.byref(e))
+                norm2 = float(e.value) ** 2
+            got[march] = (outs, norm2)
+        finally:
+            ctx.call("pm_set_fr_rows_sweep", 1)
+    for a, c in zip(got[1][0], got[0][0]):
+        assert bool(t.isfinite(a).all()) and t.equal(a, c)
+    assert abs(got[1][1] - got[0][1]) <= (1e-12 if slab else 3e-7) * got[0][1]
+    # the norm is the norm of the operator's output
+    assert abs(got[1][1] - float((got[1][0][0].double() ** 2).sum())) <= 1e-6 * got[1][1]
+
+
 @pytest.mark.parametrize("slab", [False, True])
 def test_marching_residual_norm_is_the_row_kernels(amd, slab):
     """laplacian.residual_error at 512^3 (the convergence test after every V-cycle): the marching kernel (a plane of x
