@@ -420,18 +420,18 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
             const int tj2 = jf ? tjn : tj, lj2 = jf ? ljn : rl + 1;
             kraw[u][0] = at(ti, tj, xi + 1, rl + 1);
             kraw[u][1] = at(ti, tj2, xi + 1, lj2);
-            if (IFACE) kraw[u][2] = at(tin, tj, lin, rl + 1), kraw[u][3] = at(tin, tj2, lin, lj2);
+            if constexpr (IFACE) kraw[u][2] = at(tin, tj, lin, rl + 1), kraw[u][3] = at(tin, tj2, lin, lj2);
         }
         // j-halo rows for lines 0 and 15 (+ the edge rows on an i face): one quad per thread (2 n / 4 <= FBLK)
         const int jt = min((int)threadIdx.x, 2 * nq - 1), jw = jt / nq, jq = jt - jw * nq;
         const int tjx = jw ? (tj + 1) % kT : (tj + kT - 1) % kT;
         fft_v4f jv = *reinterpret_cast<const fft_v4f *>(hj + ((((int64_t)ti * kT + tjx) * 2 + (jw ? 0 : 1)) * 8 + xi) * n + 4 * jq);
         fft_v4f ev = {0.f, 0.f, 0.f, 0.f};
-        if (IFACE)
+        if constexpr (IFACE)
             ev = *reinterpret_cast<const fft_v4f *>(hi + ((((int64_t)tin * kT + tjx) * 2 + iside) * 18 + (jw ? 0 : 17)) * n + 4 * jq);
         // the neighbouring column's i-halo plane, one row per line: fetched here too (8 quads per thread)
         fft_v4f iv[IFACE ? 8 : 1];
-        if (IFACE) {
+        if constexpr (IFACE) {
             const float *src = hi + (((int64_t)tin * kT + tj) * 2 + iside) * 18 * n + n;  // row lj = 1
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
                 const int rl = idx & 15, sm = idx >> 4, side = sm >= kT, m = sm - (side ? kT : 0);
                 const bool jf = rl == 0 || rl == 15;
                 float sum = kraw[u][0] + (jf ? kraw[u][1] : 0.f);
-                if (IFACE) sum = (sum + kraw[u][2]) + (jf ? kraw[u][3] : 0.f);
+                if constexpr (IFACE) sum = (sum + kraw[u][2]) + (jf ? kraw[u][3] : 0.f);
                 float *dst = reinterpret_cast<float *>(buf + (rl >> 1) * NP(n) + PADI(side ? 16 * m : 16 * m + 15)) + (rl & 1);
                 *dst += sum;
             }
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(FBLK) void fftp_z_r2c(const float *__restrict__ rho
         };
         if ((int)threadIdx.x < 2 * nq) add4(jw ? 15 : 0, 4 * jq, IFACE ? jv + ev : jv);
         __syncthreads();
-        if (IFACE) {
+        if constexpr (IFACE) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int t = threadIdx.x + u * FBLK;
