@@ -218,8 +218,14 @@ __global__ __launch_bounds__(BLK) void lap_operator_kernel(const float *__restri
     }
 }
 
+static bool lap_operator_march(pm_ctx *c, const float *d_x, const float *d_b, int n, int mode, float *d_out, XRange xr);
+
 static int lap_operator_launch(pm_ctx *c, const float *d_x, const float *d_b, int n, int mode, float *d_out, XRange xr) {
     const int64_t total = (int64_t)xr.ni * n * n;
+    if (lap_operator_march(c, d_x, d_b, n, mode, d_out, xr)) {  // (from 512^3: see lap_residual_error_march_kernel)
+        PM_LAUNCH_CHECK();
+        return PM_OK;
+    }
     hipLaunchKernelGGL(lap_operator_kernel, dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_x, d_b,
                        ilog2(n), mode, (float)((double)n * n), d_out, xr);
     PM_LAUNCH_CHECK();
@@ -490,6 +496,80 @@ __global__ __launch_bounds__(BLK) void lap_residual_error_march_kernel(const flo
         for (int c2 = 0; c2 < 8; ++c2) prev[c2] = cur[c2], cur[c2] = next[c2];
     }
     block_sum_to(acc, result);
+}
+
+// laplacian.operator / residual (lap_operator_kernel) through the same march: same expression per cell
+template <int MODE>
+__global__ __launch_bounds__(BLK) void lap_operator_march_kernel(const float *__restrict__ x, const float *__restrict__ b,
+                                                                 int log2n, float invh2, float *__restrict__ out, XRange xr) {
+    __shared__ __attribute__((aligned(16))) float sh[2][RM_TJ + 2][RM_TK + 8];
+    const int n = 1 << log2n, m = n - 1, tid = threadIdx.x;
+    const int ncol_k = n / RM_TK, ncol_j = n / RM_TJ;
+    const int col = blockIdx.x % (ncol_k * ncol_j), seg = blockIdx.x / (ncol_k * ncol_j);
+    const int kb = (col % ncol_k) * RM_TK, j0 = (col / ncol_k) * RM_TJ;
+    const int jj = tid >> 4, kq = tid & 15, j = j0 + jj, k0 = kb + 8 * kq;
+    const int ia = xr.i0 + seg * RM_LX, ie = min(ia + RM_LX, xr.i0 + xr.ni);
+    auto row = [&](const float *g, int a, int bb) -> const float * {
+        return g + ((((int64_t)(a & xr.xmask) << log2n) + (bb & m)) << log2n);
+    };
+    auto ld8 = [&](const float *p, float *d) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(p), q1 = *reinterpret_cast<const float4 *>(p + 4);
+        d[0] = q0.x, d[1] = q0.y, d[2] = q0.z, d[3] = q0.w, d[4] = q1.x, d[5] = q1.y, d[6] = q1.z, d[7] = q1.w;
+    };
+    const bool edge_j = jj == 0 || jj == RM_TJ - 1, edge_k = kq == 0 || kq == 15;
+    const int jrow = jj == 0 ? j0 - 1 : j0 + RM_TJ, lrow = jj == 0 ? 0 : RM_TJ + 1;
+    const int kcell = kq == 0 ? kb - 1 : kb + RM_TK, lcell = kq == 0 ? 3 : 4 + RM_TK;
+    float prev[8], cur[8], next[8], erow[8], bb8[8], ecell = 0.f;
+    if (ia < ie) {
+        ld8(row(x, ia - 1, j) + k0, prev);
+        ld8(row(x, ia, j) + k0, cur);
+    }
+    for (int i = ia; i < ie; ++i) {
+        float *pl = &sh[i & 1][0][0];
+        constexpr int RS = RM_TK + 8;
+        ld8(row(x, i + 1, j) + k0, next);
+        if (MODE) ld8(b + cidx(i, j, k0, log2n), bb8);
+        if (edge_j) ld8(row(x, i, jrow) + k0, erow);
+        if (edge_k) ecell = row(x, i, j)[kcell & m];
+        *reinterpret_cast<float4 *>(pl + (jj + 1) * RS + 4 + 8 * kq) = make_float4(cur[0], cur[1], cur[2], cur[3]);
+        *reinterpret_cast<float4 *>(pl + (jj + 1) * RS + 8 + 8 * kq) = make_float4(cur[4], cur[5], cur[6], cur[7]);
+        if (edge_j) {
+            *reinterpret_cast<float4 *>(pl + lrow * RS + 4 + 8 * kq) = make_float4(erow[0], erow[1], erow[2], erow[3]);
+            *reinterpret_cast<float4 *>(pl + lrow * RS + 8 + 8 * kq) = make_float4(erow[4], erow[5], erow[6], erow[7]);
+        }
+        if (edge_k) pl[(jj + 1) * RS + lcell] = ecell;
+        __syncthreads();
+        const float *me = pl + (jj + 1) * RS + 4 + 8 * kq, *ym = me - RS, *yp = me + RS;
+        const float4 a0 = *reinterpret_cast<const float4 *>(ym), a1 = *reinterpret_cast<const float4 *>(ym + 4);
+        const float4 c0 = *reinterpret_cast<const float4 *>(yp), c1 = *reinterpret_cast<const float4 *>(yp + 4);
+        const float aym[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float ayp[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        float v[10], res[8];
+        v[0] = me[-1], v[9] = me[8];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) v[c2 + 1] = cur[c2];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+            const float s = prev[c2] + aym[c2] + v[c2] - 6.0f * v[c2 + 1] + v[c2 + 2] + ayp[c2] + next[c2];
+            res[c2] = MODE ? (-(s)*invh2 + bb8[c2]) : s * invh2;
+        }
+        float4 *o4 = reinterpret_cast<float4 *>(out + cidx(i, j, k0, log2n));
+        o4[0] = make_float4(res[0], res[1], res[2], res[3]);
+        o4[1] = make_float4(res[4], res[5], res[6], res[7]);
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) prev[c2] = cur[c2], cur[c2] = next[c2];
+    }
+}
+
+static bool lap_operator_march(pm_ctx *c, const float *d_x, const float *d_b, int n, int mode, float *d_out, XRange xr) {
+    if (!(n >= 512 && c->mg_fused_sweep && pm_aligned16(d_x) && pm_aligned16(d_b) && pm_aligned16(d_out))) return false;
+    const unsigned blocks = (unsigned)((n / RM_TJ) * (n / RM_TK) * ((xr.ni + RM_LX - 1) / RM_LX));
+    const float invh2 = (float)((double)n * n);
+    if (mode)
+        hipLaunchKernelGGL(lap_operator_march_kernel<1>, dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), invh2, d_out, xr);
+    else
+        hipLaunchKernelGGL(lap_operator_march_kernel<0>, dim3(blocks), dim3(BLK), 0, c->stream, d_x, d_b, ilog2(n), invh2, d_out, xr);
+    return true;
 }
 
 static int lap_residual_sumsq(pm_ctx *c, const float *d_x, const float *d_b, int n, XRange xr, double *h_sum) {

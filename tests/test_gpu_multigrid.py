@@ -339,6 +339,40 @@ def test_marching_fr_operator_is_the_cell_kernels(amd, slab, frn):
 
 
 @pytest.mark.parametrize("slab", [False, True])
+def test_marching_laplacian_operator_is_the_cell_kernel(amd, slab):
+    """laplacian.operator and residual (laplacian.py:15-122) at 512^3 through the marching kernel against the
+    cell-per-thread one, bit for bit; cube and slab level array (40 planes, ghosts either side)."""
+    from pysco_amd import _lib as L
+
+    t = amd.torch
+    n, nx = 512, 40
+    g = t.Generator(device="cuda")
+    g.manual_seed(11)
+    shape = (nx + 2, n, n) if slab else (n, n, n)
+    x = t.rand(shape, generator=g, device="cuda")
+    b = t.rand(shape, generator=g, device="cuda")
+    ctx = L.context(4)
+    got = {}
+    for march in (1, 0):
+        ctx.call("pm_set_fused_sweep", march)
+        try:
+            outs = []
+            for mode in (0, 1):
+                o = t.full(shape, float("nan"), device="cuda")
+                if slab:
+                    ctx.call("pm_lap_operator_slab", L.ptr(x), L.ptr(b), n, nx, mode, L.ptr(o))
+                    o = o[1:-1]
+                else:
+                    ctx.call("pm_lap_operator", L.ptr(x), L.ptr(b) if mode else None, n, mode, L.ptr(o))
+                outs.append(o.clone())
+            got[march] = outs
+        finally:
+            ctx.call("pm_set_fused_sweep", 1)
+    for a, c in zip(got[1], got[0]):
+        assert bool(t.isfinite(a).all()) and t.equal(a, c)
+
+
+@pytest.mark.parametrize("slab", [False, True])
 def test_marching_residual_norm_is_the_row_kernels(amd, slab):
     """laplacian.residual_error at 512^3 (the convergence test after every V-cycle): the marching kernel (a plane of x
     loaded once, neighbours through registers and LDS) against the row kernel it replaces there -- the same per-cell
