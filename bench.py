@@ -147,8 +147,23 @@ def alg_bytes_level(stage):
                 "pm_prolongation": 8.0 * 8 + 4.0,  # (size = the coarse grid's: 8 fine cells read + written, 1 coarse read)
                 # one V-cycle: (Npre + Npost) sweeps of 12 B + restricted residual 16 B + prolongation 12 B per cell,
                 # summed over the levels (x 8/7), Npre + Npost = 3
-                "pm_lap_vcycle": (3 * 12.0 + 16.0 + 12.0) * 8.0 / 7.0}.get(name)
+                "pm_lap_vcycle": (3 * 12.0 + 16.0 + 12.0) * 8.0 / 7.0,
+                # one FAS V-cycle of the scalaron (multigrid.py:297-376; SURVEY.md section 8d, "73-82 B/cell" per level):
+                # (Npre + Npost) = 3 sweeps of u, b, rhs -> u (16 B), the restriction of u (4.5 B), the coarse right-hand
+                # side L(R u) - R(residual) and the correction u += P(e_c - R u): the upper figure of SURVEY's range,
+                # 82 B/cell on a level, x 8/7 over the levels
+                "pm_fr_vcycle": 82.0 * 8.0 / 7.0}.get(name)
     return None if per_cell is None else per_cell * c
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(cpu_n, budget_s=15.0, config="newton_fft"):
@@ -198,14 +213,30 @@ def cpu_baseline(cpu_n, budget_s=15.0, config="newton_fft"):
         _, pk_cpu, nm = orc.fourier_grid_to_Pk(orc.fft_3D_real(orc.TSC(pos_c, cpu_n)), 3)
     finally:
         orc.use_openmp(False)
+    # the device side runs the very loop the headline times: Morton-sorted stream, prediction + incremental re-sort in
+    # every step (param["rebucket_straggler_fraction"] as pysco_amd.main sets it), the order policy after every step;
+    # int32 tags follow the particles so that the two sides are compared particle by particle
+    from pysco_amd import main as pm_main
+    from pysco_amd import utils as pm_utils
+
     pos_g, vel_g = torch.from_numpy(pos0).cuda(), torch.from_numpy(vel0).cuda()
     par_g, tables = make_param(cpu_n, cpu_n**3, config)
+    order = []
+    pos_g, vel_g = pm_utils.reorder_particles(pos_g, vel_g, _order_out=order)
+    par_g["particle_id"] = torch.arange(cpu_n**3, dtype=torch.int32, device="cuda")[order[0]].contiguous()
+    par_g["rebucket_straggler_fraction"] = pm_main.REBUCKET_FRACTION
     acc_g, phi_g, ex_g = solver.pm(pos_g, par_g, tables=tables)
+    pk_stragglers = []
     for _ in range(K):
+        par_g["nsteps"] += 1
         pos_g, vel_g, acc_g, phi_g, ex_g = integration.integrate(pos_g, vel_g, acc_g, phi_g, ex_g, tables, par_g,
                                                                  np.float32(3e38))
+        pos_g, vel_g, acc_g = pm_main.reorder_policy(pos_g, vel_g, acc_g, par_g)
+        pk_stragglers.append(pm_utils.straggler_fraction(cpu_n)[0])
     _, pk_gpu, _ = fourier.fourier_grid_to_Pk(fourier.fft_3D_real(mesh.TSC(pos_g, cpu_n)), 3)
-    pos_gh = pos_g.cpu().numpy()
+    inv = torch.argsort(par_g["particle_id"].long())
+    pos_gh = pos_g[inv].cpu().numpy()  # (back in the CPU side's order)
+    del inv
     dx = np.abs(pos_gh - pos_c)
     max_dx = float(np.minimum(dx, 1 - dx).max())
     del pos_g, vel_g, acc_g, phi_g, ex_g, dx
@@ -220,10 +251,13 @@ def cpu_baseline(cpu_n, budget_s=15.0, config="newton_fft"):
         threads = orc.num_threads()
     finally:
         orc.use_openmp(False)
-    return {"value": cpu_n**3 * sn / tn, "unit": "particles/s", "cores": threads, "kind": "port",
+    return {"value": cpu_n**3 * sn / tn, "unit": "particles/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "cores_visible": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
             "value_1core": cpu_n**3 * s1 / t1,
             "pk_rel_err": {"value": pk_rel_err, "vs_fp64": pk_rel_err_fp64, "bins": int(ok.sum()), "steps": K,
-                           "max_dx": max_dx,
+                           "max_dx": max_dx, "device_loop": "sorted stream, prediction + re-bucket every step",
+                           "device_stragglers_max": None if not pk_stragglers or pk_stragglers[0] is None
+                           else float(max(pk_stragglers)),
                            "what": f"after {K} leapfrog steps of the {cpu_n}^3 sample on both sides: max over bins of "
                                    "|P_hip - P_cpu| / P_cpu (each side's particles and estimator; TSC, deconvolved, "
                                    "p = 3); vs_fp64: the HIP estimator against a float64 evaluation of the same "
@@ -233,6 +267,108 @@ def cpu_baseline(cpu_n, budget_s=15.0, config="newton_fft"):
                       f"restatement of PySCo's Numba path (oracle/pm_oracle.c): {sn} steps in {tn:.1f} s on {threads} "
                       f"threads (OpenMP, atomic deposit, scipy.fft workers), {s1} steps in {t1:.1f} s on 1 core "
                       "(serial build, numpy.fft)"}
+
+
+def launch_ranks(n):
+    """python bench.py --gpus N without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py
+    <the same arguments>` as a child (one rank per GPU, rendezvous on 127.0.0.1) and return its exit code.  The ranks
+    inherit stdout, so rank 0's JSON line is this command's output."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:  # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+# the short legs the default invocation runs after the headline, each in a child process of its own (a clean device,
+# and a failure there cannot take the headline with it): the other BASELINE.json configs on one GPU and the headline's
+# "clustered" workload (SURVEY.md section 8d: rms displacement 3 cells)
+SECONDARY = [
+    ("newton_fft_512", ["--config", "newton_fft", "--ncells", "512", "--steps", "20", "--warmup", "5"]),   # config 2 (fp32)
+    ("newton_mg_128", ["--config", "newton_mg", "--steps", "20", "--warmup", "5"]),                        # config 1
+    ("fr_512", ["--config", "fr", "--steps", "8", "--warmup", "3"]),                                       # config 4
+    ("mond_512", ["--config", "mond", "--steps", "8", "--warmup", "3"]),                                   # config 5 on one GPU
+    ("newton_fft_1024_clustered", ["--config", "newton_fft", "--rms-cells", "3.0", "--steps", "10", "--warmup", "3"]),
+]
+
+
+def run_secondary(budget_s=420.0):
+    """Runs the SECONDARY legs as children (`bench.py --leg NAME ...`: no CPU baseline, no children of their own) and
+    returns {name: compact result}.  Bounded: a leg that would start after `budget_s` seconds is skipped and says so."""
+    import subprocess
+
+    out, t0 = {}, time.perf_counter()
+    for name, leg_args in SECONDARY:
+        if time.perf_counter() - t0 > budget_s:
+            out[name] = {"skipped": "time budget of the default run spent"}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--leg", name] + leg_args
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out[name] = json.loads(line[-1]) if r.returncode == 0 and line else {
+                "failed": r.returncode, "stderr_tail": r.stderr[-400:]}
+        except subprocess.TimeoutExpired:
+            out[name] = {"failed": "timeout (300 s)"}
+    return out
+
+
+XGMI_PEAK = 7 * 153.0e9  # B/s per GPU and direction: 7 links x 153 GB/s (SURVEY.md section 8d)
+
+
+def comm_report(dist, slab, n, world, steps):
+    """N > 1: what the step's exchanges moved, per rank and step, and what the all-to-all of this rank's share of the
+    half-spectrum achieves on its own -- the collective timed alone, same tensor the slab FFT exchanges per kz chunk --
+    against the xGMI peak of one GPU."""
+    import torch
+
+    cs = dict(slab.comm_stats)
+    nh = n // 2 + 1
+    chunk = torch.zeros((n, (nh + 3) // 4, n // world), dtype=torch.complex64, device="cuda")  # [ky][kz chunk][x local]
+    reps = 5
+    slab.all_to_all(chunk)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        slab.all_to_all(chunk)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = (time.perf_counter() - t0) / reps
+    sent = chunk.numel() * chunk.element_size() * (world - 1) / world
+    tw = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    dt = float(tw.item())
+    for k in cs:
+        slab.comm_stats[k] = cs[k]
+    return {"backend": dist.get_backend(), "alltoall_bytes_per_rank_per_step": cs["a2a_bytes"] / steps,
+            "alltoall_calls_per_step": cs["a2a_calls"] / steps, "ring_bytes_per_rank_per_step": cs["ring_bytes"] / steps,
+            "alltoall_alone": {"bytes_sent_per_rank": sent, "ms": round(dt * 1e3, 4), "GBps_per_rank": round(sent / dt / 1e9, 2),
+                               "xgmi_peak_GBps": XGMI_PEAK / 1e9, "frac_of_xgmi_peak": round(sent / dt / XGMI_PEAK, 4),
+                               "what": "all_to_all_single of one kz chunk of this rank's half-spectrum, timed alone "
+                                       f"({reps} calls, max over ranks)"},
+            "alltoall_ms_per_step_at_that_rate": round(cs["a2a_bytes"] / steps / max(sent / dt, 1.0) * 1e3, 3)}
+
+
+def compact(out):
+    """What a secondary leg reports: step time, throughput, the dominant stage against the roofline, V-cycles,
+    the straggler series in brief."""
+    r = out["roofline"]
+    ss = out.get("straggler_series") or []
+    return {"workload": out["config"]["workload"], "ms_per_step": round(out["ms_per_step"], 4), "value": out["value"],
+            "unit": out["unit"], "steps": out["steps"], "warmup": out["warmup"], "dtype": out["dtype"],
+            "dominant_stage": r["kernel"], "frac": r["frac"], "achieved_GBps": r["achieved"], "step_frac": r["step_frac"],
+            "vcycles_per_step": out["config"].get("vcycles_per_step", {}),
+            "stages": [{k: st[k] for k in ("stage", "calls_per_step", "avg_ms", "alg_GBps")} for st in r["stages"][:5]],
+            "ms_first_last": [out["per_step"][0]["wall_ms"], out["per_step"][-1]["wall_ms"]] if out.get("per_step") else None,
+            "stragglers_first_last_max": [ss[0], ss[-1], max(ss)] if ss else None}
 
 
 def main():
@@ -247,18 +383,23 @@ def main():
     ap.add_argument("--cpu-ncells", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-placement", action="store_true", help="skip pysco_amd.main.tune_placement (development)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline only: skip the short legs of the other BASELINE configs / workloads (profiling runs)")
+    ap.add_argument("--leg", default="", help=argparse.SUPPRESS)  # a secondary leg run as a child: compact line, no children
     ap.add_argument("--rebucket-fraction", type=float, default=None,
                     help="param['rebucket_straggler_fraction'] of the timed loop (default: pysco_amd.main's; "
                          "negative: off, i.e. the reference's in-place step + a full sort every n_reorder steps)")
     args = ap.parse_args()
 
-    import torch
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        # not started by a launcher: start one rank per GPU ourselves -- BEFORE anything touches the GPU (this process
+        # never does) -- and pass rank 0's line and the launcher's exit code on
+        raise SystemExit(launch_ranks(args.gpus))
+
+    import torch
     dev_index = local_rank % max(1, torch.cuda.device_count())  # (== local_rank on a full node)
     torch.cuda.set_device(dev_index)
     dist = None
@@ -330,6 +471,8 @@ def main():
 
     if dist is not None:
         dist.barrier()
+        for k in slab.comm_stats:
+            slab.comm_stats[k] = 0
     torch.cuda.synchronize()
     L.profile_start()
     t0 = time.perf_counter()
@@ -366,6 +509,9 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
 
+    comm = None
+    if dist is not None:
+        comm = comm_report(dist, slab, n, world, args.steps)
     ms_per_step = wall / args.steps * 1e3
     value = npart * args.steps / wall
     assert bool(torch.isfinite(pos).all()) and bool(torch.isfinite(vel).all())
@@ -392,6 +538,12 @@ def main():
                    "pm_kick_drift_wrap_slab": 60.0 * npart / world,
                    "pm_kick_drift_wrap_deposit_slab": 60.0 * npart / world + 4.0 * cells,
                    "pm_kick_drift_wrap_deposit_slab_khalo": 60.0 * npart / world + 4.0 * cells})
+    rank_spread = None
+    if dist is not None:  # every rank's stage table: max / min over ranks of the per-call average
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {k: v[1] / max(1, v[0]) for k, v in stages.items()})
+        rank_spread = {k: [round(min(g.get(k, 0.0) for g in gathered), 4), round(max(g.get(k, 0.0) for g in gathered), 4)]
+                       for k in stages}
     table = []
     for name, (calls, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):
         avg = ms / calls
@@ -461,6 +613,12 @@ def main():
                         "wall_ms": round(step_events[i].elapsed_time(step_events[i + 1]), 3),
                         "ms": {k[3:]: round(v, 3) for k, v in sorted(per_step[i].items(), key=lambda kv: -kv[1])[:3]}}
                        for i in show]
+    if comm is not None:
+        out["comm"] = comm
+        out["stage_ms_min_max_over_ranks"] = rank_spread
+        probe = getattr(slab.get(n), "placement_probe_ms", None)  # (rank 0's; every rank runs its own search)
+        if probe:
+            out["placement_probe_ms"] = probe
     if pm_main.last_placement_probe_ms:  # in-place pass over each candidate particle array [ms], ascending: the first six are in use
         out["placement_probe_ms"] = pm_main.last_placement_probe_ms
     if straggler_frac and straggler_frac[0] is not None:  # every timed step: stragglers found, dt taken, dt guessed for the next
@@ -475,6 +633,20 @@ def main():
         # the P(k) half of the metric as top-level keys (BASELINE.json: "... + P(k) rel-err")
         pk = out["cpu_baseline"]["pk_rel_err"]
         out["pk_rel_err"], out["pk_rel_err_fp64"], out["pk_steps"] = pk["value"], pk["vs_fp64"], pk["steps"]
+    if args.leg:
+        out = compact(out)
+    elif (rank == 0 and world == 1 and not args.no_secondary and args.config == "newton_fft" and not args.ncells
+          and args.rms_cells == 0.5):
+        # the default invocation: everything this process holds on the device goes first, then the other workloads
+        pos = vel = acc = phi = extra = None
+        L._ctxs.clear()
+        from pysco_amd import mesh as _mesh
+
+        for pool in ("_rebucket_pool", "_pool"):
+            if hasattr(_mesh, pool) and hasattr(getattr(_mesh, pool), "clear"):
+                getattr(_mesh, pool).clear()
+        torch.cuda.empty_cache()
+        out["secondary"] = run_secondary()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -123,6 +123,8 @@ constexpr size_t PM_PINNED_BYTES = 16384;
 
 #endif
 
+constexpr int PM_SCRATCH_SINK = 64, PM_SCRATCH_WORDS = 256;
+
 struct pm_ctx {
     int n;          // cells per side
     int log2n;
@@ -146,7 +148,8 @@ struct pm_ctx {
     rocfft_execution_info info_s[4];
     void *work_s[4];
     long long key_s[4];               // batch (2-D) or stride (1-D) the cached plan was built for
-    // small device scratch: [0..63] words for reductions / flags, then 3 tables of n floats
+    // small device scratch: [0..63] words for reductions / flags, [PM_SCRATCH_SINK, +192) the store sink of the
+    // re-bucketing gather (lanes without a particle); then 3 tables of n floats
     unsigned *d_scratch;
     float *d_tab;      // 3*n floats (k2, s, spare)
     double *d_hist;    // 3*n doubles (P(k) bins)

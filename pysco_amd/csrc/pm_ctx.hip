@@ -64,8 +64,8 @@ extern "C" int pm_ctx_create(pm_ctx **out, int n, void *stream) {
     c->tile_x_lo = 0, c->tile_nx = n;
     c->last_stragglers = -1, c->last_np = 0, c->last_complete = 1;
     c->stream = (hipStream_t)stream;
-    PM_HIP(hipMalloc((void **)&c->d_scratch, 64 * sizeof(unsigned)));
-    PM_HIP(hipMemset(c->d_scratch, 0, 64 * sizeof(unsigned)));
+    PM_HIP(hipMalloc((void **)&c->d_scratch, PM_SCRATCH_WORDS * sizeof(unsigned)));
+    PM_HIP(hipMemset(c->d_scratch, 0, PM_SCRATCH_WORDS * sizeof(unsigned)));
     PM_HIP(hipMalloc((void **)&c->d_tab, 3 * (size_t)n * sizeof(float)));
     PM_HIP(hipMalloc((void **)&c->d_hist, 3 * (size_t)n * sizeof(double)));
     PM_HIP(hipEventCreate(&c->ev0));

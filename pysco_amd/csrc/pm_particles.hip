@@ -423,36 +423,44 @@ __device__ __forceinline__ void gather_lds(float xp, float yp, float zp, int i, 
         // v_cndmask per particle, and with the LDS relieved the kernel is VALU-bound: 2 % slower.)
         const unsigned a_xy = lds_offset(txy + (c0 - (PM_HJ + 1) * PM_HK - 1));  // cell (-1, -1, -1)
 #define PM_DS_READ_B64(dst, addr, off) asm("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define PM_DS_READ_B32(dst, addr, off) asm("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+        // One drain per x-plane: the nine z reads are issued behind the nine (x, y) reads and waited for together.  (As C
+        // loads the compiler placed them behind the explicit wait of the (x, y) reads: two LDS round trips per plane.)
+        const unsigned a_z = lds_offset(tz + (c0 - (PM_HJ + 1) * PM_HK - 1));
 #pragma unroll 1
         for (int a = 0; a < 3; ++a) {
             const float wxa = a == 0 ? wx[0] : (a == 1 ? wx[1] : wx[2]);
-            const unsigned pxy = a_xy + (unsigned)a * (PM_HJ * PM_HK * 8);
+            const unsigned pxy = a_xy + (unsigned)a * (PM_HJ * PM_HK * 8), pz = a_z + (unsigned)a * (PM_HJ * PM_HK * 4);
             pm_v2f g[3][3];
+            float gz[3][3];
 #define PM_ROW(b)                                     \
     PM_DS_READ_B64(g[b][0], pxy, (b * PM_HK + 0) * 8); \
     PM_DS_READ_B64(g[b][1], pxy, (b * PM_HK + 1) * 8); \
-    PM_DS_READ_B64(g[b][2], pxy, (b * PM_HK + 2) * 8)
+    PM_DS_READ_B64(g[b][2], pxy, (b * PM_HK + 2) * 8); \
+    PM_DS_READ_B32(gz[b][0], pz, (b * PM_HK + 0) * 4); \
+    PM_DS_READ_B32(gz[b][1], pz, (b * PM_HK + 1) * 4); \
+    PM_DS_READ_B32(gz[b][2], pz, (b * PM_HK + 2) * 4)
             PM_ROW(0);
             PM_ROW(1);
             PM_ROW(2);
 #undef PM_ROW
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[1][2]),
-                           "+v"(g[2][0]), "+v"(g[2][1]), "+v"(g[2][2]));
+                           "+v"(g[2][0]), "+v"(g[2][1]), "+v"(g[2][2]), "+v"(gz[0][0]), "+v"(gz[0][1]), "+v"(gz[0][2]),
+                           "+v"(gz[1][0]), "+v"(gz[1][1]), "+v"(gz[1][2]), "+v"(gz[2][0]), "+v"(gz[2][1]), "+v"(gz[2][2]));
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 const float wxy = wxa * wy[b];
-                const float *zr = tz + c0 + ((a - 1) * PM_HJ + (b - 1)) * PM_HK;
-                const float gz[3] = {zr[-1], zr[0], zr[1]};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float w = wxy * wz[c];
                     axy = axy + pm_v2f{w, w} * g[b][c];
-                    az = az + w * gz[c];
+                    az = az + w * gz[b][c];
                 }
             }
         }
 #undef PM_DS_READ_B64
+#undef PM_DS_READ_B32
     }
     acc[0] = axy.x, acc[1] = axy.y, acc[2] = az;
 }
@@ -810,11 +818,30 @@ static int rebucket_bufs(pm_ctx *c, unsigned ntiles, int64_t np, RbBufs *b) {
     const size_t dbytes = up((size_t)np);
     const size_t need = 2 * t32 + w32 + 3 * t64 + up(tmp) + dbytes;
     if (c->rb_buf_bytes < need) {
-        if (c->rb_buf) PM_HIP(hipFree(c->rb_buf));
-        c->rb_buf = nullptr, c->rb_buf_bytes = 0, c->sorted_pos = nullptr, c->sorted_table = nullptr, c->stay_valid = 0;
+        // Growing (a slab's particle count crept past the headroom): the tile-offset table of the stream the last
+        // gather wrote lives in here and may already be some caller's `work.start` -- so callers size this buffer
+        // BEFORE they take pointers into it (tile_lists_impl, pm_rebucket_prepare, the fused kick, the gather), and
+        // the head of the buffer (everything whose place depends on the tiles only: counts, fill, both tables) moves
+        // across with its contents, so a table on file stays on file.  The per-workgroup histograms and the codes
+        // are recounted by whoever asked for the larger buffer.
         const size_t roomy = need + need / 16;  // (a slab's particle count creeps up and down with the migration)
-        PM_HIP(hipMalloc(&c->rb_buf, roomy));
-        c->rb_buf_bytes = roomy;
+        void *grown = nullptr;
+        PM_HIP(hipMalloc(&grown, roomy));
+        char *old = (char *)c->rb_buf;
+        if (old) {
+            const size_t head = 2 * t32 + 3 * t64;
+            if (c->sorted_table && c->sorted_ntiles == ntiles && c->rb_buf_bytes >= head) {
+                PM_HIP(hipMemcpyAsync(grown, old, head, hipMemcpyDeviceToDevice, c->stream));
+                c->sorted_table = (int64_t *)((char *)grown + ((char *)c->sorted_table - old));
+            } else {
+                c->sorted_pos = nullptr, c->sorted_table = nullptr;
+            }
+            if ((const char *)c->lists_ptr[0] >= old && (const char *)c->lists_ptr[0] < old + c->rb_buf_bytes)
+                c->lists_pos = nullptr;  // prepared ranges that read the old table: void (callers prepare afterwards)
+            PM_HIP(hipStreamSynchronize(c->stream));
+            PM_HIP(hipFree(old));
+        }
+        c->rb_buf = grown, c->rb_buf_bytes = roomy, c->stay_valid = 0;
     }
     // the parts whose size depends on the tiles only come first: the tile-offset tables stay where they are when the
     // particle count changes (a slab's migration), so the table of one step can be read while the next is written
@@ -1091,7 +1118,13 @@ static int tile_lists_impl(pm_ctx *c, const float *d_pos, int64_t np, unsigned c
     if (!d_pos || np == 0 || c->n < 16) return PM_OK;
     TileWork work;
     unsigned blocks = 0;
-    int rc = tile_ranges(c, d_pos, np, &work, &blocks);
+    int rc = 0;
+    RbBufs rb;
+    if (d_codes && np < 4294967296LL) {  // (before any pointer into the buffer is taken: rebucket_bufs may move it)
+        rc = rebucket_bufs(c, (unsigned)(((int64_t)c->n * c->n * c->n) >> (PM_LI + PM_LJ + PM_LK)), np, &rb);
+        if (rc) return rc;
+    }
+    rc = tile_ranges(c, d_pos, np, &work, &blocks);
     if (rc) return rc;
     const unsigned ntiles = work.ntiles;
     c->lists_ptr[0] = work.start, c->lists_ptr[1] = work.xstart, c->lists_ptr[2] = c->lists_ptr[3] = nullptr;
@@ -1103,9 +1136,6 @@ static int tile_lists_impl(pm_ctx *c, const float *d_pos, int64_t np, unsigned c
         if (rc) return rc;
         ScanCount sc{nullptr, nullptr, nullptr};
         if (d_codes) {  // the destination counts of the re-bucketing gather in the same pass (pm_tile_lists_codes)
-            RbBufs rb;
-            rc = rebucket_bufs(c, ntiles, np, &rb);
-            if (rc) return rc;
             PM_HIP(hipMemsetAsync(rb.tile_count, 0, ((size_t)ntiles + 1) * sizeof(unsigned), c->stream));
             sc.codes = d_codes, sc.tile_count = rb.tile_count, sc.wg_hist = rb.wg_hist;
         }
@@ -1664,20 +1694,22 @@ static int kdw_deposit_launch(pm_ctx *c, float *pos, float *vel, const float *ac
     TileWork work;
     unsigned blocks = 0;
     tile_lists_drop(c);
-    int rc = tile_ranges(c, pos, np, &work, &blocks);  // ranges of the positions before the drift
+    // destination counts for the incremental re-sort: single-GPU layout only (a slab's migration renumbers the
+    // particles).  Their buffer is sized before the ranges are looked up: it holds the offsets table of a stream the
+    // gather wrote, and growing moves it.
+    RbBufs rb;
+    tile_window(c, &work);
+    const bool count_stay = !lv.idx && work.nlaunch == work.ntiles;
+    int rc = count_stay ? rebucket_bufs(c, work.ntiles, np, &rb) : 0;
+    if (rc) return rc;
+    rc = tile_ranges(c, pos, np, &work, &blocks);  // ranges of the positions before the drift
     if (rc) return rc;
     const unsigned ntiles = work.ntiles;
     ListBufs b;
     rc = list_bufs(c, np, ntiles, &b);
     if (rc) return rc;
-    // destination counts for the incremental re-sort: single-GPU layout only (a slab's migration renumbers the
-    // particles)
-    RbBufs rb;
-    const bool count_stay = !lv.idx && work.nlaunch == ntiles;
     DestCount dcount{nullptr, nullptr, nullptr, c->dt_pred, -0.5f * (dt + c->dt_pred) * c->acc_scale_pred};
     if (count_stay) {
-        rc = rebucket_bufs(c, ntiles, np, &rb);
-        if (rc) return rc;
         PM_HIP(hipMemsetAsync(rb.tile_count, 0, ((size_t)ntiles + 1) * sizeof(unsigned), c->stream));
         dcount.tile_count = rb.tile_count, dcount.wg_hist = rb.wg_hist, dcount.dcode = rb.dcode;
     } else if (c->codes_user) {
@@ -1986,7 +2018,21 @@ struct Rebucket {
     float *pos_out, *vel_out, *acc_out;
     const unsigned *id;       // optional particle tags carried along (NULL: none)
     unsigned *id_out;
+    float *sink;              // 64 x 3 floats: where the lanes of the range loop that have no particle store
 };
+// p for the lanes set in `mask`, q for the others, without a branch the compiler could put back
+typedef __attribute__((address_space(1))) float pm_gfloat;  // (global memory: rebuilt from integers a pointer is "flat")
+__device__ __forceinline__ pm_gfloat *select_ptr(unsigned long long mask, float *p, float *q) {
+    const unsigned plo = (unsigned)(uintptr_t)p, phi = (unsigned)((uintptr_t)p >> 32);
+    const unsigned qlo = (unsigned)(uintptr_t)q, qhi = (unsigned)((uintptr_t)q >> 32);
+    unsigned lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(qlo), "v"(plo), "s"(mask));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(qhi), "v"(phi), "s"(mask));
+    return (pm_gfloat *)(((uintptr_t)hi << 32) | lo);
+}
+typedef float pm_v3f __attribute__((ext_vector_type(3)));
+typedef float pm_v3fu __attribute__((ext_vector_type(3), aligned(4)));  // a 12-byte particle record: one dwordx3 access
+typedef __attribute__((address_space(1))) pm_v3fu pm_gv3fu;
 
 // One workgroup per tile: gather + second kick + CFL maxima.  ORDER == 0: `src` is the [.,n,n,3] force
 // grid; ORDER in {2,3,5,7}: `src` is the potential and the force tile is differentiated in LDS.
@@ -2164,6 +2210,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     const unsigned smask = gridDim.x >= 8192u ? 63u : (gridDim.x >= 512u ? 7u : 0u);
     const bool sample = (blockIdx.x & smask) == 0u;
     float sabs = 0.f, scnt = 0.f;
+    unsigned lost = 0u;  // a re-bucketing pass found no slot for a particle (the caller hears of it: pm_last_maxabs)
     __shared__ float s_sum[2][BLK / 64];
     // (o, w, p): where the particle's acceleration and velocity go -- the range's own base with a 32-bit
     // relative index, or the arrays' base with the 64-bit index of a listed straggler
@@ -2172,8 +2219,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                      bool own_range, int64_t src_index, int dcode_known) {
         // (the particle's destination code: from the prefetch queue of the range loop, or -- listed particles --
         // loaded here so that its latency hides behind the gather)
-        int dcode_p = 13;
-        if constexpr (REBUCKET) dcode_p = dcode_known >= 0 ? dcode_known : (int)rb.dcode[src_index];
+        const int dcode_p = dcode_known;
         const float xp = x * nf, yp = y * nf, zp = z * nf;
         const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
         const bool inside = in_tile(i, j, k, t);
@@ -2194,44 +2240,25 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
             a[0] = r.x, a[1] = r.y, a[2] = r.z;
         }
         if constexpr (REBUCKET) {
-            int64_t d64 = -1;  // where the particle goes (-1: not written)
-            if (own_range) {
-                // the destination the fused kick counted for it; stayers (nearly all) take consecutive slots of
-                // the own slice with one LDS atomic per wave and iteration, movers one each
-                const int dd_d = min(dcode_p, 26);
-                const bool stay = !skip && dd_d == 13;
-                const unsigned long long m = __ballot(stay);
-                const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                unsigned wb = 0;
-                if (stay && before == 0) wb = atomicAdd(&s_slot[13], (unsigned)__popcll(m));  // the first staying lane
-                wb = __shfl((int)wb, m ? __ffsll((long long)m) - 1 : (tid & 63), 64);
-                unsigned slot = wb + before;
-                if (!skip && !stay) slot = atomicAdd(&s_slot[dd_d], 1u);
-                // (slot < s_mine always, unless the positions were changed behind the prepared lists: memory safety)
-                if (!skip && slot < s_mine[dd_d]) d64 = s_dest[dd_d] + slot;
-            } else {
-                // a listed particle (it is inside this tile, or the lists are void): counted one by one by the
-                // fused kick, so it takes its slot from the destination's counter itself -- the lanes of a wave
-                // that stay in this tile (nearly all) with one global atomic between them
-                const int dd_d = min(dcode_p, 26);
-                const TileId ta = tile_of_cell(i, j, k);
-                const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
-                struct { unsigned key; } dd;
-                dd.key = tile_key((ta.ti + dd_d / 9 - 1 + Ti) % Ti, (ta.tj + (dd_d / 3) % 3 - 1 + Tj) % Tj,
-                                  (ta.tk + dd_d % 3 - 1 + Tk) % Tk);
-                const bool here = dd.key == key;
-                const unsigned long long m = __ballot(here);
-                const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                unsigned wb = 0;
-                if (here && before == 0) wb = atomicAdd(rb.fill + key, (unsigned)__popcll(m));
-                wb = __shfl((int)wb, m ? __ffsll((long long)m) - 1 : (tid & 63), 64);
-                const unsigned slot = here ? wb + before : atomicAdd(rb.fill + dd.key, 1u);
-                d64 = rb.newstart[dd.key] + (int64_t)slot;
-                if (d64 >= rb.newstart[dd.key + 1]) d64 = -1;  // (memory safety, as above)
-            }
+            // (listed particles only: a re-bucketing pass serves its ranges in the loop of its own below)
+            // A listed particle (it is inside this tile, or the lists are void) was counted one by one by the fused
+            // kick, so it takes its slot from the destination's counter itself -- the lanes of a wave that stay in
+            // this tile (nearly all) with one global atomic between them
+            const int dd_d = min(dcode_p, 26);
+            const TileId ta = tile_of_cell(i, j, k);
+            const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
+            const unsigned dkey = tile_key((ta.ti + dd_d / 9 - 1 + Ti) % Ti, (ta.tj + (dd_d / 3) % 3 - 1 + Tj) % Tj,
+                                           (ta.tk + dd_d % 3 - 1 + Tk) % Tk);
+            const bool here = dkey == key;
+            const unsigned long long m = __ballot(here);
+            const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            unsigned wb = 0;
+            if (here && before == 0) wb = atomicAdd(rb.fill + key, (unsigned)__popcll(m));
+            wb = __shfl((int)wb, m ? __ffsll((long long)m) - 1 : (tid & 63), 64);
+            const unsigned slot = here ? wb + before : atomicAdd(rb.fill + dkey, 1u);
+            int64_t d64 = rb.newstart[dkey] + (int64_t)slot;
+            if (d64 >= rb.newstart[dkey + 1]) d64 = -1, lost = 1u;  // (codes changed behind the counts: memory safety)
             if (d64 >= 0) {
-                // three 12-byte stores (written field by field through the three output pointers the compiler
-                // keeps them apart as nine dword stores, each touching every line of the wave's span)
                 float w[3];
 #pragma unroll
                 for (int mm = 0; mm < 3; ++mm) {
@@ -2240,11 +2267,10 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                     mv = max(mv, __float_as_uint(w[mm]) & 0x7fffffffu);
                 }
                 sabs += fabsf(a[0]), scnt += 1.0f;
-                typedef float pm_v3f __attribute__((ext_vector_type(3)));
                 const pm_v3f vp = {x, y, z}, va = {a[0], a[1], a[2]}, vw = {w[0], w[1], w[2]};
-                asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(rb.pos_out + 3 * d64), "v"(vp) : "memory");
-                asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(rb.acc_out + 3 * d64), "v"(va) : "memory");
-                asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(rb.vel_out + 3 * d64), "v"(vw) : "memory");
+                __builtin_nontemporal_store(vp, reinterpret_cast<pm_v3fu *>(rb.pos_out + 3 * d64));
+                __builtin_nontemporal_store(va, reinterpret_cast<pm_v3fu *>(rb.acc_out + 3 * d64));
+                __builtin_nontemporal_store(vw, reinterpret_cast<pm_v3fu *>(rb.vel_out + 3 * d64));
                 if (rb.id) rb.id_out[d64] = rb.id[src_index];
             }
         } else if (!skip) {
@@ -2262,14 +2288,104 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
             }
         }
     };
-    if (has_range) {
+    constexpr int QD = 2;  // queue slots in use (measured at 1024^3: 4 slots 16.3 ms, 3: 16.3, 2: 15.95, 1: 16.4)
+    if constexpr (REBUCKET) {
+        // The range of a re-bucketing pass.  What this loop is made for is that a wave NEVER drains its memory queue:
+        // vector-memory operations retire in order, so a wait for one load is a wait for every load and every STORE
+        // issued before it.  (Until round 3 the destination byte was loaded inside the iteration that used it and the
+        // stores were inline asm, which the compiler's wait counting does not see: every particle ended in
+        // s_waitcnt vmcnt(0), i.e. behind the acknowledgement of its predecessor's three stores and the arrival of
+        // the refills just issued -- two memory round trips per particle and wave, with four waves per SIMD to hide
+        // them.)  Position, velocity and destination byte are now loaded two particles ahead, the stores are
+        // ordinary (nontemporal) stores, and the body is ONE basic block as far as vector memory goes -- lanes
+        // without a particle (the tail of the range, strangers the lists serve) run along on a dummy cell and store
+        // to a 768-byte sink instead of branching around the stores -- so the counted waits the compiler derives
+        // (vmcnt(N), N = everything issued since) leave the stores and the refills in flight.
+        if (has_range) {
+            const unsigned cnt = (unsigned)(e - s), last = cnt - 1u;
+            const unsigned char *const dbase = rb.dcode + s;
+            const unsigned lane = (unsigned)tid & 63u;
+            float *const sink = rb.sink + 3u * lane;
+            // Four register slots, two particles ahead: body u takes its particle from slot u and refills slot (u + 2) % 4,
+            // which was emptied two bodies ago -- every load lands in the registers it is consumed from (no copies behind a
+            // wait for a load just issued, which is what two slots refilled at the point of use came to) and has two
+            // gathers' time to arrive.
+            constexpr int NS = 4;
+            unsigned dq[NS];  // (a dword each: as bytes the compiler packs the four into one register at the bottom of the
+                              // loop, behind a wait for the loads)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) dq[u] = dbase[min((unsigned)tid + u * BLK, last)];
+            dq[2] = dq[3] = 13u;
+            // (the primed loads are waited for here, once: the compiler's counted waits inside the loop are the minimum over
+            // the ways into it, and coming from the priming there is next to nothing behind a slot's loads to count on)
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll 1
+            for (unsigned r0 = tid; (unsigned)__builtin_amdgcn_readfirstlane((int)r0) < cnt; r0 += NS * BLK) {
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    const unsigned r = r0 + u * BLK;
+                    const float x = q.x[u], y = q.y[u], z = q.z[u];
+                    const float v[3] = {qv.q.x[u], qv.q.y[u], qv.q.z[u]};
+                    const int dd_d = (int)min(dq[u], 26u);
+                    q.load((u + 2) % NS, r + 2 * BLK);
+                    qv.q.load((u + 2) % NS, r + 2 * BLK);
+                    dq[(u + 2) % NS] = dbase[min(r + 2 * BLK, last)];
+                    float a[3] = {0.f, 0.f, 0.f};
+                    bool ok = false;
+                    int64_t d64 = 0;
+                    // (a wave past the end of the range -- the last trip of the loop -- skips the arithmetic, not the loads
+                    // and stores: a branch around those would be a branch the counted waits have to allow for)
+                    if ((unsigned)__builtin_amdgcn_readfirstlane((int)r) < cnt) {
+                        const float xp = x * nf, yp = y * nf, zp = z * nf;
+                        const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+                        // (a stranger in the own range is served by the tile it is in now, from its list)
+                        const bool mine = r < cnt && in_tile(i, j, k, t);
+                        gather_lds<SCHEME>(xp, yp, zp, mine ? i : t.ti * PM_TI, mine ? j : t.tj * PM_TJ, mine ? k : t.tk * PM_TK,
+                                           t, tile, a);
+                        // the destination the fused kick counted for it; stayers (nearly all) take consecutive slots of
+                        // the own slice with one LDS atomic per wave and iteration, movers one each
+                        const bool stay = mine && dd_d == 13;
+                        const unsigned long long m = __ballot(stay);
+                        const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        unsigned wb = 0;
+                        if (stay && before == 0) wb = atomicAdd(&s_slot[13], (unsigned)__popcll(m));  // the first staying lane
+                        wb = __shfl((int)wb, m ? __ffsll((long long)m) - 1 : (int)lane, 64);
+                        unsigned slot = wb + before;
+                        if (mine && !stay) slot = atomicAdd(&s_slot[dd_d], 1u);
+                        // (slot < s_mine always, unless the positions were changed behind the prepared lists: memory safety)
+                        ok = mine && slot < s_mine[dd_d];
+                        lost |= (unsigned)(mine && !ok);
+                        d64 = s_dest[dd_d] + (int64_t)slot;
+                    }
+                    float w[3];
+#pragma unroll
+                    for (int mm = 0; mm < 3; ++mm) w[mm] = v[mm] + mhalf_dt * a[mm];
+                    if (ok) {
+#pragma unroll
+                        for (int mm = 0; mm < 3; ++mm) {
+                            ma = max(ma, __float_as_uint(a[mm]) & 0x7fffffffu);
+                            mv = max(mv, __float_as_uint(w[mm]) & 0x7fffffffu);
+                        }
+                        sabs += fabsf(a[0]), scnt += 1.0f;
+                    }
+                    const pm_v3f vp = {x, y, z}, va = {a[0], a[1], a[2]}, vw = {w[0], w[1], w[2]};
+                    // (the select is two v_cndmask written out: from `ok ? p : sink` the compiler makes a branch around
+                    // each store, and a store that may not have been issued is a store its wait counting cannot rely on)
+                    const unsigned long long okm = __ballot(ok);
+                    __builtin_nontemporal_store(vp, (pm_gv3fu *)select_ptr(okm, rb.pos_out + 3 * d64, sink));
+                    __builtin_nontemporal_store(va, (pm_gv3fu *)select_ptr(okm, rb.acc_out + 3 * d64, sink));
+                    __builtin_nontemporal_store(vw, (pm_gv3fu *)select_ptr(okm, rb.vel_out + 3 * d64, sink));
+                    if (rb.id) {
+                        if (ok) rb.id_out[d64] = rb.id[s + r];
+                    }
+                }
+            }
+        }
+    } else if (has_range) {
         float *const o = out + 3 * s, *const w3 = KICK ? vel + 3 * s : nullptr;
         const unsigned cnt = (unsigned)(e - s);
         // QD particles per trip, one per queue slot: slot u is consumed and refilled in place, where popping the head
-        // and shifting the queue cost 18 register moves per particle (gather 17.2 -> 16.5 ms at 1024^3).  (The
-        // destination codes are NOT queued alongside: loaded inside serve() they are the youngest load in flight and the
-        // wait for them drains the queue -- yet four codes prefetched per lane measured 17.0 ms.)
-        constexpr int QD = 2;  // slots in use (measured at 1024^3: 4 slots 16.3 ms, 3: 16.3, 2: 15.95, 1: 16.4)
+        // and shifting the queue cost 18 register moves per particle (gather 17.2 -> 16.5 ms at 1024^3)
 #pragma unroll 1
         for (unsigned r0 = tid; r0 < cnt; r0 += QD * BLK) {
 #pragma unroll
@@ -2281,7 +2397,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                     if (KICK) v[0] = qv.q.x[u], v[1] = qv.q.y[u], v[2] = qv.q.z[u];
                     q.load(u, r + QD * BLK);
                     if (KICK) qv.q.load(u, r + QD * BLK);
-                    serve(o, w3, r, x, y, z, v, true, s + r, -1);
+                    serve(o, w3, r, x, y, z, v, true, s + r, 13);
                 }
             }
         }
@@ -2291,7 +2407,7 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         const int64_t p = lists.idx[l];
         float v[3] = {0.f, 0.f, 0.f};
         if (KICK) v[0] = vel[3 * p], v[1] = vel[3 * p + 1], v[2] = vel[3 * p + 2];
-        serve(out, vel, p, pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], v, false, p, -1);
+        serve(out, vel, p, pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], v, false, p, REBUCKET ? (int)rb.dcode[p] : 13);
     }
     for (int off = 32; off > 0; off >>= 1) {
         ma = max(ma, (unsigned)__shfl_down((int)ma, off, 64));
@@ -2318,6 +2434,10 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                 atomicAdd(maxbits + PM_SAMPLE_WORD + 2, (unsigned)scnt);
             }
         }
+    }
+    if constexpr (REBUCKET) {  // (never, unless positions or codes were changed behind the prepared counts)
+        const unsigned long long lm = __ballot(lost != 0u);
+        if (lm && (tid & 63) == 0) atomicAdd(maxbits + PM_SAMPLE_WORD + 3, (unsigned)__popcll(lm));
     }
 }
 
@@ -2579,10 +2699,11 @@ extern "C" int pm_rebucket_prepare(pm_ctx *c, const float *d_pos, int64_t np, un
     TileWork work;
     TileLists lists;
     unsigned nblk = 0;
-    int rc = tile_work_for(c, d_pos, np, &work, &lists, &nblk);
-    if (rc) return rc;
     RbBufs b;
-    rc = rebucket_bufs(c, work.ntiles, np, &b);
+    int rc = rebucket_bufs(c, (unsigned)(((int64_t)c->n * c->n * c->n) >> (PM_LI + PM_LJ + PM_LK)), np, &b);  // (first: it may move)
+    if (rc) return rc;
+    PM_REQUIRE(c->lists_pos == d_pos, "the tile lists read a table that has just moved: call pm_tile_lists again");
+    rc = tile_work_for(c, d_pos, np, &work, &lists, &nblk);
     if (rc) return rc;
     PM_HIP(hipMemsetAsync(b.tile_count, 0, ((size_t)work.ntiles + 1) * sizeof(unsigned), c->stream));
     hipLaunchKernelGGL(rebucket_prepare_kernel, dim3(nblk), dim3(BLK), 0, c->stream, d_pos, work, lists, c->n, d_codes,
@@ -2609,12 +2730,15 @@ static int gradient_interp_kick_rebucket(pm_ctx *c, int order, int scheme, const
     TileWork work;
     TileLists lists;
     unsigned nblk = 0;
-    int rc = tile_work_for(c, d_pos, np, &work, &lists, &nblk);
+    RbBufs b;
+    // (sized for this np by whoever prepared the counts -- the fused kick, pm_tile_lists_codes, pm_rebucket_prepare --
+    // so this call only hands out the pointers; were it to grow the buffer, the counts would be gone: checked below)
+    int rc = rebucket_bufs(c, (unsigned)(((int64_t)c->n * c->n * c->n) >> (PM_LI + PM_LJ + PM_LK)), np, &b);
+    if (rc) return rc;
+    PM_REQUIRE(c->stay_valid && c->lists_pos == d_pos, "the re-sort's buffer moved under the prepared counts");
+    rc = tile_work_for(c, d_pos, np, &work, &lists, &nblk);
     if (rc) return rc;
     const unsigned ntiles = work.ntiles;
-    RbBufs b;
-    rc = rebucket_bufs(c, ntiles, np, &b);
-    if (rc) return rc;
     int64_t *table = b.table[c->rb_cur ^ 1];  // (work.start may be the other table: this stream's own layout)
     const unsigned tb = (ntiles + 1 + BLK - 1) / BLK;
     hipLaunchKernelGGL(rebucket_counts_kernel, dim3(tb), dim3(BLK), 0, c->stream, b.tile_count, ntiles, b.cnt);
@@ -2628,6 +2752,7 @@ static int gradient_interp_kick_rebucket(pm_ctx *c, int order, int scheme, const
     Rebucket rb;
     rb.newstart = table, rb.fill = b.fill, rb.wg_hist = b.wg_hist, rb.dcode = c->stay_codes;
     rb.pos_out = d_pos_out, rb.vel_out = d_vel_out, rb.acc_out = d_acc_out, rb.id = d_id, rb.id_out = d_id_out;
+    rb.sink = reinterpret_cast<float *>(c->d_scratch + PM_SCRATCH_SINK);
     float *vel = const_cast<float *>(d_vel);  // read only by the re-bucketing instantiation
     switch (scheme) {
         case PM_NGP: rc = rebucket_order<PM_NGP>(c, order, d_phi, geo, d_pos, vel, np, half_dt, work, lists, nblk, rb); break;
@@ -2726,6 +2851,14 @@ extern "C" int pm_last_maxabs(pm_ctx *c, float *h_max_acc, float *h_max_vel) {
     memcpy(&sum, &bits[PM_SAMPLE_WORD], sizeof(double));
     const unsigned cnt = bits[PM_SAMPLE_WORD + 2];
     c->last_acc_meanabs = cnt >= 1024u ? sum / (double)cnt : 0.0;  // (came with the same copy; a handful of particles is no sample)
+    if (bits[PM_SAMPLE_WORD + 3] != 0u) {
+        // the re-bucketing gather found no slot for some particles: their records were NOT written (positions or
+        // destination codes changed between the count and the gather).  The output arrays are incomplete.
+        pm_set_error("the re-bucketing gather dropped particles in %u waves: positions or destination codes changed behind "
+                     "the prepared counts (call pm_tile_lists + pm_rebucket_prepare again, or reorder the particles)",
+                     bits[PM_SAMPLE_WORD + 3]);
+        return PM_EINVAL;
+    }
     return PM_OK;
 }
 

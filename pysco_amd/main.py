@@ -39,42 +39,15 @@ def reserve_step_buffers(position) -> None:
             mesh._rebucket_pool.append(torch.empty_like(position))
 
 
-def tune_placement(position, velocity, acceleration=None, max_candidates: int = 10):
-    """Measured on MI355X: how fast the fused kick + drift + deposit streams through the particle arrays -- position
-    and velocity updated in place, acceleration read -- depends on the physical memory the allocations landed in, and
-    on the COMBINATION of arrays more than on each one: an in-place pass over a single 12.9 GB array runs at 5.08 or
-    4.5 TB/s depending on the allocation (tools/bench_array_single.py), and the three-array update takes 11.05 to
-    11.85 ms over triples of arrays that are all "fast" on their own, while a "slow" one can be part of the fastest
-    triples (tools/exp_triples.py); the kernel then runs 13.2 or 15.1 ms at 1024^3.  Nothing in the virtual layout
-    controls it, so this allocates candidate arrays, times the update's own access pattern (pm_probe_update: values
-    unchanged) over every PAIR (updated, updated) of candidates, takes the best pair for position and velocity of the
-    live set, the best disjoint pair for the set the re-bucketing gather writes (the fused kick updates that one in
-    place a step later), then the best third array for each; the rest is freed.  One-time cost at 1024^3: 0.3 s per
-    candidate allocated + about 11 ms per combination timed (1 s).  Returns the (possibly new) position, velocity[,
-    acceleration] tensors; values and order unchanged."""
-    if not L.is_device_array(position):
-        return (position, velocity) if acceleration is None else (position, velocity, acceleration)
-    from . import mesh
-
+def rank_triples(arrays, npart):
+    """The measurement behind tune_placement, on any list of >= 6 device arrays of at least npart x 3 floats: times the
+    fused kick's own traffic (pm_probe_update: two arrays rewritten in place, a third read, every value left as it
+    is) over every pair, the leaders again best-of-three, and returns ((i, j, k) of the best triple, (i, j, k) of the
+    best triple disjoint from it, {timings}) -- (updated, updated, read) = (position, velocity, acceleration).
+    The x-slab step places each rank's capacity-backed arrays with it (pysco_amd.slab.Slab._adopt)."""
     torch = L.require_gpu()
     ctx = L.context(4)
-    live = [position, velocity] + ([acceleration] if acceleration is not None else [])
-    free_bytes, _ = torch.cuda.mem_get_info(position.device)
-    each = position.numel() * 4
-    # (the candidates that are not kept are freed again before anything else is allocated: they may use what is free now)
-    n_cand = int(max(0, min(max_candidates, free_bytes // each - 2)))
-    mesh._rebucket_pool.clear()
-    cand = []
-    try:
-        for _ in range(n_cand):
-            cand.append(torch.zeros_like(position))
-    except torch.OutOfMemoryError:
-        pass
-    arrays = live + cand
-    n, npart = len(arrays), position.shape[0]
-    if npart % 4:  # (the probe streams whole float4: odd sizes are not worth tuning)
-        reserve_step_buffers(position)
-        return tuple(live)
+    n = len(arrays)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def probe(i, j, k):  # the update's traffic over (arrays[i], arrays[j]) in place + arrays[k] read; x * 1 leaves every value
@@ -84,11 +57,6 @@ def tune_placement(position, velocity, acceleration=None, max_candidates: int = 
         torch.cuda.synchronize()
         return e0.elapsed_time(e1)
 
-    global last_placement_probe_ms
-    if n < 6:  # no room for a second set: leave things as they are
-        last_placement_probe_ms = None
-        reserve_step_buffers(position)
-        return tuple(live)
     probe(0, 1, 2)  # (warm-up)
     pairs = []
     for i in range(n):
@@ -111,9 +79,50 @@ def tune_placement(position, velocity, acceleration=None, max_candidates: int = 
         return best
 
     acc_a, acc_b = third(set_a), third(set_b)
-    last_placement_probe_ms = {"pairs": [round(t[0], 3) for t in pairs], "live_set": round(acc_a[0], 3),
-                               "output_set": round(acc_b[0], 3)}
+    info = {"pairs": [round(t[0], 3) for t in pairs], "live_set": round(acc_a[0], 3), "output_set": round(acc_b[0], 3)}
     logging.info(f"placement probe [ms]: pairs {pairs[0][0]:.2f} .. {pairs[-1][0]:.2f}, chosen triples {acc_a[0]:.2f} {acc_b[0]:.2f}")
+    return (set_a[1], set_a[2], acc_a[1]), (set_b[1], set_b[2], acc_b[1]), info
+
+
+def tune_placement(position, velocity, acceleration=None, max_candidates: int = 10):
+    """Measured on MI355X: how fast the fused kick + drift + deposit streams through the particle arrays -- position
+    and velocity updated in place, acceleration read -- depends on the physical memory the allocations landed in, and
+    on the COMBINATION of arrays more than on each one: an in-place pass over a single 12.9 GB array runs at 5.08 or
+    4.5 TB/s depending on the allocation (tools/bench_array_single.py), and the three-array update takes 11.05 to
+    11.85 ms over triples of arrays that are all "fast" on their own, while a "slow" one can be part of the fastest
+    triples (tools/exp_triples.py); the kernel then runs 13.2 or 15.1 ms at 1024^3.  Nothing in the virtual layout
+    controls it, so this allocates candidate arrays, times the update's own access pattern (pm_probe_update: values
+    unchanged) over every PAIR (updated, updated) of candidates, takes the best pair for position and velocity of the
+    live set, the best disjoint pair for the set the re-bucketing gather writes (the fused kick updates that one in
+    place a step later), then the best third array for each; the rest is freed.  One-time cost at 1024^3: 0.3 s per
+    candidate allocated + about 11 ms per combination timed (1 s).  Returns the (possibly new) position, velocity[,
+    acceleration] tensors; values and order unchanged."""
+    if not L.is_device_array(position):
+        return (position, velocity) if acceleration is None else (position, velocity, acceleration)
+    from . import mesh
+
+    torch = L.require_gpu()
+    live = [position, velocity] + ([acceleration] if acceleration is not None else [])
+    free_bytes, _ = torch.cuda.mem_get_info(position.device)
+    each = position.numel() * 4
+    # (the candidates that are not kept are freed again before anything else is allocated: they may use what is free now)
+    n_cand = int(max(0, min(max_candidates, free_bytes // each - 2)))
+    mesh._rebucket_pool.clear()
+    cand = []
+    try:
+        for _ in range(n_cand):
+            cand.append(torch.zeros_like(position))
+    except torch.OutOfMemoryError:
+        pass
+    arrays = live + cand
+    npart = position.shape[0]
+    global last_placement_probe_ms
+    if npart % 4 or len(arrays) < 6:  # (the probe streams whole float4; no room for a second set: leave things as they are)
+        last_placement_probe_ms = None
+        reserve_step_buffers(position)
+        return tuple(live)
+    (ia, ja, ka), (ib, jb, kb), last_placement_probe_ms = rank_triples(arrays, npart)
+    set_a, set_b, acc_a, acc_b = (0, ia, ja), (0, ib, jb), (0, ka), (0, kb)
     homes = [arrays[set_a[1]], arrays[set_a[2]], arrays[acc_a[1]]][:len(live)]
     spare = [arrays[set_b[1]], arrays[set_b[2]], arrays[acc_b[1]]]
     same = lambda a, b: a.data_ptr() == b.data_ptr()  # noqa: E731
@@ -130,7 +139,7 @@ def tune_placement(position, velocity, acceleration=None, max_candidates: int = 
             pending[0] = (x.clone(), h)
     mesh._rebucket_pool.extend(spare)
     out = homes
-    del cand, arrays, pairs, top, spare
+    del cand, arrays, spare
     torch.cuda.empty_cache()
     return tuple(out)
 

@@ -355,12 +355,24 @@ def _unstage(t, like):
     return t.to(like.device) if t.device != like.device else t
 
 
+# bytes this rank handed to the all-to-alls / the ring exchanges for OTHER ranks (bench.py reports them per step against
+# the 7 x 153 GB/s of a GPU's xGMI links)
+comm_stats = {"a2a_bytes": 0, "a2a_calls": 0, "ring_bytes": 0, "ring_calls": 0}
+
+
+def _count_a2a(t) -> None:
+    world = _dist().get_world_size()
+    comm_stats["a2a_bytes"] += t.numel() * t.element_size() * (world - 1) // world
+    comm_stats["a2a_calls"] += 1
+
+
 def all_to_all(send, out_splits: Optional[List[int]] = None, in_splits: Optional[List[int]] = None):
     """all_to_all_single along dim 0; equal splits when both lists are None."""
     import torch
 
     dist = _dist()
     s = _stage(send.contiguous())
+    _count_a2a(s)
     if out_splits is None:
         out = torch.empty_like(s)
     else:
@@ -381,6 +393,7 @@ class _AllToAllHandle:
         dist = _dist()
         self.like = send
         self.src = _stage(send.contiguous())  # kept alive until wait()
+        _count_a2a(self.src)
         self.out = torch.empty_like(self.src)
         a, b = (torch.view_as_real(self.out), torch.view_as_real(self.src)) if self.src.is_complex() else (self.out, self.src)
         self.work = dist.all_to_all_single(a, b, async_op=True)
@@ -399,6 +412,8 @@ def exchange_planes(to_left, to_right):
     rank, world = dist.get_rank(), dist.get_world_size()
     left, right = (rank - 1) % world, (rank + 1) % world
     sl, sr = _stage(to_left.contiguous()), _stage(to_right.contiguous())
+    comm_stats["ring_bytes"] += sl.numel() * sl.element_size() + sr.numel() * sr.element_size()
+    comm_stats["ring_calls"] += 1
     from_right, from_left = torch.empty_like(sl), torch.empty_like(sr)
     # order matters when left == right (2 ranks): a rank's first send (to its left) is its peer's
     # "from my right", so receives are posted in the order [from_right, from_left]
@@ -493,15 +508,62 @@ class Slab:
                 and st["bufs"][1].data_ptr() == velocity.data_ptr()):
             return
         cap = int(n * 1.03) + 4096
+        codes = self._rebucket_on(position)
+        placed = self._place_arrays(position, cap) if codes else None
         bufs = []
-        for a in (position, velocity) + tuple(self.carry):
-            b = torch.empty((cap,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+        for k, a in enumerate((position, velocity) + tuple(self.carry)):
+            if placed is not None and k < 2:
+                b = placed["live"][k]
+            else:
+                b = torch.empty((cap,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
             b[:n] = a
             bufs.append(b)
-        codes = self._rebucket_on(position)
         if codes:  # destination codes of the incremental re-sort: one more per-particle array that migrates (13 = stays)
             bufs.append(torch.full((cap,), 13, dtype=torch.uint8, device=position.device))
-        self._store = {"bufs": bufs, "n": n, "cap": cap, "codes": codes, "out": None}
+        self._store = {"bufs": bufs, "n": n, "cap": cap, "codes": codes, "out": placed["out"] if placed else None,
+                       "acc": placed["acc"] if placed else None}
+
+    def _place_arrays(self, position, cap):
+        """Every rank runs the placement search of the single-GPU loop (pysco_amd.main.rank_triples; DESIGN.md section
+        5) on its own capacity-backed arrays: the streaming particle kernels run up to 15 % faster or slower with the
+        physical memory an allocation happened to land in, and on G ranks the slowest draw sets the step.  Candidates
+        of the store's capacity are allocated, the fused kick's own traffic is timed over every pair of them, the
+        best triple becomes (position, velocity, acceleration) of the live set, the best disjoint one the set the
+        re-bucketing gather writes; the rest is freed.  Large ranks only (a probe pass must be worth timing), and
+        only where the memory is there; PMSTEP_SLAB_PLACEMENT=0 turns it off."""
+        import torch
+
+        from . import main as pm_main
+
+        n = position.shape[0]
+        if (os.environ.get("PMSTEP_SLAB_PLACEMENT", "1") == "0" or n < 2**22 or position.dtype != torch.float32
+                or not position.is_cuda):
+            return None
+        free_bytes, _ = torch.cuda.mem_get_info(position.device)
+        each = cap * 12
+        n_cand = int(min(10, free_bytes // (each * max(1, self.world_on_device())) - 2))
+        if n_cand < 6:
+            return None
+        cand = []
+        try:
+            for _ in range(n_cand):
+                cand.append(torch.zeros((cap, 3), dtype=torch.float32, device=position.device))
+        except torch.OutOfMemoryError:
+            cand = cand[:-1]
+        if len(cand) < 6:
+            return None
+        a, b, info = pm_main.rank_triples(cand, n & ~3)
+        self.placement_probe_ms = info
+        placed = {"live": [cand[a[0]], cand[a[1]]], "out": [cand[b[0]], cand[b[1]]], "acc": [cand[a[2]], cand[b[2]]]}
+        del cand
+        torch.cuda.empty_cache()
+        return placed
+
+    def world_on_device(self) -> int:
+        """Ranks that share this rank's GPU (1 on a real node; all of them in a one-GPU rehearsal)."""
+        import torch
+
+        return max(1, -(-self.world // max(1, torch.cuda.device_count())))
 
     def _rebucket_on(self, position) -> bool:
         return bool(_SLAB_REBUCKET and hasattr(self.ops, "gradient_interp_kick_rebucket") and self.n >= 16
@@ -527,7 +589,7 @@ class Slab:
             nb = torch.empty((cap,) + tuple(b.shape[1:]), dtype=b.dtype, device=b.device)
             nb[:st["n"]] = b[:st["n"]]
             new.append(nb)
-        st["bufs"], st["cap"], st["out"] = new, cap, None
+        st["bufs"], st["cap"], st["out"], st["acc"] = new, cap, None, None
 
     def _migrate_leavers(self, leave):
         """Send the particles at (sorted) indices `leave` to their owners and file the arrivals into the
@@ -712,7 +774,11 @@ class Slab:
             npart, cap = st["n"], st["cap"]
             if st["out"] is None:
                 st["out"] = [torch.empty_like(st["bufs"][0]), torch.empty_like(st["bufs"][1])]
-            acc = torch.empty((npart, 3), dtype=torch.float32, device=position.device)
+            if st.get("acc"):  # (placed with the sets: the one that goes with the set being written)
+                acc = st["acc"][1][:npart]
+                st["acc"].reverse()
+            else:
+                acc = torch.empty((npart, 3), dtype=torch.float32, device=position.device)
             ids = ids_out = None
             if self.carry:
                 ids = torch.arange(npart, dtype=torch.int32, device=position.device)

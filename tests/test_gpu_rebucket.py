@@ -273,7 +273,7 @@ def test_rebucket_from_codes_alone(fused_scan):
         assert torch.equal(vel_out.cpu(), ref_vel.cpu()[perm])
 
 
-@pytest.mark.parametrize("change", [+500, -300, 0])
+@pytest.mark.parametrize("change", [+500, -300, 0, +20000])
 def test_sorted_stream_resized_after_a_migration(change):
     """What a slab rank does between two gathers, on one GPU: the re-bucketing gather leaves a tile-sorted stream and
     its offsets on file; a "migration" then overwrites some particles in place (arrivals in the leavers' holes) and
@@ -281,7 +281,9 @@ def test_sorted_stream_resized_after_a_migration(change):
     the LAST TILE OF THE WINDOW, which is not the last tile of the mesh here): the next scan finds the strangers one by
     one -- not a large part of the stream, as the bisected envelope of the keys did whenever a probe landed on an
     arrival (change != 0 here; the same count keeps the offsets anyway) -- and the next gather serves every particle,
-    appended ones included."""
+    appended ones included.  change = +20000 takes the count past the 1/16 headroom of the re-sort's buffer, which
+    holds the offsets on file: the buffer is re-allocated and the table must move with it (it used to be freed under
+    the pointer the scan had just taken)."""
     import ctypes as C
 
     import torch
@@ -304,7 +306,7 @@ def test_sorted_stream_resized_after_a_migration(change):
     vel = torch.rand((npart, 3), generator=g, device="cuda") - 0.5
     phi = torch.rand((n, n, n), generator=g, device="cuda")
     ctx = L.context(n)
-    cap = npart + 1000
+    cap = npart + max(change, 0) + 1000
     half_dt = float(np.float32(0.01))
 
     def gather(p, v, count, codes):
