@@ -432,6 +432,36 @@ int pm_fft1d_x(pm_ctx *ctx, void *d_data, int64_t ncolumns, int inverse);
 int pm_greens_slab(pm_ctx *ctx, int kind, int p, void *d_xk, const float *h_k2, const float *h_s, float c0, int j0,
                    int nj);
 
+/* ---- the fp64 device mode (pm_create(N, Np, ngpu, real_bytes)) ---------------------------
+ * pm_ctx_create_real(..., real_bytes): 4 = pm_ctx_create (the reference's float32, every entry point above);
+ * 8 = a context of the fp64 mode of the Newtonian FFT step, served by the pm_real64_* entry points below, which take
+ * arrays of double in the layouts above.  The reference has no fp64 mode (mesh.py:2467, fourier.py:21): these are the
+ * same formulas in double, there to state the <= 1e-10 tolerance between the build's fp64 CPU and fp64 device paths
+ * (BASELINE.md section 6).  Each names the reference function whose formula it evaluates. */
+int pm_ctx_create_real(pm_ctx **out, int n, void *stream, int real_bytes);
+int pm_ctx_real_bytes(pm_ctx *ctx);
+/* integration.py:250-258: v += -half_dt a; x += dt v; utils.periodic_wrap(x) */
+int pm_real64_kick_drift_wrap(pm_ctx *ctx, double *d_pos, double *d_vel, const double *d_acc, double half_dt, double dt,
+                              int64_t np);
+/* utils.linear_operator_inplace :644-684 (x = a x + b) and prod_vector_scalar_inplace (b = 0) */
+int pm_real64_scale_add(pm_ctx *ctx, double *d_x, double a, double b, int64_t n);
+/* utils.max_abs :410-430 */
+int pm_real64_max_abs(pm_ctx *ctx, const double *d_x, int64_t n, double *h_out);
+/* mesh.NGP :2240 / CIC :2284 / TSC :2468; d_rho [n,n,n] is overwritten */
+int pm_real64_deposit(pm_ctx *ctx, int scheme, const double *d_pos, int64_t np, double *d_rho);
+/* solver.fft :453-522: r2c, Green's function (pm_greens' kinds and tables, in double), c2r with 1/n^3.
+ * d_rhs may be overwritten. */
+int pm_real64_poisson_fft(pm_ctx *ctx, int kind, int p, const double *d_rhs, double *d_phi, const double *h_k2,
+                          const double *h_s, double c0);
+/* mesh.derivative :2072 (order 2, 3, 5, 7): d_force [n,n,n,3] */
+int pm_real64_gradient(pm_ctx *ctx, int order, const double *d_phi, double *d_force);
+/* mesh.invNGP_vec :2639 / invCIC_vec :2752 / invTSC_vec :2960 into d_acc; with d_vel (may be NULL) also the second
+ * kick v += -half_dt a (integration.py:262); h_max_acc / h_max_vel (may be NULL): max|a|, max|v| (integration.py:267-326) */
+int pm_real64_interp_kick(pm_ctx *ctx, int scheme, const double *d_force, const double *d_pos, int64_t np, double *d_acc,
+                          double *d_vel, double half_dt, double *h_max_acc, double *h_max_vel);
+/* fourier.fourier_grid_to_Pk :22-100 of fft_3D_real(d_rho): per-bin sums of |k|, |delta_k|^2 W^(-2p), mode counts (n each) */
+int pm_real64_pk(pm_ctx *ctx, int p, double *d_rho, const double *h_sinc, double *h_ksum, double *h_pksum, double *h_nmodes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -489,9 +489,9 @@ def pm(position, param, potential=None, additional_field=None, tables=(), pk_out
         potential = fft(rhs, param, pk_out)
     elif solver == "full_fft":
         # The reference's full_fft branch calls the two-argument fft_force with three (solver.py:181, 200) and dies
-        # with TypeError; with param["full_fft_reference_bug"] set the restatement does the same.  Otherwise it does
-        # what the branch spells out: the potential is left alone and the force comes from fft_force (solver.py:524).
-        if param.get("full_fft_reference_bug", False):
+        # with TypeError: so does the restatement, unless param["full_fft_force"] asks for what the branch spells out:
+        # the potential is left alone and the force comes from fft_force (solver.py:524).
+        if not param.get("full_fft_force", False):
             raise TypeError("fft_force() takes 2 positional arguments but 3 were given")
     else:
         raise NotImplementedError(f"{param['linear_newton_solver']=}, should be multigrid, fft, fft_7pt or full_fft")

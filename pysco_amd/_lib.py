@@ -20,6 +20,7 @@ GREEN_PLAIN, GREEN_COMPENSATED, GREEN_7PT = 0, 1, 2
 _vp = C.c_void_p
 _i64 = C.c_int64
 _f = C.c_float
+_d = C.c_double
 _i = C.c_int
 
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
@@ -142,6 +143,17 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_fft2d_c2r": (_vp, _vp, _vp, _i),
     "pm_fft1d_x": (_vp, _vp, _i64, _i),
     "pm_greens_slab": (_vp, _i, _i, _vp, _vp, _vp, _f, _i, _i),
+    # the fp64 device mode (pm_real64.hip)
+    "pm_ctx_create_real": (C.POINTER(_vp), _i, _vp, _i),
+    "pm_ctx_real_bytes": (_vp,),
+    "pm_real64_kick_drift_wrap": (_vp, _vp, _vp, _vp, _d, _d, _i64),
+    "pm_real64_scale_add": (_vp, _vp, _d, _d, _i64),
+    "pm_real64_max_abs": (_vp, _vp, _i64, C.POINTER(_d)),
+    "pm_real64_deposit": (_vp, _i, _vp, _i64, _vp),
+    "pm_real64_poisson_fft": (_vp, _i, _i, _vp, _vp, _vp, _vp, _d),
+    "pm_real64_gradient": (_vp, _i, _vp, _vp),
+    "pm_real64_interp_kick": (_vp, _i, _vp, _vp, _i64, _vp, _vp, _d, C.POINTER(_d), C.POINTER(_d)),
+    "pm_real64_pk": (_vp, _i, _vp, _vp, _vp, _vp, _vp),
 }
 _RESTYPES = {"pm_last_error": C.c_char_p, "pm_khalo_floats": C.c_int64, "pm_khalo_floats_slab": C.c_int64}
 
@@ -209,7 +221,7 @@ _PROFILE_SIZE_ARG = {"pm_lap_gauss_seidel": 2, "pm_lap_smoothing": 2, "pm_fr_vcy
                      "pm_quartic_gauss_seidel": 4, "pm_cubic_operator": 4, "pm_quartic_operator": 4,
                      "pm_cubic_residual_error": 3, "pm_quartic_residual_error": 3, "pm_mond_rhs": 2}
 
-_ctxs: Dict[Tuple[int, int], "Context"] = {}
+_ctxs: Dict[tuple, "Context"] = {}
 _profiler = None  # list of (name, start_event, stop_event) while stage profiling is enabled
 
 
@@ -246,16 +258,17 @@ def profile_stop(per_step: bool = False):
 
 
 class Context:
-    """pm_ctx for one (device, grid size)."""
+    """pm_ctx for one (device, grid size, arithmetic type)."""
 
-    def __init__(self, n: int):
+    def __init__(self, n: int, real_bytes: int = 4):
         torch = require_gpu()
         self.lib = load_library()
         self.n = int(n)
+        self.real_bytes = int(real_bytes)
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.handle = _vp()
         stream = torch.cuda.current_stream().cuda_stream
-        check(self.lib.pm_ctx_create(C.byref(self.handle), self.n, _vp(stream)))
+        check(self.lib.pm_ctx_create_real(C.byref(self.handle), self.n, _vp(stream), self.real_bytes))
         self._stream = stream
         self._stream_obj = torch.cuda.current_stream()
 
@@ -296,12 +309,13 @@ class Context:
             pass
 
 
-def context(n: int) -> Context:
+def context(n: int, real_bytes: int = 4) -> Context:
+    """The context of (current device, n) -- of the fp64 device mode with real_bytes = 8 (pm_real64_* entry points)."""
     torch = require_gpu()
-    key = (torch.cuda.current_device(), int(n))
+    key = (torch.cuda.current_device(), int(n)) if real_bytes == 4 else (torch.cuda.current_device(), int(n), int(real_bytes))
     ctx = _ctxs.get(key)
     if ctx is None:
-        ctx = _ctxs[key] = Context(n)
+        ctx = _ctxs[key] = Context(n, real_bytes)
     ctx.use_current_stream()
     return ctx
 

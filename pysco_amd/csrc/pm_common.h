@@ -119,6 +119,7 @@ struct Stencil {
 // Small device -> host read-back on the context's stream, synchronised: through pinned memory (a copy into pageable
 // memory is staged by the runtime and costs 10-20 us more; the step does five of these at 128^3).
 int pm_read_back(pm_ctx *c, void *h_dst, const void *d_src, size_t bytes);
+void pm_fft_setup_once();  // rocfft_setup(), once per process
 constexpr size_t PM_PINNED_BYTES = 16384;
 
 #endif
@@ -140,6 +141,13 @@ struct pm_ctx {
     rocfft_execution_info pad_info_r2c, pad_info_c2r;
     void *pad_work;
     void *d_spec;  // lazily allocated half-spectrum scratch for pm_poisson_fft
+    // the fp64 device mode (pm_ctx_create_real(..., 8); pm_real64.hip): double-precision plans, spectrum, tables
+    int real_bytes;  // 4 (default) or 8
+    rocfft_plan plan64_r2c, plan64_c2r;
+    rocfft_execution_info info64_r2c, info64_c2r;
+    void *fft64_work, *d_spec64;
+    size_t fft64_work_bytes;
+    double *d_tab64;  // 3 n doubles
     void *fp_B, *fp_C, *fp_tw;  // fused FFT Poisson solve: two transposed half-spectra + twiddle table
     size_t fp_B_bytes, fp_C_bytes;
     float *h_pow;               // host staging of the per-axis sinc^(-2p) table

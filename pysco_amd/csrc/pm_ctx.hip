@@ -18,9 +18,13 @@ extern "C" int pm_version(void) { return 100; }
 
 static std::once_flag g_fft_once;
 
+void pm_fft_setup_once() {
+    std::call_once(g_fft_once, [] { rocfft_setup(); });
+}
+
 static int build_plans(pm_ctx *c) {
     if (c->plan_r2c) return PM_OK;
-    std::call_once(g_fft_once, [] { rocfft_setup(); });
+    pm_fft_setup_once();
     const size_t len[3] = {(size_t)c->n, (size_t)c->n, (size_t)c->n};  // fastest first
     PM_FFT(rocfft_plan_create(&c->plan_r2c, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
                               rocfft_precision_single, 3, len, 1, nullptr));
@@ -47,12 +51,25 @@ static int build_plans(pm_ctx *c) {
     return PM_OK;
 }
 
+// SURVEY.md section 8(b)'s pm_create(N, Np, ngpu, real_bytes): the arithmetic type of a context.  4: the fp32 mode (the
+// reference's precision, every entry point of pmstep.h but the pm_real64_* ones); 8: the fp64 device mode of the
+// Newtonian FFT step (pm_real64_*: arrays of double).
+extern "C" int pm_ctx_create_real(pm_ctx **out, int n, void *stream, int real_bytes) {
+    PM_REQUIRE(real_bytes == 4 || real_bytes == 8, "real_bytes must be 4 (float) or 8 (double)");
+    int rc = pm_ctx_create(out, n, stream);
+    if (rc == PM_OK) (*out)->real_bytes = real_bytes;
+    return rc;
+}
+
+extern "C" int pm_ctx_real_bytes(pm_ctx *c) { return c ? c->real_bytes : 0; }
+
 extern "C" int pm_ctx_create(pm_ctx **out, int n, void *stream) {
     PM_REQUIRE(out != nullptr, "out is NULL");
     PM_REQUIRE(n >= 4 && n <= 16384 && (n & (n - 1)) == 0, "n must be a power of two in [4, 16384]");
     pm_ctx *c = new pm_ctx();
     memset(c, 0, sizeof(*c));
     c->acc_scale_pred = 1.0f;
+    c->real_bytes = 4;
     c->vc_graph_mode = 1, c->mg_fused_coarse = 1, c->fr_rows_sweep = 1, c->fr_march_gradient = 1;
     if (hipHostMalloc(&c->h_pinned, PM_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) c->h_pinned = nullptr, (void)hipGetLastError();
     c->n = n;
@@ -88,6 +105,13 @@ extern "C" int pm_ctx_destroy(pm_ctx *c) {
     if (c->pad_info_c2r) rocfft_execution_info_destroy(c->pad_info_c2r);
     if (c->pad_work) hipFree(c->pad_work);
     if (c->d_spec) hipFree(c->d_spec);
+    if (c->plan64_r2c) rocfft_plan_destroy(c->plan64_r2c);
+    if (c->plan64_c2r) rocfft_plan_destroy(c->plan64_c2r);
+    if (c->info64_r2c) rocfft_execution_info_destroy(c->info64_r2c);
+    if (c->info64_c2r) rocfft_execution_info_destroy(c->info64_c2r);
+    if (c->fft64_work) hipFree(c->fft64_work);
+    if (c->d_spec64) hipFree(c->d_spec64);
+    if (c->d_tab64) hipFree(c->d_tab64);
     if (c->fp_B) hipFree(c->fp_B);
     if (c->fp_C) hipFree(c->fp_C);
     if (c->fp_tw) hipFree(c->fp_tw);
@@ -197,7 +221,7 @@ extern "C" int pm_fft_c2r(pm_ctx *c, void *d_xk, float *d_x) {
 // of two -- rocFFT takes any length; the hand-written LDS FFT passes are radix-2 and stay on the mesh sizes).
 static int build_padded_plans(pm_ctx *c) {
     if (c->pad_r2c) return PM_OK;
-    std::call_once(g_fft_once, [] { rocfft_setup(); });
+    pm_fft_setup_once();
     const size_t m = (size_t)c->n * 3 / 2;
     const size_t len[3] = {m, m, m};
     PM_FFT(rocfft_plan_create(&c->pad_r2c, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
@@ -264,7 +288,7 @@ extern "C" int pm_poisson_fft(pm_ctx *c, int kind, int p, const float *d_rhs, fl
 
 static int slab_plan(pm_ctx *c, int which, long long key) {
     if (c->plan_s[which] && c->key_s[which] == key) return PM_OK;
-    std::call_once(g_fft_once, [] { rocfft_setup(); });
+    pm_fft_setup_once();
     if (c->plan_s[which]) {
         PM_HIP(hipStreamSynchronize(c->stream));
         rocfft_plan_destroy(c->plan_s[which]);

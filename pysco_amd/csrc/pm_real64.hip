@@ -1,0 +1,621 @@
+// The fp64 device mode (pm_ctx_create_real(..., real_bytes = 8)): the Newtonian FFT step of PySCo's hot path with
+// every array and every scalar in double -- kick + drift + wrap (integration.py:192-264, utils.py:220-298, 1120-1149),
+// NGP / CIC / TSC deposit (mesh.py:2240-2595), r2c -> Green's function -> c2r (solver.py:453-522, fourier.py:460-595),
+// gradient of order 2 / 3 / 5 / 7 (mesh.py:639-850), inverse interpolation (mesh.py:2600-3088) + second kick + CFL
+// maxima, max_abs (utils.py:410-430) and the binned P(k) (fourier.py:22-100).
+//
+// The reference has no fp64 mode (it is float32 end to end: mesh.py:2467, fourier.py:21); this one exists to state a
+// tolerance between the build's own fp64 CPU and fp64 device paths (BASELINE.md section 6:
+// <= 1e-10), i.e. to separate rounding from algorithmic differences.  Same formulas and operation order as the fp32
+// kernels; the data layout is the fp32 mode's with 8-byte elements ([Np,3] particles, [n,n,n] grids, [n,n,n,3] force).
+//
+// Design for MI355X: the deposit accumulates a workgroup's chunk of the (Morton-sorted) stream in an LDS tile of
+// doubles with ds_add_f64 -- measured at 6.4 lane-operations per clock and CU (tools/micro/lds_atomics.hip), against
+// ~1.3 TB/s of added bytes for memory-side atomics -- and flushes the tile with one global_atomic_add_f64 per touched
+// cell; a chunk that spans several tiles re-anchors the tile, particles outside the first few tiles go straight to
+// global atomics: the result never depends on the order of the stream, only the speed does.  The gather differentiates
+// nothing on the fly: the force grid is written once ([n,n,n,3] doubles: 3.2 GB at 512^3) and a workgroup stages the
+// 10 x 18 x 18 force tile of its chunk in LDS (3 x 25.9 KB).  rocFFT double-precision plans do the transforms.
+#include "pm_common.h"
+
+#define BLK 256
+
+namespace {
+
+constexpr int TI = 8, TJ = 16, TK = 16, LI = 3, LJ = 4, LK = 4;  // tile of 8 x 16 x 16 cells: 2048 Morton codes
+constexpr int HI = TI + 2, HJ = TJ + 2, HK = TK + 2;
+constexpr int TILE = HI * HJ * HK;   // 3240 cells with the one-cell halo TSC / CIC reach
+constexpr int PPT = 8, CHUNK = BLK * PPT, MAX_PASSES = 6;
+
+__device__ __forceinline__ int cell_of(double xp, int n) {
+    const int i = (int)xp;  // np.int16(x_part): truncation (mesh.py:2506)
+    return min(max(i, 0), n - 1);
+}
+
+__device__ __forceinline__ void tsc_weights(double xp, int i, double w[3]) {  // mesh.py:2510-2520
+    const double d = xp - 0.5 - (double)i;
+    w[1] = 0.75 - d * d;
+    const double a = 0.5 - d, b = 0.5 + d;
+    w[0] = 0.5 * (a * a);
+    w[2] = 0.5 * (b * b);
+}
+
+__device__ __forceinline__ void cic_weights(double xp, int i, double &w0, double &w1, int &sgn) {  // mesh.py:2312-2330
+    const double d = xp - 0.5 - (double)i;
+    sgn = (d > 0.0) - (d < 0.0);
+    w1 = fabs(d);
+    w0 = 1.0 - w1;
+}
+
+__device__ __forceinline__ int64_t cell_index(int n, int log2n, int i, int j, int k) {
+    const int m = n - 1;
+    return ((((int64_t)(i & m) << log2n) + (j & m)) << log2n) + (k & m);
+}
+
+__device__ __forceinline__ double wrap01(double y) {  // utils.py:1120-1149 (eps is a Python float there too)
+    const double eps = -(1.0 / 33554432.0) * (1.0 + 1e-6);
+    if (y < 0.0) return y > eps ? 0.0 : y + 1.0;
+    return y >= 1.0 ? y - 1.0 : y;
+}
+
+// ---- kick + drift + wrap ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void kdw64_kernel(double *__restrict__ pos, double *__restrict__ vel,
+                                                    const double *__restrict__ acc, double mhalf_dt, double dt, int64_t n3) {
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < n3; t += (int64_t)gridDim.x * BLK) {
+        const double v = vel[t] + mhalf_dt * acc[t];  // y += a * x (utils.py:297): product and sum rounded separately
+        vel[t] = v;
+        pos[t] = wrap01(pos[t] + dt * v);
+    }
+}
+
+__global__ __launch_bounds__(BLK) void axpb64_kernel(double *__restrict__ x, double a, double b, int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < n; t += (int64_t)gridDim.x * BLK) x[t] = a * x[t] + b;
+}
+
+// integer order of the bit patterns == order of the magnitudes, NaN on top (np.max(np.abs(x)) propagates NaN)
+__global__ __launch_bounds__(BLK) void maxabs64_kernel(const double *__restrict__ x, int64_t n, unsigned long long *out) {
+    unsigned long long m = 0;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < n; t += (int64_t)gridDim.x * BLK)
+        m = max(m, (unsigned long long)__double_as_longlong(x[t]) & 0x7fffffffffffffffull);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned long long)__shfl_down((long long)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
+}
+
+// ---- deposit ------------------------------------------------------------------------------------------------------
+struct Tile {
+    int ti, tj, tk;
+};
+
+template <int SCHEME>
+__device__ __forceinline__ void deposit_global(double xp, double yp, double zp, int i, int j, int k, int n, int log2n,
+                                               double *rho) {
+    auto at = [&](int a, int b, int c) { return rho + cell_index(n, log2n, a, b, c); };
+    if (SCHEME == PM_NGP) {
+        atomicAdd(at(i, j, k), 1.0);
+    } else if (SCHEME == PM_CIC) {
+        double wx[2], wy[2], wz[2];
+        int sx, sy, sz;
+        cic_weights(xp, i, wx[0], wx[1], sx), cic_weights(yp, j, wy[0], wy[1], sy), cic_weights(zp, k, wz[0], wz[1], sz);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) atomicAdd(at(i + a * sx, j + b * sy, k + c * sz), wx[a] * wy[b] * wz[c]);
+    } else {
+        double wx[3], wy[3], wz[3];
+        tsc_weights(xp, i, wx), tsc_weights(yp, j, wy), tsc_weights(zp, k, wz);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const double wxy = wx[a] * wy[b];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) atomicAdd(at(i + a - 1, j + b - 1, k + c - 1), wxy * wz[c]);
+            }
+    }
+}
+
+template <int SCHEME>
+__device__ __forceinline__ void deposit_lds(double xp, double yp, double zp, int i, int j, int k, const Tile &t, double *tile) {
+    const int li = i - t.ti * TI + 1, lj = j - t.tj * TJ + 1, lk = k - t.tk * TK + 1;
+    auto at = [&](int a, int b, int c) { return tile + ((li + a) * HJ + (lj + b)) * HK + (lk + c); };
+    if (SCHEME == PM_NGP) {
+        atomicAdd(at(0, 0, 0), 1.0);
+    } else if (SCHEME == PM_CIC) {
+        double wx[2], wy[2], wz[2];
+        int sx, sy, sz;
+        cic_weights(xp, i, wx[0], wx[1], sx), cic_weights(yp, j, wy[0], wy[1], sy), cic_weights(zp, k, wz[0], wz[1], sz);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) atomicAdd(at(a * sx, b * sy, c * sz), wx[a] * wy[b] * wz[c]);
+    } else {
+        double wx[3], wy[3], wz[3];
+        tsc_weights(xp, i, wx), tsc_weights(yp, j, wy), tsc_weights(zp, k, wz);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const double wxy = wx[a] * wy[b];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) atomicAdd(at(a - 1, b - 1, c - 1), wxy * wz[c]);
+            }
+    }
+}
+
+// the tile of the first still-unserved particle of the chunk (uniform); false when nothing is left
+__device__ __forceinline__ bool next_anchor(unsigned todo, const double *chunk_pos, double nf, int n, int *s_first,
+                                            int *s_anchor, Tile &t) {
+    const int tid = threadIdx.x;
+    if (tid == 0) *s_first = 0x7fffffff;
+    __syncthreads();
+    if (todo) atomicMin(s_first, (__ffs((int)todo) - 1) * BLK + tid);
+    __syncthreads();
+    const int first = *s_first;
+    if (first == 0x7fffffff) return false;
+    if (tid == 0) {
+        const double *q = chunk_pos + 3 * first;
+        s_anchor[0] = cell_of(q[0] * nf, n) >> LI, s_anchor[1] = cell_of(q[1] * nf, n) >> LJ, s_anchor[2] = cell_of(q[2] * nf, n) >> LK;
+    }
+    __syncthreads();
+    t.ti = s_anchor[0], t.tj = s_anchor[1], t.tk = s_anchor[2];
+    return true;
+}
+
+template <int SCHEME>
+__global__ __launch_bounds__(BLK) void deposit64_kernel(const double *__restrict__ pos, int64_t np, int n, int log2n,
+                                                        double *__restrict__ rho) {
+    __shared__ double tile[TILE];  // 25.9 KB
+    __shared__ int s_first, s_anchor[3];
+    const int tid = threadIdx.x;
+    const double nf = (double)n;
+    for (int c = tid; c < TILE; c += BLK) tile[c] = 0.0;
+    const int64_t base = (int64_t)blockIdx.x * CHUNK;
+    unsigned todo = 0;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r)
+        if (base + r * BLK + tid < np) todo |= 1u << r;
+    Tile t;
+    const bool tiled = n >= 16;
+    for (int pass = 0; tiled && pass < MAX_PASSES; ++pass) {
+        if (!next_anchor(todo, pos + 3 * base, nf, n, &s_first, s_anchor, t)) break;
+#pragma unroll 1
+        for (int r = 0; r < PPT; ++r)
+            if (todo >> r & 1u) {
+                const double *q = pos + 3 * (base + r * BLK + tid);
+                const double xp = q[0] * nf, yp = q[1] * nf, zp = q[2] * nf;
+                const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+                if ((i >> LI) == t.ti && (j >> LJ) == t.tj && (k >> LK) == t.tk) {
+                    deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
+                    todo &= ~(1u << r);
+                }
+            }
+        __syncthreads();
+        for (int c = tid; c < TILE; c += BLK) {  // flush: one global atomic per touched cell, rows of 18 along k
+            const double v = tile[c];
+            if (v != 0.0) {
+                const int lk = c % HK, lij = c / HK, lj = lij % HJ, li = lij / HJ;
+                atomicAdd(rho + cell_index(n, log2n, t.ti * TI - 1 + li, t.tj * TJ - 1 + lj, t.tk * TK - 1 + lk), v);
+                tile[c] = 0.0;
+            }
+        }
+    }
+#pragma unroll 1
+    for (int r = 0; r < PPT; ++r)  // what the tiles did not take (an unsorted stream): straight to global atomics
+        if (todo >> r & 1u) {
+            const double *q = pos + 3 * (base + r * BLK + tid);
+            const double xp = q[0] * nf, yp = q[1] * nf, zp = q[2] * nf;
+            deposit_global<SCHEME>(xp, yp, zp, cell_of(xp, n), cell_of(yp, n), cell_of(zp, n), n, log2n, rho);
+        }
+}
+
+// ---- Green's function (fourier.py:460-595) ------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(BLK) void greens64_kernel(double2 *__restrict__ x, int n, int p, const double *__restrict__ k2,
+                                                       const double *__restrict__ s, double c0) {
+    const int nh = (n >> 1) + 1;
+    const int64_t total = (int64_t)n * n * nh;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t % nh);
+        const int64_t ij = t / nh;
+        const int j = (int)(ij % n), i = (int)(ij / n);
+        double g;
+        if (KIND == PM_GREEN_7PT) {
+            g = c0 / ((s[i] + s[j]) + s[k]);
+        } else {
+            const double invk2 = c0 / ((k2[i] + k2[j]) + k2[k]);
+            g = KIND == PM_GREEN_COMPENSATED ? pow((s[i] * s[j]) * s[k], (double)(-2 * p)) * invk2 : invk2;
+        }
+        double2 v = x[t];
+        if (t == 0) v = make_double2(0.0, 0.0);  // x[0,0,0] = 0 (fourier.py:491, 544, 595)
+        else v.x *= g, v.y *= g;
+        x[t] = v;
+    }
+}
+
+// ---- gradient (mesh.py:639-850): [n,n,n] -> [n,n,n,3] -------------------------------------------------------------
+template <int ORDER>
+__device__ __forceinline__ double stencil64(const double *a, double scale) {  // a[3] is the centre
+    if (ORDER == 2) return scale * (-a[3] + a[4]);
+    if (ORDER == 3) return scale * (-a[2] + a[4]);
+    if (ORDER == 5) return scale * (8.0 * (-a[2] + a[4]) + a[1] - a[5]);
+    return scale * (45.0 * (-a[2] + a[4]) + 9.0 * (a[1] - a[5]) - a[0] + a[6]);
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(BLK) void gradient64_kernel(const double *__restrict__ phi, int n, int log2n,
+                                                         double *__restrict__ force) {
+    constexpr int R = (ORDER == 2 || ORDER == 3) ? 1 : (ORDER == 5 ? 2 : 3);
+    const double scale = ORDER == 2 ? (double)n : (ORDER == 3 ? 0.5 * n : (ORDER == 5 ? n / 12.0 : n / 60.0));
+    const int64_t total = (int64_t)n * n * n;
+    const int m = n - 1;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        const int k = (int)(t & m), j = (int)((t >> log2n) & m), i = (int)(t >> (2 * log2n));
+        double a[7];
+#pragma unroll
+        for (int o = 0; o < 7; ++o) a[o] = 0.0;
+#pragma unroll
+        for (int o = -R; o <= R; ++o) a[o + 3] = phi[cell_index(n, log2n, i + o, j, k)];
+        const double gx = stencil64<ORDER>(a, scale);
+#pragma unroll
+        for (int o = -R; o <= R; ++o) a[o + 3] = phi[cell_index(n, log2n, i, j + o, k)];
+        const double gy = stencil64<ORDER>(a, scale);
+#pragma unroll
+        for (int o = -R; o <= R; ++o) a[o + 3] = phi[cell_index(n, log2n, i, j, k + o)];
+        const double gz = stencil64<ORDER>(a, scale);
+        force[3 * t] = gx, force[3 * t + 1] = gy, force[3 * t + 2] = gz;
+    }
+}
+
+// ---- gather + second kick + CFL maxima ----------------------------------------------------------------------------
+// 27 (8, 1) cells read through `at(a, b, c, m)`, summed in the reference's left-to-right order (mesh.py:3058-3086)
+template <int SCHEME, class F>
+__device__ __forceinline__ void gather27(double xp, double yp, double zp, int i, int j, int k, F at, double acc[3]) {
+    if (SCHEME == PM_NGP) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[m] = at(0, 0, 0, m);
+    } else if (SCHEME == PM_CIC) {
+        double wx[2], wy[2], wz[2];
+        int sx, sy, sz;
+        cic_weights(xp, i, wx[0], wx[1], sx), cic_weights(yp, j, wy[0], wy[1], sy), cic_weights(zp, k, wz[0], wz[1], sz);
+        bool first = true;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const double w = wx[a] * wy[b] * wz[c];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) acc[m] = first ? w * at(a * sx, b * sy, c * sz, m) : acc[m] + w * at(a * sx, b * sy, c * sz, m);
+                    first = false;
+                }
+    } else {
+        double wx[3], wy[3], wz[3];
+        tsc_weights(xp, i, wx), tsc_weights(yp, j, wy), tsc_weights(zp, k, wz);
+        bool first = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const double wxy = wx[a] * wy[b];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double w = wxy * wz[c];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) acc[m] = first ? w * at(a - 1, b - 1, c - 1, m) : acc[m] + w * at(a - 1, b - 1, c - 1, m);
+                    first = false;
+                }
+            }
+    }
+}
+
+template <int SCHEME, bool KICK>
+__global__ __launch_bounds__(BLK) void interp64_kernel(const double *__restrict__ force, const double *__restrict__ pos,
+                                                       int64_t np, int n, int log2n, double *__restrict__ out,
+                                                       double *__restrict__ vel, double mhalf_dt,
+                                                       unsigned long long *__restrict__ maxbits) {
+    extern __shared__ double tile[];  // [3][TILE]: 77.8 KB (two workgroups per CU)
+    __shared__ int s_first, s_anchor[3];
+    const int tid = threadIdx.x;
+    const double nf = (double)n;
+    const int64_t base = (int64_t)blockIdx.x * CHUNK;
+    unsigned todo = 0;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r)
+        if (base + r * BLK + tid < np) todo |= 1u << r;
+    unsigned long long ma = 0, mv = 0;
+    auto finish = [&](int64_t p, const double a[3]) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            out[3 * p + m] = a[m];
+            ma = max(ma, (unsigned long long)__double_as_longlong(a[m]) & 0x7fffffffffffffffull);
+            if (KICK) {
+                const double v = vel[3 * p + m] + mhalf_dt * a[m];
+                vel[3 * p + m] = v;
+                mv = max(mv, (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull);
+            }
+        }
+    };
+    Tile t;
+    const bool tiled = n >= 16;
+    for (int pass = 0; tiled && pass < MAX_PASSES; ++pass) {
+        if (!next_anchor(todo, pos + 3 * base, nf, n, &s_first, s_anchor, t)) break;  // (its barriers also close the last pass's reads)
+        for (int f = tid; f < 3 * TILE; f += BLK) {  // consecutive lanes, consecutive doubles of a row of 18 x 3
+            const int c = f / 3, m = f - 3 * c;
+            const int lk = c % HK, lij = c / HK, lj = lij % HJ, li = lij / HJ;
+            tile[m * TILE + c] = force[3 * cell_index(n, log2n, t.ti * TI - 1 + li, t.tj * TJ - 1 + lj, t.tk * TK - 1 + lk) + m];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < PPT; ++r)
+            if (todo >> r & 1u) {
+                const int64_t p = base + r * BLK + tid;
+                const double xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
+                const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+                if ((i >> LI) == t.ti && (j >> LJ) == t.tj && (k >> LK) == t.tk) {
+                    const int c0 = ((i - t.ti * TI + 1) * HJ + (j - t.tj * TJ + 1)) * HK + (k - t.tk * TK + 1);
+                    double a[3];
+                    gather27<SCHEME>(xp, yp, zp, i, j, k,
+                                     [&](int da, int db, int dc, int m) { return tile[m * TILE + c0 + (da * HJ + db) * HK + dc]; }, a);
+                    finish(p, a);
+                    todo &= ~(1u << r);
+                }
+            }
+    }
+#pragma unroll 1
+    for (int r = 0; r < PPT; ++r)  // what the tiles did not take: through L2
+        if (todo >> r & 1u) {
+            const int64_t p = base + r * BLK + tid;
+            const double xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
+            const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+            double a[3];
+            gather27<SCHEME>(xp, yp, zp, i, j, k,
+                             [&](int da, int db, int dc, int m) { return force[3 * cell_index(n, log2n, i + da, j + db, k + dc) + m]; }, a);
+            finish(p, a);
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        ma = max(ma, (unsigned long long)__shfl_down((long long)ma, off, 64));
+        mv = max(mv, (unsigned long long)__shfl_down((long long)mv, off, 64));
+    }
+    if ((tid & 63) == 0) {
+        if (ma > __atomic_load_n(maxbits, __ATOMIC_RELAXED)) atomicMax(maxbits, ma);
+        if (KICK && mv > __atomic_load_n(maxbits + 1, __ATOMIC_RELAXED)) atomicMax(maxbits + 1, mv);
+    }
+}
+
+// ---- P(k) (fourier.py:22-100), every product and sum in double -----------------------------------------------------
+__global__ __launch_bounds__(BLK) void pk64_kernel(const double2 *__restrict__ x, int n, int log2n, int p,
+                                                   const double *__restrict__ sincs, double *__restrict__ hist) {
+    extern __shared__ double lds[];  // 3 n: ksum, pksum, nmodes
+    for (int b = threadIdx.x; b < 3 * n; b += BLK) lds[b] = 0.0;
+    __syncthreads();
+    const int nh = (n >> 1) + 1, middle = n >> 1, mask = n - 1;
+    const int64_t total = (int64_t)n * n * nh;
+    for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLK) {
+        if (t == 0) continue;  // the k = 0 mode is skipped (fourier.py:80-82)
+        const int k = (int)(t % nh);
+        const int64_t ij = t / nh;
+        const int j = (int)(ij & mask), i = (int)(ij >> log2n);
+        const double kx = (i >= middle) ? (double)(i - n) : (double)i, ky = (j >= middle) ? (double)(j - n) : (double)j;
+        const double kz = (double)k;
+        const double comp = pow((sincs[i] * sincs[j]) * sincs[k], (double)(-2 * p));
+        const double2 v = x[t];
+        const double knorm = sqrt((kx * kx + ky * ky) + kz * kz);
+        const int kidx = (int)(knorm + 0.5);
+        atomicAdd(&lds[kidx], knorm);
+        atomicAdd(&lds[n + kidx], (v.x * v.x + v.y * v.y) * comp);
+        atomicAdd(&lds[2 * n + kidx], 1.0);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 3 * n; b += BLK)
+        if (lds[b] != 0.0) atomicAdd(&hist[b], lds[b]);
+}
+
+int blocks_for(int64_t items, int per_block) {
+    int64_t b = (items + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > 262144 ? 262144 : b));
+}
+
+int build_plans64(pm_ctx *c) {
+    if (c->plan64_r2c) return PM_OK;
+    pm_fft_setup_once();
+    const size_t len[3] = {(size_t)c->n, (size_t)c->n, (size_t)c->n};
+    PM_FFT(rocfft_plan_create(&c->plan64_r2c, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                              rocfft_precision_double, 3, len, 1, nullptr));
+    rocfft_plan_description d = nullptr;
+    PM_FFT(rocfft_plan_description_create(&d));
+    // ifft_3D_real carries 1/n^3 (np.fft.irfftn, fourier.py:277)
+    PM_FFT(rocfft_plan_description_set_scale_factor(d, 1.0 / ((double)c->n * c->n * c->n)));
+    PM_FFT(rocfft_plan_create(&c->plan64_c2r, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                              rocfft_precision_double, 3, len, 1, d));
+    PM_FFT(rocfft_plan_description_destroy(d));
+    size_t w1 = 0, w2 = 0;
+    PM_FFT(rocfft_plan_get_work_buffer_size(c->plan64_r2c, &w1));
+    PM_FFT(rocfft_plan_get_work_buffer_size(c->plan64_c2r, &w2));
+    c->fft64_work_bytes = w1 > w2 ? w1 : w2;
+    if (c->fft64_work_bytes) PM_HIP(hipMalloc(&c->fft64_work, c->fft64_work_bytes));
+    PM_FFT(rocfft_execution_info_create(&c->info64_r2c));
+    PM_FFT(rocfft_execution_info_create(&c->info64_c2r));
+    if (c->fft64_work_bytes) {
+        PM_FFT(rocfft_execution_info_set_work_buffer(c->info64_r2c, c->fft64_work, c->fft64_work_bytes));
+        PM_FFT(rocfft_execution_info_set_work_buffer(c->info64_c2r, c->fft64_work, c->fft64_work_bytes));
+    }
+    const size_t nspec = (size_t)c->n * c->n * (c->n / 2 + 1);
+    PM_HIP(hipMalloc(&c->d_spec64, nspec * 2 * sizeof(double)));
+    PM_HIP(hipMalloc((void **)&c->d_tab64, 3 * (size_t)c->n * sizeof(double)));
+    return PM_OK;
+}
+
+int fft64(pm_ctx *c, bool forward, void *in, void *out) {
+    // (rocFFT reads the stream from the execution info: set on every call, the caller may have changed it)
+    rocfft_execution_info info = forward ? c->info64_r2c : c->info64_c2r;
+    PM_FFT(rocfft_execution_info_set_stream(info, c->stream));
+    void *i[1] = {in}, *o[1] = {out};
+    PM_FFT(rocfft_execute(forward ? c->plan64_r2c : c->plan64_c2r, i, o, info));
+    return PM_OK;
+}
+
+}  // namespace
+
+#define PM_REQUIRE_F64(c) PM_REQUIRE((c) && (c)->real_bytes == 8, "this context was not created with real_bytes = 8 (pm_ctx_create_real)")
+
+extern "C" int pm_real64_kick_drift_wrap(pm_ctx *c, double *d_pos, double *d_vel, const double *d_acc, double half_dt,
+                                         double dt, int64_t np) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(d_pos && d_vel && d_acc && np >= 0, "bad argument");
+    if (np == 0) return PM_OK;
+    hipLaunchKernelGGL(kdw64_kernel, dim3(blocks_for(3 * np, BLK * 4)), dim3(BLK), 0, c->stream, d_pos, d_vel, d_acc, -half_dt,
+                       dt, 3 * np);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+extern "C" int pm_real64_scale_add(pm_ctx *c, double *d_x, double a, double b, int64_t n) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(d_x && n >= 0, "bad argument");
+    if (n == 0) return PM_OK;
+    hipLaunchKernelGGL(axpb64_kernel, dim3(blocks_for(n, BLK * 4)), dim3(BLK), 0, c->stream, d_x, a, b, n);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+extern "C" int pm_real64_max_abs(pm_ctx *c, const double *d_x, int64_t n, double *h_out) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(d_x && h_out && n > 0, "bad argument");
+    unsigned long long *d_bits = reinterpret_cast<unsigned long long *>(c->d_scratch + 48);
+    PM_HIP(hipMemsetAsync(d_bits, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(maxabs64_kernel, dim3(blocks_for(n, BLK * 8)), dim3(BLK), 0, c->stream, d_x, n, d_bits);
+    PM_LAUNCH_CHECK();
+    return pm_read_back(c, h_out, d_bits, sizeof(double));
+}
+
+extern "C" int pm_real64_deposit(pm_ctx *c, int scheme, const double *d_pos, int64_t np, double *d_rho) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(d_pos && d_rho && np >= 0, "bad argument");
+    const int n = c->n;
+    PM_HIP(hipMemsetAsync(d_rho, 0, (size_t)n * n * n * sizeof(double), c->stream));
+    if (np == 0) return PM_OK;
+    const dim3 grid((unsigned)((np + CHUNK - 1) / CHUNK));
+    switch (scheme) {
+        case PM_NGP: hipLaunchKernelGGL((deposit64_kernel<PM_NGP>), grid, dim3(BLK), 0, c->stream, d_pos, np, n, c->log2n, d_rho); break;
+        case PM_CIC: hipLaunchKernelGGL((deposit64_kernel<PM_CIC>), grid, dim3(BLK), 0, c->stream, d_pos, np, n, c->log2n, d_rho); break;
+        case PM_TSC: hipLaunchKernelGGL((deposit64_kernel<PM_TSC>), grid, dim3(BLK), 0, c->stream, d_pos, np, n, c->log2n, d_rho); break;
+        default: pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme); return PM_EINVAL;
+    }
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+extern "C" int pm_real64_poisson_fft(pm_ctx *c, int kind, int p, const double *d_rhs, double *d_phi, const double *h_k2,
+                                     const double *h_s, double c0) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(d_rhs && d_phi && h_k2 && h_s, "NULL argument");
+    int rc = build_plans64(c);
+    if (rc) return rc;
+    const int n = c->n;
+    rc = fft64(c, true, const_cast<double *>(d_rhs), c->d_spec64);  // (rocFFT's not-in-place real transforms may overwrite their input: callers pass a density they no longer need)
+    if (rc) return rc;
+    PM_HIP(hipMemcpyAsync(c->d_tab64, h_k2, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PM_HIP(hipMemcpyAsync(c->d_tab64 + n, h_s, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int64_t total = (int64_t)n * n * (n / 2 + 1);
+    const dim3 grid(blocks_for(total, BLK * 2));
+    double2 *x = reinterpret_cast<double2 *>(c->d_spec64);
+    switch (kind) {
+        case PM_GREEN_PLAIN: hipLaunchKernelGGL((greens64_kernel<PM_GREEN_PLAIN>), grid, dim3(BLK), 0, c->stream, x, n, p, c->d_tab64, c->d_tab64 + n, c0); break;
+        case PM_GREEN_COMPENSATED: hipLaunchKernelGGL((greens64_kernel<PM_GREEN_COMPENSATED>), grid, dim3(BLK), 0, c->stream, x, n, p, c->d_tab64, c->d_tab64 + n, c0); break;
+        case PM_GREEN_7PT: hipLaunchKernelGGL((greens64_kernel<PM_GREEN_7PT>), grid, dim3(BLK), 0, c->stream, x, n, p, c->d_tab64, c->d_tab64 + n, c0); break;
+        default: pm_set_error("unknown Green's function kind %d", kind); return PM_EINVAL;
+    }
+    PM_LAUNCH_CHECK();
+    return fft64(c, false, c->d_spec64, d_phi);
+}
+
+extern "C" int pm_real64_gradient(pm_ctx *c, int order, const double *d_phi, double *d_force) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(d_phi && d_force, "NULL argument");
+    const int n = c->n;
+    const dim3 grid(blocks_for((int64_t)n * n * n, BLK));
+    switch (order) {
+        case 2: hipLaunchKernelGGL((gradient64_kernel<2>), grid, dim3(BLK), 0, c->stream, d_phi, n, c->log2n, d_force); break;
+        case 3: hipLaunchKernelGGL((gradient64_kernel<3>), grid, dim3(BLK), 0, c->stream, d_phi, n, c->log2n, d_force); break;
+        case 5: hipLaunchKernelGGL((gradient64_kernel<5>), grid, dim3(BLK), 0, c->stream, d_phi, n, c->log2n, d_force); break;
+        case 7: hipLaunchKernelGGL((gradient64_kernel<7>), grid, dim3(BLK), 0, c->stream, d_phi, n, c->log2n, d_force); break;
+        default: pm_set_error("gradient_order=%d, should be 2, 3, 5 or 7", order); return PM_EINVAL;
+    }
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+template <int SCHEME>
+static int interp64_launch(pm_ctx *c, const double *force, const double *pos, int64_t np, double *out, double *vel,
+                           double half_dt, unsigned long long *bits) {
+    const dim3 grid((unsigned)((np + CHUNK - 1) / CHUNK));
+    const size_t lds = 3 * TILE * sizeof(double);
+    if (vel) {
+        PM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&interp64_kernel<SCHEME, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((interp64_kernel<SCHEME, true>), grid, dim3(BLK), lds, c->stream, force, pos, np, c->n, c->log2n, out,
+                           vel, -half_dt, bits);
+    } else {
+        PM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&interp64_kernel<SCHEME, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((interp64_kernel<SCHEME, false>), grid, dim3(BLK), lds, c->stream, force, pos, np, c->n, c->log2n, out,
+                           vel, 0.0, bits);
+    }
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// inv<scheme>_vec of the [n,n,n,3] force at the particles -> d_acc; with d_vel: v += -half_dt * a in the same pass
+// (the second kick of the leapfrog); max|a| and (with d_vel) max|v| come back for the next step's dt criteria.
+extern "C" int pm_real64_interp_kick(pm_ctx *c, int scheme, const double *d_force, const double *d_pos, int64_t np,
+                                     double *d_acc, double *d_vel, double half_dt, double *h_max_acc, double *h_max_vel) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(d_force && d_pos && d_acc && np > 0, "bad argument");
+    unsigned long long *d_bits = reinterpret_cast<unsigned long long *>(c->d_scratch + 48);
+    PM_HIP(hipMemsetAsync(d_bits, 0, 2 * sizeof(unsigned long long), c->stream));
+    int rc;
+    switch (scheme) {
+        case PM_NGP: rc = interp64_launch<PM_NGP>(c, d_force, d_pos, np, d_acc, d_vel, half_dt, d_bits); break;
+        case PM_CIC: rc = interp64_launch<PM_CIC>(c, d_force, d_pos, np, d_acc, d_vel, half_dt, d_bits); break;
+        case PM_TSC: rc = interp64_launch<PM_TSC>(c, d_force, d_pos, np, d_acc, d_vel, half_dt, d_bits); break;
+        default: pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme); return PM_EINVAL;
+    }
+    if (rc) return rc;
+    double m[2] = {0.0, 0.0};
+    if (h_max_acc || h_max_vel) {
+        rc = pm_read_back(c, m, d_bits, sizeof(m));
+        if (rc) return rc;
+    }
+    if (h_max_acc) *h_max_acc = m[0];
+    if (h_max_vel) *h_max_vel = m[1];
+    return PM_OK;
+}
+
+// Binned, window-deconvolved power spectrum of a real grid (fourier.fourier_grid_to_Pk o fourier.fft_3D_real): sums per
+// bin of |k|, of |delta_k|^2 W^(-2p) and of the mode count, n entries each (the caller divides, fourier.py:96-100).
+extern "C" int pm_real64_pk(pm_ctx *c, int p, double *d_rho, const double *h_sinc, double *h_ksum, double *h_pksum,
+                            double *h_nmodes) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(d_rho && h_sinc && h_ksum && h_pksum && h_nmodes, "NULL argument");
+    const int n = c->n;
+    PM_REQUIRE((size_t)3 * n * sizeof(double) <= 64 * 1024, "n too large for the LDS histogram");
+    int rc = build_plans64(c);
+    if (rc) return rc;
+    rc = fft64(c, true, d_rho, c->d_spec64);
+    if (rc) return rc;
+    PM_HIP(hipMemcpyAsync(c->d_tab64 + 2 * n, h_sinc, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PM_HIP(hipMemsetAsync(c->d_hist, 0, 3 * (size_t)n * sizeof(double), c->stream));
+    int blocks = blocks_for((int64_t)n * n * (n / 2 + 1), BLK * 16);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pk64_kernel, dim3(blocks), dim3(BLK), 3 * n * sizeof(double), c->stream,
+                       reinterpret_cast<const double2 *>(c->d_spec64), n, c->log2n, p, c->d_tab64 + 2 * n, c->d_hist);
+    PM_LAUNCH_CHECK();
+    PM_HIP(hipMemcpyAsync(h_ksum, c->d_hist, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipMemcpyAsync(h_pksum, c->d_hist + n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return pm_read_back(c, h_nmodes, c->d_hist + 2 * n, n * sizeof(double));
+}

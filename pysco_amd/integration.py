@@ -61,15 +61,22 @@ def predict_next_step(dt, dt1, dt2, tables, param, t_snap_next, meanabs) -> None
         if t_end < t_snap_next:
             guess = min(guess, float(t_snap_next) - t_end)
         param["_dt_pred"] = guess if np.isfinite(guess) and guess > 0 else None
-    except Exception:  # (tables that cannot be evaluated ahead: fall back to the trend of dt)
+    except (KeyError, IndexError, TypeError, ValueError, ArithmeticError) as err:
+        # (tables that cannot be evaluated ahead, a degenerate criterion: fall back to the trend of dt -- the guess
+        # only decides where particles are FILED, never what is computed)
+        logging.debug(f"no prediction of the next step ({err!r})")
         param["_dt_pred"] = None
 
 
 def integrate(position, velocity, acceleration, potential, additional_field, tables: List, param,
               t_snap_next=np.float32(0)):
     """One step: dt = min(free-fall, CFL, scale-factor criterion), then leapfrog or euler."""
-    from . import slab
+    from . import real64, slab
 
+    if real64.is_float64(position):  # the fp64 device mode (Newtonian FFT step, leapfrog)
+        if slab.active():
+            raise NotImplementedError("the fp64 device mode is single-GPU")
+        return real64.integrate(position, velocity, acceleration, potential, additional_field, tables, param, t_snap_next)
     if slab.active():  # slab-decomposed step: same logic with all-reduced maxima + particle migration
         return slab.get(2 ** int(param["ncoarse"])).integrate(position, velocity, acceleration, potential,
                                                               additional_field, tables, param, t_snap_next)
@@ -139,7 +146,7 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
         from . import slab
 
         ncells_1d = 2 ** int(param["ncoarse"])
-        scheme = {"cic": L.CIC, "tsc": L.TSC}.get(param["mass_scheme"].casefold())
+        scheme = {"ngp": L.NGP, "cic": L.CIC, "tsc": L.TSC}.get(param["mass_scheme"].casefold())  # (mesh.py:2240-2595)
         if (_FUSE_DEPOSIT and scheme is not None and ncells_1d >= 16 and not slab.active()
                 and 0 < position.shape[0] < 2**32):
             # the deposit of pm() rides on the streaming update (pmstep.h: pm_kick_drift_wrap_deposit)

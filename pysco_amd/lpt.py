@@ -6,7 +6,8 @@ with NumPy's generator exactly as the reference draws it (same seed -> same fiel
 the grid -> inverse Laplacian -> displacement = gradient -> particles displaced from the lattice; second order from
 the Hessian products of the first-order potential.  The random numbers and the transfer table are host work (a few
 NumPy calls); every grid operation -- Green's function, k-space gradient / Hessians, FFTs, products, the particle
-displacement -- is a HIP kernel behind the C ABI (include/pmstep.h).  1LPT, 2LPT and 3LPT; de-aliasing is not built.
+displacement -- is a HIP kernel behind the C ABI (include/pmstep.h).  1LPT, 2LPT and 3LPT, with or without the
+reference's `dealiased_ICS` (Orszag's 3/2 rule: `_ProductGrid`).
 """
 from __future__ import annotations
 
@@ -297,4 +298,9 @@ def generate(param, tables):
         snap = dict(param.items()) if not isinstance(param, dict) else dict(param)
         snap["i_snap"] = 0
         iostream.write_snapshot_particles(position, velocity, snap)
+        if snap["output_snapshot_format"].casefold() == "parquet":
+            # the reference's finalise_initial_conditions names the side file of the INITIAL snapshot without the
+            # snapshot number (initial_conditions.py:266-270: output_00000/param_{extra}.txt): written under that
+            # name too, for tools that look for the reference's layout
+            iostream.write_param_file(f"{snap['base']}/output_00000/param_{snap['extra']}.txt", iostream._public(snap))
     return position, velocity

@@ -275,6 +275,8 @@ def run(param) -> None:
     torch = L.require_gpu()
     position = L.to_device(position, torch.float32)
     velocity = L.to_device(velocity, torch.float32)
+    if param.get("particle_id") is True:  # diagnostics: int32 tags 0 .. npart-1 in the order of the initial conditions
+        param["particle_id"] = torch.arange(position.shape[0], dtype=torch.int32, device=position.device)
     try:
         return_state = run_nbody(position, velocity, param, tables, z_out, on_snapshot=iostream.write_snapshot_particles)
     finally:

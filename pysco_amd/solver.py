@@ -42,8 +42,12 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     (mesh.derivative_interp_vec_kick_rebucket); when it did, the dict holds the new "position", "velocity" (and
     "ids" if it came with some) and the returned acceleration is in the new order.
     """
-    from . import slab
+    from . import real64, slab
 
+    if real64.is_float64(position):  # the fp64 device mode (Newtonian FFT step): pm_real64_* entry points
+        if slab.active():
+            raise NotImplementedError("the fp64 device mode is single-GPU")
+        return real64.pm(position, param, potential, additional_field, tables, _kick=_kick)
     if slab.active():  # one process per GPU: x-slab decomposition (no reference counterpart)
         return slab.get(2 ** int(param["ncoarse"])).pm(position, param, potential, additional_field, tables,
                                                        kick=_kick)
@@ -57,9 +61,11 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
     THEORY = param["theory"].casefold()
     pos_d = _dev(position)
 
-    if MASS_SCHEME not in ("cic", "tsc"):
+    # (NGP -- mesh.py:2240-2278, a utility in the reference, which refuses it here, solver.py:80-93 -- runs through the
+    # same fused kernels as an extension the caller has to ask for: param["allow_ngp"]; window exponent 1)
+    if MASS_SCHEME not in ("cic", "tsc") and not (MASS_SCHEME == "ngp" and param.get("allow_ngp", False)):
         raise NotImplementedError(f"{param['mass_scheme']=}, should be 'CIC' or 'TSC'")
-    param["MAS_index"] = 2 if MASS_SCHEME == "cic" else 3
+    param["MAS_index"] = {"ngp": 1, "cic": 2, "tsc": 3}[MASS_SCHEME]
     ctx = L.context(ncells_1d)
     # tile ranges + straggler lists once for the deposit and the gather of these positions (pmstep.h)
     ctx.call("pm_tile_lists", L.ptr(pos_d), pos_d.shape[0])
@@ -71,7 +77,7 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
             # the tiles' k-halo contributions still in a side buffer (pmstep.h: pm_kick_drift_wrap_deposit_khalo)
             density, khalo = _density if isinstance(_density, tuple) else (_density, None)
         else:
-            density = mesh.CIC(pos_d, ncells_1d) if MASS_SCHEME == "cic" else mesh.TSC(pos_d, ncells_1d)
+            density = {"ngp": mesh.NGP, "cic": mesh.CIC, "tsc": mesh.TSC}[MASS_SCHEME](pos_d, ncells_1d)
 
         # Without an f(R) term the force grid is only ever read by the gather: the gather kernel then takes
         # the potential and differentiates its own LDS tile (mesh.derivative_interp_vec_kick), and the
@@ -109,7 +115,7 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
             finally:
                 ctx.call("pm_set_gather_mode", 1)
         else:
-            acceleration = mesh.invCIC_vec(force, pos_d) if MASS_SCHEME == "cic" else mesh.invTSC_vec(force, pos_d)
+            acceleration = {"ngp": mesh.invNGP_vec, "cic": mesh.invCIC_vec, "tsc": mesh.invTSC_vec}[MASS_SCHEME](force, pos_d)
             if _kick is not None:
                 utils.add_vector_scalar_inplace(_kick[0], acceleration, -_kick[1])
         del force
@@ -199,9 +205,11 @@ def _solve_grid(density, param, potential_d, additional_field_d, tables, want_fo
             potential_d = fft(rhs, param)
     elif LINEAR_NEWTON_SOLVER == "full_fft":
         # The reference passes three arguments to the two-argument fft_force (solver.py:181, 200 vs :526-529) and
-        # raises TypeError; param["full_fft_reference_bug"] = True keeps that.  Otherwise the branch does what it
-        # spells out: the potential is left alone, the force comes from fft_force (below).
-        if param.get("full_fft_reference_bug", False):
+        # raises TypeError: that is what this does too unless the caller asks for the working path with
+        # param["full_fft_force"] = True -- the branch as it spells itself out: the force comes from fft_force
+        # (below) and the potential is left ALONE, i.e. it is whatever came in (possibly empty: do not switch to a
+        # solver that warm-starts from it in mid-run).
+        if not param.get("full_fft_force", False):
             raise TypeError("fft_force() takes 2 positional arguments but 3 were given")
     else:
         raise NotImplementedError(

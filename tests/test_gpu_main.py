@@ -33,10 +33,14 @@ def _write_initial_snapshot(param, pos, vel, aexp):
     iostream.write_snapshot_particles(pos, vel, snap)
 
 
-def test_example_run_end_to_end_vs_oracle_loop(tmp_path):
+@pytest.mark.parametrize("policy", ["in_place", "product"])
+def test_example_run_end_to_end_vs_oracle_loop(tmp_path, policy, monkeypatch):
     """examples/param.ini (Newton, 128^3 mesh and particles, TSC, multigrid solver, order-5 gradient, leapfrog): ten
     steps from z = 49 through main.run on the device, snapshots at two redshifts, against the oracle's loop on the
-    same tables.  (Initial conditions: a Zel'dovich-like particle set handed in as snapshot 0.)"""
+    same tables.  (Initial conditions: a Zel'dovich-like particle set handed in as snapshot 0.)
+    policy "in_place": the reference's semantics (arrays updated in place, no re-sort within the run); "product":
+    what main.run does when nothing is said -- prediction + incremental re-sort in every step -- with the snapshots'
+    particles matched to the oracle's through int32 tags recorded as each snapshot is written."""
     import copy
 
     from pysco_amd import cosmotable, iostream
@@ -46,12 +50,27 @@ def test_example_run_end_to_end_vs_oracle_loop(tmp_path):
     pos, vel = zeldovich_particles(n, seed=12, rms_cells=0.3, vel_factor=0.02)
     pos, vel = orc.reorder_particles(pos, vel)  # Morton order: the run then has no reason to permute the particles
     z_out = "[30, 18]"
-    param = _example_param(tmp_path, z_out=z_out, initial_conditions=0, output_snapshot_format="parquet",
-                           rebucket_straggler_fraction=None, n_reorder=1000, reorder_straggler_fraction=1.0)
+    if policy == "in_place":
+        param = _example_param(tmp_path, z_out=z_out, initial_conditions=0, output_snapshot_format="parquet",
+                               rebucket_straggler_fraction=None, n_reorder=1000, reorder_straggler_fraction=1.0)
+    else:
+        param = _example_param(tmp_path, z_out=z_out, initial_conditions=0, output_snapshot_format="parquet")
     _write_initial_snapshot(param, pos, vel, 1.0 / 50)
     ref_param = copy.deepcopy(param)
+    tags = []
+    if policy == "product":
+        param["particle_id"] = True
+        write = iostream.write_snapshot_particles
+
+        def write_and_note(position, velocity, par):
+            tags.append(par["particle_id"].long().cpu().numpy().copy())
+            return write(position, velocity, par)
+
+        monkeypatch.setattr(iostream, "write_snapshot_particles", write_and_note)
     amd_main.run(param)
     assert param["nsteps"] >= 8 and param["i_snap"] == 3
+    if policy == "product":
+        assert len(tags) == 2 and not np.array_equal(tags[-1], np.arange(n**3))  # (the stream WAS permuted)
 
     # the same loop with the oracle (main.py:97-156), same tables
     par = ref_param
@@ -81,6 +100,9 @@ def test_example_run_end_to_end_vs_oracle_loop(tmp_path):
         p_dev, v_dev = iostream.read_snapshot_particles_parquet(f"{d}/particles_{param['extra']}.parquet")
         side = iostream.read_param_file(f"{d}/param_{param['extra']}_{i:05d}.txt")
         assert abs(float(side["aexp"]) - a_ref) < 1e-6 and int(side["i_snap"]) == i
+        if tags:  # back into the order of the initial conditions
+            inv = np.argsort(tags[i - 1])
+            p_dev, v_dev = p_dev[inv], v_dev[inv]
         dd = np.abs(p_dev - p_ref)
         assert np.minimum(dd, 1 - dd).max() < 1e-5  # positions after ten steps
         assert np.abs(v_dev - v_ref).max() < 2e-3 * np.abs(v_ref).max()

@@ -458,8 +458,7 @@ def test_pm_errors(amd, golden):
     for key, val, exc in (("mass_scheme", "NGP", NotImplementedError), ("save_power_spectrum", "maybe", NotImplementedError),
                           ("linear_newton_solver", "cg", NotImplementedError), ("theory", "brans-dicke", NotImplementedError),
                           ("linear_newton_solver", "full_fft", TypeError), ("gradient_stencil_order", 4, ValueError)):
-        if val == "full_fft":
-            base["full_fft_reference_bug"] = True  # the reference's arity bug, kept behind a flag (solver.py:181)
+        # (full_fft: the reference's arity bug, solver.py:181 -- the default here too; param["full_fft_force"] opts in)
         p = dict(base)
         p[key] = val
         with pytest.raises(exc):
@@ -505,6 +504,42 @@ def test_integrate_vs_golden(amd, golden, integ, nsteps, resident):
     with pytest.raises(NotImplementedError):
         param["integrator"] = "rk4"
         amd.integration.integrate(p, v, acc, pot, extra, tables, param, t_next)
+
+
+def test_integrate_vs_golden_with_the_product_loop(amd, golden):
+    """The golden 10-step leapfrog trajectory of the reference once more, the way pysco_amd.main.run_nbody steps it:
+    Morton-sorted stream, next-step prediction and the incremental re-sort in EVERY step (param
+    ["rebucket_straggler_fraction"] = the loop's default), the order policy after every step -- compared with the
+    reference's particles one by one through int32 tags."""
+    from pysco_amd import main as amd_main
+
+    g = golden("integrate_leapfrog")
+    tables = synth_tables()
+    param = param_from_json(g["param0_json"])
+    t = amd.torch
+    p, v = t.from_numpy(g["pos0"].copy()).cuda(), t.from_numpy(g["vel0"].copy()).cuda()
+    order = []
+    p, v = amd.utils.reorder_particles(p, v, _order_out=order)
+    param["particle_id"] = t.arange(p.shape[0], dtype=t.int32, device="cuda")[order[0]].contiguous()
+    param["rebucket_straggler_fraction"] = amd_main.REBUCKET_FRACTION
+    param["nsteps"] = 0
+    acc, pot, extra = amd.solver.pm(p, param, tables=tables)
+    t_next = np.float32(g["t_snap_next"])
+    rebucketed = 0
+    for s in range(10):
+        param["nsteps"] += 1
+        p_in = p
+        p, v, acc, pot, extra = amd.integration.integrate(p, v, acc, pot, extra, tables, param, t_next)
+        rebucketed += int(p.data_ptr() != p_in.data_ptr())  # (the gather wrote a new stream)
+        p, v, acc = amd_main.reorder_policy(p, v, acc, param)
+        assert abs(param["t"] - g["t"][s]) < 1e-6 and abs(param["aexp"] - g["aexp"][s]) < 1e-6
+        assert bool(param["write_snapshot"]) == bool(g["write_snapshot"][s])
+        if s in (0, 9):
+            inv = t.argsort(param["particle_id"].long())
+            d = np.abs(p[inv].cpu().numpy() - g[f"pos_{s+1}"])
+            assert np.minimum(d, 1 - d).max() <= 1e-5
+            np.testing.assert_allclose(v[inv].cpu().numpy(), g[f"vel_{s+1}"], rtol=0, atol=2e-5 * _scale(g[f"vel_{s+1}"]))
+    assert rebucketed >= 8, rebucketed  # the product default: (nearly) every step re-buckets
 
 
 @pytest.mark.parametrize("theory_solver", [("newton", "fft"), ("newton", "fft_7pt"), ("newton", "multigrid")])
@@ -982,8 +1017,8 @@ def test_pm_full_fft_works_and_matches_the_oracle(amd, theory, scheme):
     pos, _ = zeldovich_particles(n, seed=8, rms_cells=0.6)
     tables = bench.synth_tables()
     param, _ = bench.make_param(n, n**3)
-    param.update(linear_newton_solver="full_fft", mass_scheme=scheme, theory=theory, fR_n=1, fR_logfR0=5, boxlen=1000.0,
-                 Npre=2, Npost=1, epsrel=1e-2)
+    param.update(linear_newton_solver="full_fft", full_fft_force=True, mass_scheme=scheme, theory=theory, fR_n=1,
+                 fR_logfR0=5, boxlen=1000.0, Npre=2, Npost=1, epsrel=1e-2)
     amd.utils.set_units(param)
     par_o = dict(param)
     acc_o, pot_o, extra_o = orc.pm(pos, par_o, tables=tables)

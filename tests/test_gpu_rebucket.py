@@ -35,6 +35,8 @@ def _run(n, pos_h, vel_h, steps, rebucket, sort_first=True, scheme="TSC", order=
     integration._PREDICT = predict
     param, tables = bench.make_param(n, pos_h.shape[0], config)
     param["mass_scheme"], param["gradient_stencil_order"] = scheme, order
+    if scheme == "NGP":
+        param["allow_ngp"] = True  # (the reference's pm() refuses NGP; the fused kernels serve it on request)
     if rebucket is not None:
         param["rebucket_straggler_fraction"] = rebucket
     pos, vel = torch.from_numpy(pos_h).cuda(), torch.from_numpy(vel_h).cuda()
@@ -57,7 +59,7 @@ def _run(n, pos_h, vel_h, steps, rebucket, sort_first=True, scheme="TSC", order=
 
 
 @pytest.mark.parametrize("n,npart_1d,scheme,order", [(64, 64, "TSC", 5), (64, 48, "CIC", 3), (32, 64, "TSC", 7),
-                                                     (128, 96, "TSC", 2)])
+                                                     (128, 96, "TSC", 2), (64, 64, "NGP", 5), (32, 48, "NGP", 2)])
 def test_rebucket_steps_match_inplace_steps(n, npart_1d, scheme, order):
     """Four leapfrog steps re-bucketing in every one of them vs the same steps in place: same particles (by tag),
     same positions / velocities / accelerations; the stream comes out tile-sorted; (32, 64): 8 particles per
