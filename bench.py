@@ -130,6 +130,14 @@ def alg_bytes(n, npart):
         "pm_gradient_interp_kick_rebucket": 48.0 * npart + 4.0 * cells,
         "pm_axpy": 36.0 * npart,                     # second kick: read v,a; write v
         "pm_max_abs": 12.0 * npart,                  # CFL reductions (two per step)
+        # the fp64 device mode (8-byte elements; its gradient is a pass of its own: read phi, write F(3))
+        "pm_real64_kick_drift_wrap": 120.0 * npart,
+        "pm_real64_deposit": 24.0 * npart + 8.0 * cells,
+        "pm_real64_scale_add": 16.0 * cells,
+        "pm_real64_poisson_fft": 96.0 * cells,
+        "pm_real64_gradient": 32.0 * cells,
+        "pm_real64_interp_kick": 96.0 * npart + 24.0 * cells,
+        "pm_real64_max_abs": 24.0 * npart,
     }
 
 
@@ -291,7 +299,8 @@ def launch_ranks(n):
 # and a failure there cannot take the headline with it): the other BASELINE.json configs on one GPU and the headline's
 # "clustered" workload (rms displacement 3 cells)
 SECONDARY = [
-    ("newton_fft_512", ["--config", "newton_fft", "--ncells", "512", "--steps", "20", "--warmup", "5"]),   # config 2 (fp32)
+    ("newton_fft_512", ["--config", "newton_fft", "--ncells", "512", "--steps", "20", "--warmup", "5"]),   # config 2 in fp32
+    ("newton_fft_512_f64", ["--config", "newton_fft", "--ncells", "512", "--dtype", "f64", "--steps", "10", "--warmup", "3"]),  # config 2 as stated
     ("newton_mg_128", ["--config", "newton_mg", "--steps", "20", "--warmup", "5"]),                        # config 1
     ("fr_512", ["--config", "fr", "--steps", "8", "--warmup", "3"]),                                       # config 4
     ("mond_512", ["--config", "mond", "--steps", "8", "--warmup", "3"]),                                   # config 5 on one GPU
@@ -371,6 +380,55 @@ def compact(out):
             "stragglers_first_last_max": [ss[0], ss[-1], max(ss)] if ss else None}
 
 
+def cpu_baseline_f64(cpu_n, budget_s=12.0):
+    """The fp64 CPU path (oracle/pysco_oracle_f64.py: the C restatement with REAL = double, OpenMP, numpy's float64 FFT)
+    timed on leapfrog steps of the same workload at cpu_n^3, and the fp64 device mode held against it after the same
+    steps: positions and P(k) (<= 1e-10)."""
+    import torch
+
+    from oracle import pysco_oracle as o32
+    from oracle import pysco_oracle_f64 as o64
+    from pysco_amd import integration, real64, solver
+
+    pos_d, vel_d = zeldovich_device(cpu_n)
+    pos0, vel0 = pos_d.double().cpu().numpy(), vel_d.double().cpu().numpy()
+    del pos_d, vel_d
+    o64.periodic_wrap(pos0)
+    par_c, tables = make_param(cpu_n, cpu_n**3)
+    o32.set_units(par_c)
+    par_g = dict(par_c)
+    pc, vc = pos0.copy(), vel0.copy()
+    ac, _ = o64.pm(pc, par_c)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        pc, vc, ac, _, _ = o64.integrate(pc, vc, ac, tables, par_c, 3e38)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or steps >= 10:
+            break
+    pg, vg = torch.from_numpy(pos0).cuda(), torch.from_numpy(vel0).cuda()
+    ag, phig, exg = solver.pm(pg, par_g, tables=tables)
+    for _ in range(steps):
+        pg, vg, ag, phig, exg = integration.integrate(pg, vg, ag, phig, exg, tables, par_g, 3e38)
+    dx = np.abs(pg.cpu().numpy() - pc)
+    max_dx = float(np.minimum(dx, 1 - dx).max())
+    dens = torch.empty((cpu_n,) * 3, dtype=torch.float64, device="cuda")
+    L_ = __import__("pysco_amd._lib", fromlist=["x"])
+    L_.context(cpu_n, 8).call("pm_real64_deposit", L_.TSC, L_.ptr(pg), pg.shape[0], L_.ptr(dens))
+    par_g["MAS_index"] = 3
+    _, pk_g, _ = real64.power_spectrum(dens, par_g)
+    _, pk_c, _ = o64.pk_of_density(o64.deposit("tsc", pc, cpu_n), 3)
+    pk_c = pk_c * (par_g["boxlen"] / cpu_n**2) ** 3
+    pk_rel = float(np.max(np.abs(pk_g / pk_c - 1)))
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"value": cpu_n**3 * steps / dt, "unit": "particles/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "pk_rel_err": {"value": pk_rel, "max_dx": max_dx, "steps": steps,
+                           "what": f"fp64 device mode vs fp64 CPU path after {steps} leapfrog steps at {cpu_n}^3: max over "
+                                   "bins of |P_dev / P_cpu - 1| and the largest position difference (box units)"},
+            "sample": f"{steps} leapfrog steps at {cpu_n}^3 in {dt:.1f} s with the fp64 CPU path (oracle/pm_oracle.c, REAL = double, "
+                      "OpenMP; numpy float64 FFT)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -383,6 +441,9 @@ def main():
     ap.add_argument("--cpu-ncells", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-placement", action="store_true", help="skip pysco_amd.main.tune_placement (development)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
+                    help="f64: the fp64 device mode of the Newtonian FFT step (BASELINE.json config 2 as stated: float64 "
+                         "arrays, pm_real64_* entry points, 400 B per particle-step)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline only: skip the short legs of the other BASELINE configs / workloads (profiling runs)")
     ap.add_argument("--leg", default="", help=argparse.SUPPRESS)  # a secondary leg run as a child: compact line, no children
@@ -432,6 +493,11 @@ def main():
         torch.cuda.empty_cache()
         pos, vel = sl.migrate(pos, vel)
     pos, vel = utils.reorder_particles(pos, vel)  # Morton-sorted once before timing
+    f64 = args.dtype == "f64"
+    if f64:
+        if world > 1 or args.config != "newton_fft":
+            raise SystemExit("--dtype f64: the fp64 device mode is the single-GPU Newtonian FFT step")
+        pos, vel = pos.double(), vel.double()  # (float64 arrays: solver.pm / integrate dispatch to the fp64 mode)
     L._ctxs.clear()  # drop the sort workspace
     if world > 1:
         slab._slabs.clear()
@@ -440,7 +506,7 @@ def main():
     # the product's own loop body (pysco_amd.main.run_nbody): integrate() + the particle-order policy, with its
     # incremental re-sorts and any full re-sort INSIDE the timed region
     rebucket = pm_main.REBUCKET_FRACTION if args.rebucket_fraction is None else args.rebucket_fraction
-    if world == 1 and rebucket >= 0:
+    if world == 1 and rebucket >= 0 and not f64:  # (the fp64 mode steps in place: chunks of the sorted stream, re-anchored)
         param["rebucket_straggler_fraction"] = rebucket
     acc, phi, extra = solver.pm(pos, param, tables=tables)
     t_far = np.float32(3.0e38)  # no snapshot inside the run: every step takes its own dt
@@ -460,7 +526,7 @@ def main():
     def step(pos, vel, acc, phi, extra):
         param["nsteps"] += 1
         pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, t_far)
-        if world == 1:
+        if world == 1 and not f64:
             pos, vel, acc = pm_main.reorder_policy(pos, vel, acc, param)
             if resort_at and param["nsteps"] == resort_at:  # development: does a fresh full sort change the step time?
                 pos, vel, acc = pm_main._reorder(pos, vel, acc, param)
@@ -490,7 +556,7 @@ def main():
         if world > 1:
             straggler_frac.append(utils.straggler_fraction(n)[0])  # of this rank's stream, as the gather found it
         if world == 1:
-            straggler_frac.append(utils.straggler_fraction(n)[0])
+            straggler_frac.append(None if f64 else utils.straggler_fraction(n)[0])
             dt_series.append((float(param.get("_dt_last", 0.0)), float(param.get("_dt_pred", 0.0) or 0.0)))
         L.profile_mark()
         step_events[i + 1].record()
@@ -553,6 +619,7 @@ def main():
                       "alg_GBps": None if gbs is None else round(gbs, 1)})
     dom = table[0]
     achieved = dom["alg_GBps"] or 0.0
+    b_alg = B_ALG_PER_PARTICLE * (2.0 if f64 else 1.0)  # (200 B per particle-step in fp32, 400 in fp64)
     # HBM bytes the PMC counters saw for the dominant stage's kernels, per launch of the stage, averaged over the
     # timed steps of the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/, tools/pmc_summary.py).
     # Only a summary collected with THIS command line (size, step counts, policy) describes this run: else null.
@@ -568,13 +635,13 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom["stage"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved / (HBM_PEAK / 1e9), 4), "traffic": traffic,
                 "alg_bytes_per_launch": ab.get(dom["stage"], alg_bytes_level(dom["stage"])),
-                "step_frac": round(B_ALG_PER_PARTICLE * npart / (wall / args.steps) / (HBM_PEAK * world), 4),
-                "step_alg_bytes_per_particle": B_ALG_PER_PARTICLE, "stages": table}
+                "step_frac": round(b_alg * npart / (wall / args.steps) / (HBM_PEAK * world), 4),
+                "step_alg_bytes_per_particle": b_alg, "stages": table}
     # the same two figures against what a float4 copy reaches on this GPU (SURVEY.md section 8d asks for both
     # denominators), and the dominant stage's HBM-side rate from the counters
     roofline["peak_copy"] = HBM_COPY / 1e9
     roofline["frac_of_copy"] = round(achieved / (HBM_COPY / 1e9), 4)
-    roofline["step_frac_of_copy"] = round(B_ALG_PER_PARTICLE * npart / (wall / args.steps) / (HBM_COPY * world), 4)
+    roofline["step_frac_of_copy"] = round(b_alg * npart / (wall / args.steps) / (HBM_COPY * world), 4)
     if traffic:
         roofline["traffic_GBps"] = round(traffic / (dom["avg_ms"] * 1e-3) / 1e9, 1)
     if dom["stage"].startswith("pm_gradient_interp_kick_rebucket"):
@@ -587,10 +654,10 @@ def main():
                    "mond": "QUMOND simple, multigrid"}[args.config]
     cycles = {k[len("_vcycles_"):]: round(param.get(k, 0) / max(1, args.steps + args.warmup + 1), 2)
               for k in ("_vcycles_linear", "_vcycles_fas") if k in param}
-    out = {"metric": f"particles pushed/sec (one PM step), {solver_name}, fp32", "value": value,
+    out = {"metric": f"particles pushed/sec (one PM step), {solver_name}, {'fp64' if f64 else 'fp32'}", "value": value,
            "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
+           "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": f"{args.config}: {n}^3 mesh / {n}^3 particles, TSC, "
                                   + ("FFT Poisson (compensated), " if args.config == "newton_fft" else
                                      f"multigrid Npre 2 Npost 1 epsrel 1e-2 (V-cycles per solve-step: {cycles}), ")
@@ -598,6 +665,7 @@ def main():
                                   "Morton-sorted once, then the product loop's order policy inside the timed steps ("
                                   + (f"incremental tile re-sort above {param['rebucket_straggler_fraction']:g} stragglers"
                                      if "rebucket_straggler_fraction" in param else
+                                     "fp64 device mode: in-place steps over re-anchored chunks of the sorted stream" if f64 else
                                      ("every rank's stream re-bucketed by its gather every step"
                                       + (", halo buffer of the fused kick + deposit on the slab" if slab._SLAB_KHALO else "")
                                       if world > 1 and slab._SLAB_REBUCKET else "in-place steps"))
@@ -625,7 +693,12 @@ def main():
         out["straggler_series"] = [round(f, 5) for f in straggler_frac]
         if dt_series:
             out["dt_series"] = [[float(f"{a:.6g}"), float(f"{b:.6g}")] for a, b in dt_series]
-    if not args.no_cpu_baseline and rank == 0 and world == 1:
+    if not args.no_cpu_baseline and rank == 0 and world == 1 and f64:
+        del pos, vel, acc, phi, extra
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline_f64(min(128, n))
+        out["pk_rel_err"], out["pk_steps"] = out["cpu_baseline"]["pk_rel_err"]["value"], out["cpu_baseline"]["pk_rel_err"]["steps"]
+    elif not args.no_cpu_baseline and rank == 0 and world == 1:
         del pos, vel, acc, phi, extra
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(min(args.cpu_ncells, n) if args.config == "newton_fft" else min(128, n),
