@@ -446,6 +446,7 @@ def main():
                          "arrays, pm_real64_* entry points, 400 B per particle-step)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline only: skip the short legs of the other BASELINE configs / workloads (profiling runs)")
+    ap.add_argument("--full-series", action="store_true", help="per_step for EVERY timed step (long runs), not the first / last five")
     ap.add_argument("--leg", default="", help=argparse.SUPPRESS)  # a secondary leg run as a child: compact line, no children
     ap.add_argument("--rebucket-fraction", type=float, default=None,
                     help="param['rebucket_straggler_fraction'] of the timed loop (default: pysco_amd.main's; "
@@ -676,6 +677,8 @@ def main():
     # the first and last five timed steps: straggler fraction (particles outside the tile the sort filed them
     # under) and milliseconds per C-ABI stage, so a drift of the step time with the age of the sort shows
     show = sorted(set(list(range(min(5, args.steps))) + list(range(max(0, args.steps - 5), args.steps))))
+    if args.full_series:
+        show = list(range(args.steps))
     out["per_step"] = [{"step": i + 1, "stragglers": None if not straggler_frac or straggler_frac[i] is None
                         else round(straggler_frac[i], 5),
                         "wall_ms": round(step_events[i].elapsed_time(step_events[i + 1]), 3),

@@ -120,6 +120,9 @@ __device__ __forceinline__ void force_tile_put(float *tile, int c, float gx, flo
     *reinterpret_cast<pm_v2f *>(tile + 2 * c) = pm_v2f{gx, gy};
     tile[PM_FZ + c] = gz;
 }
+#ifndef PM_ROT_CLASSES
+#define PM_ROT_CLASSES 27                             // orders in which the lanes of a dense range walk their 27 cells
+#endif
 constexpr int PM_PPT = 8;                             // particles per thread
 constexpr int PM_CHUNK = BLK * PM_PPT;                // particles per workgroup
 constexpr int PM_MAX_PASSES = 6;
@@ -173,12 +176,49 @@ typedef unsigned long long pm_acc_t;
 __device__ __forceinline__ pm_acc_t acc_of_weight(float w) { return (pm_acc_t)(unsigned)(w * 1073741824.0f); }
 __device__ __forceinline__ float weight_of_acc(pm_acc_t a) { return (float)((double)a * (1.0 / 1073741824.0)); }
 
-template <int SCHEME>
+template <int SCHEME, bool ROTATE = false>
 __device__ __forceinline__ void deposit_lds(float xp, float yp, float zp, int i, int j, int k, const TileId &t,
                                             pm_acc_t *tile) {
     // local coordinates inside the haloed tile: cell (ti*TI-1) is local 0
     const int li = i - t.ti * PM_TI + 1, lj = j - t.tj * PM_TJ + 1, lk = k - t.tk * PM_TK + 1;
     auto at = [&](int a, int b, int c) -> pm_acc_t * { return tile + ((li + a) * PM_HJ + (lj + b)) * PM_HK + (lk + c); };
+    if (ROTATE && SCHEME == PM_TSC) {
+        // Lanes in the same cell (a clustered stream: hundreds of particles per cell) add to the same 27 addresses in
+        // the same 27 instructions, and the LDS serialises them: measured at 1024^3 after 80 steps of the benchmark's
+        // own evolution (61 % of the cells empty, 39 % of the particles in cells of 8 and more) the fused kick + deposit
+        // takes 17.5 ms where conflict-free dummy addresses take 14.1.  Here every lane walks its (b, c) rows in an
+        // order of its own (9 classes by lane), so that lanes of one cell meet 9 times less often: 15.5 ms.  64-bit
+        // integer sums: any order gives the same bits.  (The rotated weights and offsets cost ~60 more vector
+        // instructions per particle -- 0.4 ms on a uniform stream -- so only workgroups with a dense range take this
+        // path: kdw_deposit_kernel.)
+        float wx[3], wy[3], wz[3];
+        tsc_weights(xp, i, wx);
+        tsc_weights(yp, j, wy);
+        tsc_weights(zp, k, wz);
+        const int r = (int)(threadIdx.x & 63u) % PM_ROT_CLASSES, ra = r / 9, rb = (r / 3) % 3, rc = r % 3;
+        float wxr[3], wyr[3], wzr[3];
+        int oa[3], ob[3], oc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            int ia = q + ra, ib = q + rb, ic = q + rc;
+            ia = ia >= 3 ? ia - 3 : ia, ib = ib >= 3 ? ib - 3 : ib, ic = ic >= 3 ? ic - 3 : ic;
+            wxr[q] = ia == 0 ? wx[0] : (ia == 1 ? wx[1] : wx[2]);
+            wyr[q] = ib == 0 ? wy[0] : (ib == 1 ? wy[1] : wy[2]);
+            wzr[q] = ic == 0 ? wz[0] : (ic == 1 ? wz[1] : wz[2]);
+            oa[q] = (ia - 1) * PM_HJ * PM_HK, ob[q] = (ib - 1) * PM_HK, oc[q] = ic - 1;
+        }
+        pm_acc_t *const base = tile + (li * PM_HJ + lj) * PM_HK + lk;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float wxy = wxr[a] * wyr[b];
+                pm_acc_t *const row = base + oa[a] + ob[b];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) atomicAdd(row + oc[c], acc_of_weight(wxy * wzr[c]));
+            }
+        return;
+    }
     if (SCHEME == PM_NGP) {
         atomicAdd(at(0, 0, 0), acc_of_weight(1.0f));
     } else if (SCHEME == PM_CIC) {
@@ -693,7 +733,14 @@ __global__ __launch_bounds__(BLK) void tile_bounds_kernel(const float *__restric
 // first chunk of tile t, and the (rare) further chunks of over-full tiles -- clustered regions, or any
 // range at all when the stream is not sorted -- are dealt to the surplus workgroups through a prefix
 // table, so no workgroup ever loops over more than one chunk.
-constexpr int PM_RANGE_CHUNK = 4096;
+// (8192 since round 3: once the benchmark's own evolution has clustered the particles -- 1024^3, 80 steps: a tenth of
+// the tiles hold more than 4096, a quarter of the particles live in them -- every surplus workgroup stages the
+// tile again (the gather its force tile, the fused kick an accumulator tile it flushes with atomics): 10.5 %
+// surplus workgroups with 4096, 1.5 % with 8192; gather 18.7 -> 18.2 ms, kick + deposit 16.6 -> 16.3, nothing
+// either way on the uniform stream of the first steps)
+constexpr int PM_RANGE_CHUNK = 8192;
+constexpr int PM_SCAN_STAGE = 4096;  // strangers a workgroup of the straggler scan stages in LDS before appending
+constexpr int PM_DENSE_RANGE = 2304;  // particles in a workgroup's range (of a tile of 2048 cells) from which it counts as dense
 
 __global__ __launch_bounds__(BLK) void tile_extra_kernel(const int64_t *__restrict__ start, unsigned ntiles,
                                                          int64_t *__restrict__ extra) {
@@ -808,7 +855,7 @@ struct RbBufs {
 
 static int rebucket_bufs(pm_ctx *c, unsigned ntiles, int64_t np, RbBufs *b) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t maxblocks = (size_t)ntiles + (size_t)(np / 4096) + 2;  // >= nlaunch + np / PM_RANGE_CHUNK + 1
+    const size_t maxblocks = (size_t)ntiles + (size_t)(np / PM_RANGE_CHUNK) + 2;  // >= nlaunch + np / PM_RANGE_CHUNK + 1
     const size_t t32 = up(((size_t)ntiles + 1) * sizeof(unsigned)), t64 = up(((size_t)ntiles + 1) * sizeof(int64_t));
     const size_t w32 = up(maxblocks * 27 * sizeof(unsigned));
     size_t tmp = 0;
@@ -927,11 +974,12 @@ __global__ __launch_bounds__(BLK) void straggler_scan_kernel(const float *__rest
     unsigned key;
     int64_t s, e;
     if (!tile_work_item(work, key, s, e)) return;
-    __shared__ unsigned s_k[PM_RANGE_CHUNK], s_p[PM_RANGE_CHUNK];  // 32 KB
+    __shared__ unsigned s_k[PM_SCAN_STAGE], s_p[PM_SCAN_STAGE];  // 32 KB
     __shared__ unsigned s_cnt, s_base;
     __shared__ unsigned s_hist[27];
     const int tid = threadIdx.x;
     const float nf = (float)n;
+    const unsigned seg0 = (blockIdx.x % PM_NSUB) * subcap;
     const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
     const bool windowed = work.nlaunch != work.ntiles;
     const int w_lo = work.ti0, w_hi = work.ti0 + (1 << work.lnti);
@@ -945,7 +993,12 @@ __global__ __launch_bounds__(BLK) void straggler_scan_kernel(const float *__rest
             const unsigned k = tile_key_of_pos(pos + 3 * p, nf, n);
             if (k != key) {
                 const unsigned slot = atomicAdd(&s_cnt, 1u);
-                s_k[slot] = k, s_p[slot] = (unsigned)p;
+                if (slot < (unsigned)PM_SCAN_STAGE) {
+                    s_k[slot] = k, s_p[slot] = (unsigned)p;
+                } else {  // past the staging area (a range of strangers: an unsorted stream): straight to the global list
+                    const unsigned g = atomicAdd(sub_counter(counts), 1u);
+                    if (g < subcap) keys[seg0 + g] = k, idx[seg0 + g] = (unsigned)p;
+                }
             }
             if (sc.codes) {
                 // the particle's destination code, made safe (a byte the caller owns) and kept inside the window of
@@ -980,11 +1033,11 @@ __global__ __launch_bounds__(BLK) void straggler_scan_kernel(const float *__rest
             atomicAdd(sc.tile_count + tile_key((t.ti + tid / 9 - 1 + Ti) % Ti, (t.tj + (tid / 3) % 3 - 1 + Tj) % Tj,
                                                (t.tk + tid % 3 - 1 + Tk) % Tk), cnt_d);
     }
-    const unsigned cnt = s_cnt;
+    const unsigned cnt = min(s_cnt, (unsigned)PM_SCAN_STAGE);
     if (cnt == 0) return;
     if (tid == 0) s_base = atomicAdd(sub_counter(counts), cnt);
     __syncthreads();
-    const unsigned base = s_base, seg = (blockIdx.x % PM_NSUB) * subcap;
+    const unsigned base = s_base, seg = seg0;
     for (unsigned i = tid; i < cnt; i += BLK)
         if (base + i < subcap) keys[seg + base + i] = s_k[i], idx[seg + base + i] = s_p[i];
 }
@@ -1439,6 +1492,8 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
         const unsigned g = atomicAdd(sub_counter(counts), 1u);
         if (g < subcap) lkeys[seg + g] = k, lidx[seg + g] = p;
     };
+    // a range well above one particle per cell: lanes of a wave share cells (deposit_lds<..., ROTATE>)
+    const bool dense = (e - s) >= PM_DENSE_RANGE;
     // two particles per iteration: 18 dword loads in flight per lane
 #pragma unroll 1
     for (int64_t p0 = s + tid; p0 < e; p0 += 2 * BLK) {
@@ -1473,7 +1528,10 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
 #pragma unroll
                 for (int m = 0; m < 3; ++m) veff[m] = v[u][m] + dc.kick * a[u][m];
                 if (in_tile(i, j, k, t)) {
-                    deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
+                    if (dense)
+                        deposit_lds<SCHEME, true>(xp, yp, zp, i, j, k, t, tile);
+                    else
+                        deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
                     if (dc.dcode) {  // (codes without counts: a slab, whose migration comes before the counting)
                         const DestCode dd = dest_of(x[u], veff, dc.dtp, nf, n, t);
                         dc.dcode[p] = (unsigned char)dd.d;

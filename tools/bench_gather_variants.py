@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--scheme", type=int, default=3)
     ap.add_argument("--order", type=int, default=5)
+    ap.add_argument("--evolve", type=int, default=0, help="take this many steps of the product loop first (a clustered, evolved state)")
+    ap.add_argument("--resort", action="store_true", help="full Morton sort of the evolved stream before measuring")
     ap.add_argument("tags", nargs="+")
     args = ap.parse_args()
     import torch
@@ -42,7 +44,49 @@ def main():
     L._ctxs.clear()
     torch.cuda.empty_cache()
     param, tables = bench.make_param(n, npart)
-    acc, phi, _ = solver.pm(pos, param, tables=tables)
+    acc, phi, extra = solver.pm(pos, param, tables=tables)
+    if args.evolve:
+        from pysco_amd import integration
+        from pysco_amd import main as pm_main
+
+        param["rebucket_straggler_fraction"] = pm_main.REBUCKET_FRACTION
+        pm_main.reserve_step_buffers(pos)
+        L.profile_start()
+        for i in range(args.evolve):
+            param["nsteps"] += 1
+            pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, np.float32(3e38))
+            pos, vel, acc = pm_main.reorder_policy(pos, vel, acc, param)
+            L.profile_mark()
+        st, per = L.profile_stop(per_step=True)
+        print("evolved", args.evolve, "steps; last step stages [ms]:", {k[3:30]: round(v, 3) for k, v in sorted(per[-1].items(), key=lambda kv: -kv[1])[:3]},
+              "dt", param.get("_dt_last"), flush=True)
+        from pysco_amd import mesh as _mesh
+
+        _mesh._rebucket_pool.clear()
+        # how clustered: particles per occupied cell, fraction of empty cells
+        c = (pos * n).to(torch.int32).clamp_(0, n - 1)
+        cell = (c[:, 0].long() * n + c[:, 1].long()) * n + c[:, 2].long()
+        del c
+        cnt = torch.bincount(cell, minlength=n**3)
+        del cell
+        print(f"cells empty {float((cnt == 0).float().mean()):.3f}, max per cell {int(cnt.max())}, particles in cells with >= 8: "
+              f"{float(cnt[cnt >= 8].sum()) / npart:.3f}", flush=True)
+        del cnt
+        c = (pos * n).to(torch.int32).clamp_(0, n - 1)
+        tile = ((c[:, 0] >> 3).long() * (n >> 4) + (c[:, 1] >> 4).long()) * (n >> 4) + (c[:, 2] >> 4).long()
+        del c
+        tc = torch.bincount(tile, minlength=n**3 // 2048)
+        del tile
+        for ch in (4096, 8192, 16384):
+            extra = int(torch.clamp((tc + ch - 1) // ch - 1, min=0).sum())
+            print(f"chunk {ch}: {extra} surplus workgroups on {tc.numel()} tiles ({extra / tc.numel():.3f})")
+        q = torch.tensor([0.1, 0.25, 0.5, 0.75, 0.9, 0.99], device=tc.device)
+        print("particles per tile quantiles", torch.quantile(tc.float(), q).tolist(), "max", int(tc.max()),
+              "tiles under 512:", float((tc < 512).float().mean()), "particles in tiles over 4096:", float(tc[tc > 4096].sum()) / npart, flush=True)
+        del tc
+        if args.resort:
+            pos, vel, acc = utils.reorder_particles(pos, vel, acc)
+            print("re-sorted (Morton)", flush=True)
     L._ctxs.clear()
     torch.cuda.empty_cache()
     sets = [(pos, vel, acc), tuple(torch.empty_like(pos) for _ in range(3))]

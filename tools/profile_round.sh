@@ -11,11 +11,11 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --gpus 1 --steps $STEPS --warmup $WARM "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-secondary "$@" > $OUT/bench.log 2>&1
 grep '^{' $OUT/bench.log | tail -1 > $OUT/bench.json
 if [ -z "$NO_PMC" ]; then
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-cpu-baseline "$@" > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-cpu-baseline "$@" > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-cpu-baseline --no-secondary "$@" > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-cpu-baseline --no-secondary "$@" > $OUT/write.log 2>&1
 rm -f $OUT/fetch/*/*kernel_trace.csv $OUT/write/*/*kernel_trace.csv
 fi
 ls $OUT/*/*
