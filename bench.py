@@ -611,10 +611,22 @@ def main():
         dist.all_gather_object(gathered, {k: v[1] / max(1, v[0]) for k, v in stages.items()})
         rank_spread = {k: [round(min(g.get(k, 0.0) for g in gathered), 4), round(max(g.get(k, 0.0) for g in gathered), 4)]
                        for k in stages}
+    # the solves issued as one C call each (pm_lap_solve / pm_fr_solve: V-cycles + residual norms until the reference's
+    # stopping rule says stop): algorithmic bytes of a call = its average number of cycles x (one V-cycle + one norm)
+    solve_bytes = {}
+    for name, (calls, _ms) in stages.items():
+        base, _, size = name.partition("@")
+        if base in ("pm_lap_solve", "pm_fr_solve") and size:
+            key = "_vcycles_linear" if base == "pm_lap_solve" else "_vcycles_fas"
+            per_cycle = alg_bytes_level(("pm_lap_vcycle@" if base == "pm_lap_solve" else "pm_fr_vcycle@") + size) + 8.0 * float(int(size)) ** 3
+            total_calls = max(1, sum(c for nm, (c, _m) in stages.items() if nm.partition("@")[0] == base))
+            # (cycles counted over warm-up + timed steps + the first pm(); calls over the timed steps: scale by the step counts)
+            cyc = param.get(key, 0) * args.steps / max(1, args.steps + args.warmup + 1) / total_calls
+            solve_bytes[name] = per_cycle * cyc
     table = []
     for name, (calls, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):
         avg = ms / calls
-        per_call = ab.get(name, alg_bytes_level(name))
+        per_call = solve_bytes.get(name, ab.get(name, alg_bytes_level(name)))
         gbs = per_call / (avg * 1e-3) / 1e9 if per_call else None
         table.append({"stage": name, "calls_per_step": calls / args.steps, "avg_ms": round(avg, 4),
                       "alg_GBps": None if gbs is None else round(gbs, 1)})
@@ -635,7 +647,7 @@ def main():
             traffic = pmc.get("stages", {}).get(dom["stage"], {}).get("hbm_bytes_per_call")
     roofline = {"bound": "hbm", "kernel": dom["stage"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved / (HBM_PEAK / 1e9), 4), "traffic": traffic,
-                "alg_bytes_per_launch": ab.get(dom["stage"], alg_bytes_level(dom["stage"])),
+                "alg_bytes_per_launch": solve_bytes.get(dom["stage"], ab.get(dom["stage"], alg_bytes_level(dom["stage"]))),
                 "step_frac": round(b_alg * npart / (wall / args.steps) / (HBM_PEAK * world), 4),
                 "step_alg_bytes_per_particle": b_alg, "stages": table}
     # the same two figures against what a float4 copy reaches on this GPU (SURVEY.md section 8d asks for both

@@ -432,6 +432,14 @@ int pm_fft1d_x(pm_ctx *ctx, void *d_data, int64_t ncolumns, int inverse);
 int pm_greens_slab(pm_ctx *ctx, int kind, int p, void *d_xk, const float *h_k2, const float *h_s, float c0, int j0,
                    int nj);
 
+/* multigrid.linear :57-83 / multigrid.FAS :129-138, the stopping loop included: V-cycles until the residual norm is
+ * under `tolerance` or no longer halves; *h_cycles V-cycles were taken, *h_residual is the last norm.
+ * max_cycles <= 0: unbounded, as the reference. */
+int pm_lap_solve(pm_ctx *ctx, float *d_x, const float *d_b, int n, int npre, int npost, float tolerance, int max_cycles,
+                 int *h_cycles, float *h_residual);
+int pm_fr_solve(pm_ctx *ctx, int fr_n, float *d_x, const float *d_b, float q, int n, int npre, int npost, float tolerance,
+                int max_cycles, int *h_cycles, float *h_residual);
+
 /* ---- the fp64 device mode (pm_create(N, Np, ngpu, real_bytes)) ---------------------------
  * pm_ctx_create_real(..., real_bytes): 4 = pm_ctx_create (the reference's float32, every entry point above);
  * 8 = a context of the fp64 mode of the Newtonian FFT step, served by the pm_real64_* entry points below, which take

@@ -143,6 +143,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_fft2d_c2r": (_vp, _vp, _vp, _i),
     "pm_fft1d_x": (_vp, _vp, _i64, _i),
     "pm_greens_slab": (_vp, _i, _i, _vp, _vp, _vp, _f, _i, _i),
+    "pm_lap_solve": (_vp, _vp, _vp, _i, _i, _i, _f, _i, C.POINTER(_i), C.POINTER(_f)),
+    "pm_fr_solve": (_vp, _i, _vp, _vp, _f, _i, _i, _i, _f, _i, C.POINTER(_i), C.POINTER(_f)),
     # the fp64 device mode (pm_real64.hip)
     "pm_ctx_create_real": (C.POINTER(_vp), _i, _vp, _i),
     "pm_ctx_real_bytes": (_vp,),
@@ -216,7 +218,7 @@ def require_gpu():
 
 # entry points that run on a level of a multigrid hierarchy: position of their grid-size argument (after the context),
 # so that the stage profiler files the calls per level ("pm_lap_gauss_seidel@512")
-_PROFILE_SIZE_ARG = {"pm_lap_gauss_seidel": 2, "pm_lap_smoothing": 2, "pm_fr_vcycle": 4, "pm_lap_vcycle": 2, "pm_lap_restrict_residual": 2, "pm_lap_operator": 2,
+_PROFILE_SIZE_ARG = {"pm_lap_gauss_seidel": 2, "pm_lap_smoothing": 2, "pm_fr_vcycle": 4, "pm_lap_vcycle": 2, "pm_lap_solve": 2, "pm_fr_solve": 4, "pm_lap_restrict_residual": 2, "pm_lap_operator": 2,
                      "pm_lap_residual_error": 2, "pm_prolongation": 2, "pm_restriction": 1, "pm_cubic_gauss_seidel": 4,
                      "pm_quartic_gauss_seidel": 4, "pm_cubic_operator": 4, "pm_quartic_operator": 4,
                      "pm_cubic_residual_error": 3, "pm_quartic_residual_error": 3, "pm_mond_rhs": 2}

@@ -1933,3 +1933,50 @@ extern "C" int pm_mond_rhs_slab(pm_ctx *c, const float *d_pot, float *d_out, int
     PM_CHECK_GRID(n);
     return mond_rhs_launch(c, d_pot, d_out, n, g0, kind, alpha, xr_slab(nx));
 }
+
+// ------------------------------------------------------------------------------------------------
+// The stopping loops of multigrid.linear (multigrid.py:57-83) and multigrid.FAS (:129-138) on this side of the C
+// ABI: V-cycle, residual norm, and the reference's two exits -- the norm is under the tolerance, or it no longer
+// halves (residual_err / residual_error_tmp < 2) -- with one small read-back per cycle and nothing of the host
+// language in between (round 2 ran the loop in Python: a few tens of microseconds of idle device per cycle, which
+// is most of a 128^3 step).  Same kernels, same order, same comparisons in float: the same number of cycles.
+// *h_cycles: V-cycles taken; *h_residual: the last residual norm.  max_cycles <= 0: no bound (the reference's loop).
+
+extern "C" int pm_lap_solve(pm_ctx *c, float *d_x, const float *d_b, int n, int npre, int npost, float tolerance,
+                            int max_cycles, int *h_cycles, float *h_residual) {
+    PM_REQUIRE(c && d_x && d_b && h_cycles && h_residual, "NULL argument");
+    float residual_err = 1e30f, tmp = 0.f;
+    int cycles = 0;
+    while (residual_err > tolerance) {
+        int rc = pm_lap_vcycle(c, d_x, d_b, n, npre, npost);
+        if (rc) return rc;
+        ++cycles;
+        rc = pm_lap_residual_error(c, d_x, d_b, n, &tmp);
+        if (rc) return rc;
+        if (tmp < tolerance || residual_err / tmp < 2.0f) break;
+        residual_err = tmp;
+        if (max_cycles > 0 && cycles >= max_cycles) break;
+    }
+    *h_cycles = cycles, *h_residual = tmp;
+    return PM_OK;
+}
+
+extern "C" int pm_fr_solve(pm_ctx *c, int fr_n, float *d_x, const float *d_b, float q, int n, int npre, int npost,
+                           float tolerance, int max_cycles, int *h_cycles, float *h_residual) {
+    PM_REQUIRE(c && d_x && d_b && h_cycles && h_residual, "NULL argument");
+    PM_REQUIRE(fr_n == 1 || fr_n == 2, "Only f(R) with n = 1 and 2");
+    float residual_err = 1e30f, tmp = 0.f;
+    int cycles = 0;
+    while (residual_err > tolerance) {
+        int rc = pm_fr_vcycle(c, fr_n, d_x, d_b, q, n, npre, npost);
+        if (rc) return rc;
+        ++cycles;
+        rc = fr_n == 1 ? pm_cubic_residual_error(c, d_x, d_b, q, n, &tmp) : pm_quartic_residual_error(c, d_x, d_b, q, n, &tmp);
+        if (rc) return rc;
+        if (tmp < tolerance || residual_err / tmp < 2.0f) break;
+        residual_err = tmp;
+        if (max_cycles > 0 && cycles >= max_cycles) break;
+    }
+    *h_cycles = cycles, *h_residual = tmp;
+    return PM_OK;
+}

@@ -8,6 +8,7 @@ branch (laplacian_reformulated) is unreachable from solver.pm() and raises here.
 """
 from __future__ import annotations
 
+import ctypes as C
 import logging
 
 import numpy as np
@@ -35,6 +36,20 @@ def linear(x, b, param):
             param["tolerance"] = tolerance
     tolerance = param["tolerance_mond"] if mond_pot else param["tolerance"]
     logging.info("Start linear Multigrid")
+    n = x.shape[0]
+    if (_NATIVE_VCYCLE and _NATIVE_SOLVE and L.is_device_array(x) and L.is_device_array(b) and n >= 8 and (n & (n - 1)) == 0
+            and param["ncoarse"] == int(np.log2(n)) and str(x.dtype) == "torch.float32"):
+        # the loop below issued from C, one call (pmstep.h: pm_lap_solve): same kernels, same comparisons, same count
+        ctx = L.context(4)
+        if getattr(ctx, "_vcycle_graphs", True) != _VCYCLE_GRAPHS:
+            ctx.call("pm_set_vcycle_graphs", int(_VCYCLE_GRAPHS))
+            ctx._vcycle_graphs = _VCYCLE_GRAPHS
+        cycles, res = C.c_int(0), C.c_float(0)
+        ctx.call("pm_lap_solve", L.ptr(x), L.ptr(b), n, int(param["Npre"]), int(param["Npost"]), float(np.float32(tolerance)), 0,
+                 C.byref(cycles), C.byref(res))
+        param["_vcycles_linear"] = param.get("_vcycles_linear", 0) + cycles.value
+        logging.info(f"residual_error={res.value} {tolerance=} after {cycles.value} V-cycles")
+        return x
     residual_err = 1e30
     while residual_err > tolerance:
         V_cycle(x, b, param)
@@ -48,6 +63,7 @@ def linear(x, b, param):
 
 
 _NATIVE_VCYCLE = True  # tests flip this to compare with the recursion written out below
+_NATIVE_SOLVE = True   # ... and this for the stopping loops written out in linear() / FAS() (pm_lap_solve / pm_fr_solve otherwise)
 _VCYCLE_GRAPHS = True  # False: pm_lap_vcycle issues plain launches instead of replaying captured hipGraphs
 
 
@@ -136,6 +152,15 @@ def FAS(x, b, param):
         param["tolerance_FAS"] = param["epsrel"] * truncation_error(x, param, b)
     tolerance = param["tolerance_FAS"]
     logging.info("Start Full-Approximation Storage Multigrid")
+    n = x.shape[0]
+    if (_NATIVE_VCYCLE and _NATIVE_SOLVE and _is_fr_field(param) and param["fR_n"] in (1, 2) and n >= 8 and (n & (n - 1)) == 0
+            and param["ncoarse"] == int(np.log2(n)) and L.is_device_array(x) and L.is_device_array(b)):
+        cycles, res = C.c_int(0), C.c_float(0)  # (pmstep.h: pm_fr_solve -- the loop below, issued from C)
+        L.context(4).call("pm_fr_solve", int(param["fR_n"]), L.ptr(x), L.ptr(b), float(np.float32(param["fR_q"])), n,
+                          int(param["Npre"]), int(param["Npost"]), float(np.float32(tolerance)), 0, C.byref(cycles), C.byref(res))
+        param["_vcycles_fas"] = param.get("_vcycles_fas", 0) + cycles.value
+        logging.info(f"residual_error={res.value} {tolerance=} after {cycles.value} FAS V-cycles")
+        return x
     residual_err = 1e30
     while residual_err > tolerance:
         V_cycle_FAS(x, b, param)

@@ -642,3 +642,55 @@ def test_mond_rhs_rows_is_the_cell_kernel(amd, kind, alpha):
         ctx.call("pm_set_fr_rows_sweep", 1)
     assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 0
     np.testing.assert_array_equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("n", [16, 64])
+def test_native_solve_loops_are_the_python_loops(amd, golden, n):
+    """pm_lap_solve / pm_fr_solve (the stopping loops of multigrid.linear / multigrid.FAS issued from C: V-cycle, residual
+    norm, "under the tolerance or no longer halving") against the same loops written out in Python: the same number
+    of V-cycles and the same bits; at 16^3 also the reference's converged solve and its tolerance (golden)."""
+    torch = amd.torch
+    rng = np.random.default_rng(3 + n)
+    if n == 16:
+        g = golden("multigrid_n16")
+        base = param_from_json(g["lin_param_json"])
+        base.pop("tolerance", None)
+        x0, b = g["vc_phi0"].copy(), g["vc_rhs"]
+    else:
+        b = rng.normal(size=(n, n, n)).astype(np.float32)
+        b -= b.mean()
+        x0 = orc.lap_initialise_potential(b)
+        base = {"theory": "newton", "compute_additional_field": False, "ncoarse": int(np.log2(n)), "Npre": 2, "Npost": 1,
+                "epsrel": 1e-3, "nsteps": 0}
+    out = {}
+    for native in (True, False):
+        amd.multigrid._NATIVE_SOLVE = native
+        try:
+            param = dict(base)
+            x = torch.from_numpy(x0.copy()).cuda()
+            amd.multigrid.linear(x, torch.from_numpy(b).cuda(), param)
+            out[native] = (x.cpu().numpy(), param["_vcycles_linear"], param["tolerance"])
+        finally:
+            amd.multigrid._NATIVE_SOLVE = True
+    assert out[True][1] == out[False][1] and out[True][1] >= 2          # the same number of V-cycles
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    if n == 16:
+        np.testing.assert_array_equal(out[True][0], g["lin_phi"])        # ... and the reference's converged solve
+    # FAS (the scalaron)
+    gq = torch.Generator(device="cuda")
+    gq.manual_seed(n)
+    dens = torch.rand((n, n, n), generator=gq, device="cuda") * 0.5 + 0.2
+    u0 = torch.rand((n, n, n), generator=gq, device="cuda") * 0.2 + 0.9
+    fas = {}
+    for native in (True, False):
+        amd.multigrid._NATIVE_SOLVE = native
+        try:
+            param = {"Npre": 2, "Npost": 1, "ncoarse": int(np.log2(n)), "fR_n": 1, "fR_q": np.float32(-0.1), "theory": "fr",
+                     "compute_additional_field": True, "epsrel": 1e-3, "nsteps": 0}
+            u = u0.clone()
+            amd.multigrid.FAS(u, dens, param)
+            fas[native] = (u.cpu().numpy(), param["_vcycles_fas"])
+        finally:
+            amd.multigrid._NATIVE_SOLVE = True
+    assert fas[True][1] == fas[False][1] and fas[True][1] >= 1
+    np.testing.assert_array_equal(fas[True][0], fas[False][0])
