@@ -328,14 +328,31 @@ __global__ __launch_bounds__(BLK) void interp64_kernel(const double *__restrict_
     for (int r = 0; r < PPT; ++r)
         if (base + r * BLK + tid < np) todo |= 1u << r;
     unsigned long long ma = 0, mv = 0;
-    auto finish = [&](int64_t p, const double a[3]) {
+    // A thread's particles (r * BLK + tid of the chunk) come through a two-deep register queue -- position, and the
+    // velocity the kick updates, of particles r + 1 and r + 2 are in flight while r is gathered: loaded where they are
+    // used, each particle waits one memory latency for its position and another for its velocity, with only two
+    // workgroups per CU (the 78 KB tile) to hide them: 12.2 ms at 512^3, most of it those waits.
+    struct Slot {
+        double x[3], v[3];
+    };
+    auto load = [&](int r) {
+        Slot q;
+        const int64_t p = min(base + (int64_t)min(r, PPT - 1) * BLK + tid, np - 1);
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
-            out[3 * p + m] = a[m];
+            q.x[m] = __builtin_nontemporal_load(pos + 3 * p + m);
+            q.v[m] = KICK ? __builtin_nontemporal_load(vel + 3 * p + m) : 0.0;
+        }
+        return q;
+    };
+    auto finish = [&](const Slot &q, int64_t p, const double a[3]) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            __builtin_nontemporal_store(a[m], out + 3 * p + m);
             ma = max(ma, (unsigned long long)__double_as_longlong(a[m]) & 0x7fffffffffffffffull);
             if (KICK) {
-                const double v = vel[3 * p + m] + mhalf_dt * a[m];
-                vel[3 * p + m] = v;
+                const double v = q.v[m] + mhalf_dt * a[m];
+                __builtin_nontemporal_store(v, vel + 3 * p + m);
                 mv = max(mv, (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull);
             }
         }
@@ -344,6 +361,7 @@ __global__ __launch_bounds__(BLK) void interp64_kernel(const double *__restrict_
     const bool tiled = n >= 16;  // (measured at 512^3: 13.0 ms tiled, 12.1 ms with every cell read through L2: no contest either way)
     for (int pass = 0; tiled && pass < MAX_PASSES; ++pass) {
         if (!next_anchor(todo, pos + 3 * base, nf, n, &s_first, s_anchor, t)) break;  // (its barriers also close the last pass's reads)
+        Slot q0 = load(0), q1 = load(1);
         for (int f = tid; f < 3 * TILE; f += BLK) {  // consecutive lanes, consecutive doubles of a row of 18 x 3
             const int c = f / 3, m = f - 3 * c;
             const int lk = c % HK, lij = c / HK, lj = lij % HJ, li = lij / HJ;
@@ -351,31 +369,35 @@ __global__ __launch_bounds__(BLK) void interp64_kernel(const double *__restrict_
         }
         __syncthreads();
 #pragma unroll 1
-        for (int r = 0; r < PPT; ++r)
+        for (int r = 0; r < PPT; ++r) {
+            const Slot q = q0;
+            q0 = q1, q1 = load(r + 2);
             if (todo >> r & 1u) {
                 const int64_t p = base + r * BLK + tid;
-                const double xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
+                const double xp = q.x[0] * nf, yp = q.x[1] * nf, zp = q.x[2] * nf;
                 const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
                 if ((i >> LI) == t.ti && (j >> LJ) == t.tj && (k >> LK) == t.tk) {
                     const int c0 = ((i - t.ti * TI + 1) * HJ + (j - t.tj * TJ + 1)) * HK + (k - t.tk * TK + 1);
                     double a[3];
                     gather27<SCHEME>(xp, yp, zp, i, j, k,
                                      [&](int da, int db, int dc, int m) { return tile[m * TILE + c0 + (da * HJ + db) * HK + dc]; }, a);
-                    finish(p, a);
+                    finish(q, p, a);
                     todo &= ~(1u << r);
                 }
             }
+        }
     }
 #pragma unroll 1
     for (int r = 0; r < PPT; ++r)  // what the tiles did not take: through L2
         if (todo >> r & 1u) {
             const int64_t p = base + r * BLK + tid;
-            const double xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
+            const Slot q = load(r);
+            const double xp = q.x[0] * nf, yp = q.x[1] * nf, zp = q.x[2] * nf;
             const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
             double a[3];
             gather27<SCHEME>(xp, yp, zp, i, j, k,
                              [&](int da, int db, int dc, int m) { return force[3 * cell_index(n, log2n, i + da, j + db, k + dc) + m]; }, a);
-            finish(p, a);
+            finish(q, p, a);
         }
     for (int off = 32; off > 0; off >>= 1) {
         ma = max(ma, (unsigned long long)__shfl_down((long long)ma, off, 64));
