@@ -637,7 +637,7 @@ def main():
     # timed steps of the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/, tools/pmc_summary.py).
     # Only a summary collected with THIS command line (size, step counts, policy) describes this run: else null.
     traffic = None
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.json")
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_summary.json")
     if world == 1 and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
         same = (pmc.get("ncells") == n and pmc.get("steps") == args.steps and pmc.get("warmup") == args.warmup
