@@ -128,6 +128,9 @@ def alg_bytes(n, npart):
         # ... and writing the arrays out of place in tile order: the same algorithmic work (the 12 B/particle of the
         # re-written position are this design's overhead, not compulsory traffic)
         "pm_gradient_interp_kick_rebucket": 48.0 * npart + 4.0 * cells,
+        # "the kick re-buckets": the gather stays in place and decides, the fused kick writes the new stream
+        "pm_gradient_interp_kick_codes": 48.0 * npart + 4.0 * cells,
+        "pm_kick_drift_wrap_deposit_rebucket": 60.0 * npart + 4.0 * cells,
         "pm_axpy": 36.0 * npart,                     # second kick: read v,a; write v
         "pm_max_abs": 12.0 * npart,                  # CFL reductions (two per step)
         # the fp64 device mode (8-byte elements; its gradient is a pass of its own: read phi, write F(3))
@@ -519,6 +522,8 @@ def main():
         pm_main.reserve_step_buffers(pos)
 
     resort_at = int(os.environ.get("PMSTEP_EXP_RESORT_AT", "0"))
+    if os.environ.get("PMSTEP_KICK_REBUCKETS") == "0":  # development A/B: the re-sort inside the gather (round 2's scheme)
+        integration._KICK_REBUCKETS = False
     if os.environ.get("PMSTEP_VCYCLE_GRAPHS") == "0":  # development A/B
         from pysco_amd import multigrid as _mg
 
@@ -586,7 +591,7 @@ def main():
     ab = alg_bytes(n, npart / world)
     for k in ab:  # per-rank share of the grid stages in slab mode
         if k not in ("pm_kick_drift_wrap", "pm_deposit", "pm_interp", "pm_interp_kick", "pm_gradient_interp_kick",
-                     "pm_gradient_interp_kick_rebucket",
+                     "pm_gradient_interp_kick_rebucket", "pm_gradient_interp_kick_codes", "pm_kick_drift_wrap_deposit_rebucket",
                      "pm_kick_drift_wrap_deposit", "pm_kick_drift_wrap_deposit_khalo",
                      "pm_axpy", "pm_max_abs"):
             ab[k] /= world

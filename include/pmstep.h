@@ -440,6 +440,22 @@ int pm_lap_solve(pm_ctx *ctx, float *d_x, const float *d_b, int n, int npre, int
 int pm_fr_solve(pm_ctx *ctx, int fr_n, float *d_x, const float *d_b, float q, int n, int npre, int npost, float tolerance,
                 int max_cycles, int *h_cycles, float *h_residual);
 
+/* "The kick re-buckets" (round 3; the single-GPU loop's incremental re-sort, utils.reorder_particles :1019 in effect):
+ * pm_gradient_interp_kick_codes = pm_gradient_interp_kick with the kick, in place (d_vel kicked, d_acc written, nothing
+ * permuted), which also DECIDES where every particle is filed after the next drift (pm_set_predicted_dt's guess) -- a flag
+ * byte for the particles that stay in their tile, an incoming list per tile for the others; needs complete tile lists
+ * for d_pos / np.  pm_kick_drift_wrap_deposit_rebucket = pm_kick_drift_wrap_deposit[_khalo] (d_khalo NULL: plain flush)
+ * obeying those decisions: position and velocity of the new step are written OUT OF PLACE into d_pos_out / d_vel_out, tile
+ * after tile (d_pos / d_vel / d_acc are only read; optional uint32 tags follow), and the new stream's tile offsets, ranges
+ * and straggler lists are left prepared.  pm_rebucket_kick_ready: *h_ready = 1 if the decisions on file are for exactly
+ * d_pos / np and no list overflowed (otherwise take the in-place step). */
+int pm_gradient_interp_kick_codes(pm_ctx *ctx, int order, int scheme, const float *d_phi, const float *d_pos, float *d_vel,
+                                  int64_t np, float half_dt, float *d_acc);
+int pm_rebucket_kick_ready(pm_ctx *ctx, const float *d_pos, int64_t np, int *h_ready);
+int pm_kick_drift_wrap_deposit_rebucket(pm_ctx *ctx, int scheme, const float *d_pos, const float *d_vel, const float *d_acc,
+                                        float half_dt, float dt, int64_t np, float *d_rho, float *d_khalo, float *d_pos_out,
+                                        float *d_vel_out, const unsigned *d_id, unsigned *d_id_out);
+
 /* ---- the fp64 device mode (pm_create(N, Np, ngpu, real_bytes)) ---------------------------
  * pm_ctx_create_real(..., real_bytes): 4 = pm_ctx_create (the reference's float32, every entry point above);
  * 8 = a context of the fp64 mode of the Newtonian FFT step, served by the pm_real64_* entry points below, which take

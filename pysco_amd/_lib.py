@@ -143,6 +143,9 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_fft2d_c2r": (_vp, _vp, _vp, _i),
     "pm_fft1d_x": (_vp, _vp, _i64, _i),
     "pm_greens_slab": (_vp, _i, _i, _vp, _vp, _vp, _f, _i, _i),
+    "pm_gradient_interp_kick_codes": (_vp, _i, _i, _vp, _vp, _vp, _i64, _f, _vp),
+    "pm_rebucket_kick_ready": (_vp, _vp, _i64, C.POINTER(_i)),
+    "pm_kick_drift_wrap_deposit_rebucket": (_vp, _i, _vp, _vp, _vp, _f, _f, _i64, _vp, _vp, _vp, _vp, _vp, _vp),
     "pm_lap_solve": (_vp, _vp, _vp, _i, _i, _i, _f, _i, C.POINTER(_i), C.POINTER(_f)),
     "pm_fr_solve": (_vp, _i, _vp, _vp, _f, _i, _i, _i, _f, _i, C.POINTER(_i), C.POINTER(_f)),
     # the fp64 device mode (pm_real64.hip)

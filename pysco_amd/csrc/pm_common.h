@@ -124,7 +124,7 @@ constexpr size_t PM_PINNED_BYTES = 16384;
 
 #endif
 
-constexpr int PM_SCRATCH_SINK = 64, PM_SCRATCH_WORDS = 256;
+constexpr int PM_SCRATCH_SINK = 64, PM_SINK_BYTES_AT = 192, PM_SCRATCH_WORDS = 288;  // sink: 192 words of records + 64 flag bytes
 
 struct pm_ctx {
     int n;          // cells per side
@@ -183,6 +183,14 @@ struct pm_ctx {
     // the re-bucketed stream (two tables: the one the current layout was written with, the one being built)
     void *rb_buf;
     size_t rb_buf_bytes;
+    // "the kick re-buckets" (pm_gradient_interp_kick_codes -> pm_kick_drift_wrap_deposit_rebucket): flags, per-workgroup and
+    // per-tile stay counts, incoming lists; valid for exactly (kr_pos, kr_np) until the next fused kick consumes them
+    void *kr_buf;
+    size_t kr_buf_bytes;
+    int kr_valid, kr_checked;
+    unsigned kr_blocks;  // workgroups of the gather's launch (the ranges it walked: KrBufs::start / xstart)
+    const float *kr_pos;
+    int64_t kr_np;
     int stay_valid;            // the destination counts belong to the prepared lists (lists_pos)
     unsigned char *codes_user;        // where the fused kick records the destination codes on a slab (pm_set_destination_codes)
     const unsigned char *stay_codes;  // the codes the destination counts were made from (the gather's Rebucket::dcode)

@@ -125,6 +125,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *c) {
     if (c->tile_tmp) hipFree(c->tile_tmp);
     if (c->list_buf) hipFree(c->list_buf);
     if (c->rb_buf) hipFree(c->rb_buf);
+    if (c->kr_buf) hipFree(c->kr_buf);
     if (c->mg_buf) hipFree(c->mg_buf);
     for (auto &g : c->vc_graphs)
         if (g.exec) hipGraphExecDestroy(g.exec);

@@ -110,6 +110,8 @@ constexpr int PM_FSTRIDE = 3264;                      // cells per plane of the 
 constexpr int PM_FZ = 2 * PM_FSTRIDE;                 // float offset of the z plane
 typedef float pm_v2f __attribute__((ext_vector_type(2)));
 typedef float pm_v4f __attribute__((ext_vector_type(4)));
+typedef float pm_v3f __attribute__((ext_vector_type(3)));
+typedef float pm_v3fu __attribute__((ext_vector_type(3), aligned(4)));  // a 12-byte particle record: one dwordx3 access
 // byte offset of a __shared__ object inside the workgroup's LDS allocation (the address a ds_* instruction takes)
 template <typename T>
 __device__ __forceinline__ unsigned lds_offset(const T *p) {
@@ -1449,13 +1451,28 @@ struct Leavers {
     int *count;
 };
 
-template <int SCHEME>
+// REB ("the kick re-buckets", struct Codes further down): what the last gather decided, and where the new stream goes
+struct KickReb {
+    const unsigned char *flag;  // [np] 13: the particle stays in the tile it is filed under
+    const unsigned *wg_stay;    // [workgroups] stayers of the workgroup's range
+    const unsigned *tile_stay;  // [ntiles] stayers of the tile
+    const unsigned *inc_count;  // [ntiles] movers in the tile's incoming list
+    const unsigned *segstart;   // [ntiles + 1] where the list lives in `entries`
+    const unsigned *entries;    // old-stream indices of the movers, by destination tile
+    const int64_t *newstart;    // [ntiles + 1] layout of the new stream: a tile's stayers, then its incoming list
+    unsigned *fill;             // [ntiles] cleared: a tile's workgroups take their stayers' slices here
+    float *pos_out, *vel_out;
+    const unsigned *id;         // optional tags (NULL: none)
+    unsigned *id_out;
+};
+
+template <int SCHEME, bool REB = false>
 __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ pos, float *__restrict__ vel,
                                                           const float *__restrict__ acc, float mhalf_dt, float dt,
                                                           TileWork work, pm_geom geo, float *__restrict__ rho,
                                                           unsigned *__restrict__ lkeys, unsigned *__restrict__ lidx,
                                                           unsigned subcap, unsigned *__restrict__ counts, Leavers lv,
-                                                          HaloBuf halo, DestCount dc) {
+                                                          HaloBuf halo, DestCount dc, KickReb kr = KickReb{}) {
     unsigned key;
     int64_t s, e;
     // Halo buffer: the first-chunk workgroup of a tile owns the tile's entries of K, Hi, Hj and the tile's own
@@ -1470,15 +1487,28 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
         else if (v != 0.f)
             unsafeAtomicAdd(rho + tile_cell_global(c, t0, geo), v);
     };
+    // REB: the first workgroup of a tile also serves the tile's incoming list -- an empty range is no reason to leave
+    const bool firstwg = (blockIdx.x + work.boff) < work.nlaunch;
+    unsigned ninc = 0;
     if (!tile_work_item(work, key, s, e)) {
-        if (owner)
-            for (int c = threadIdx.x; c < PM_TILE; c += BLK) halo_store(c, 0.f);
-        return;
+        if (REB && firstwg) {
+            key = tile_key_of_block(blockIdx.x + work.boff, work);
+            s = e = 0;
+            ninc = min(kr.inc_count[key], kr.segstart[key + 1] - kr.segstart[key]);
+        }
+        if (ninc == 0) {
+            if (owner)
+                for (int c = threadIdx.x; c < PM_TILE; c += BLK) halo_store(c, 0.f);
+            return;
+        }
+    } else if (REB && firstwg) {
+        ninc = min(kr.inc_count[key], kr.segstart[key + 1] - kr.segstart[key]);
     }
     __shared__ pm_acc_t tile[PM_TILE];  // 25.9 KB
     __shared__ unsigned s_k[PM_SCAP], s_p[PM_SCAP];
     __shared__ unsigned s_cnt, s_base;
     __shared__ unsigned s_hist[27];  // served particles per destination (13: counted as the rest)
+    __shared__ unsigned s_rbase, s_rslot;  // REB: the workgroup's slice of the tile's stayers, next free slot in it
     const int tid = threadIdx.x;
     const int n = geo.n;
     const float nf = (float)n;
@@ -1486,14 +1516,100 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
     for (int c = tid; c < PM_TILE; c += BLK) tile[c] = 0;
     if (tid == 0) s_cnt = 0;
     if (tid < 27) s_hist[tid] = 0;
+    if (REB && tid == 0) {
+        const unsigned mine = s < e ? kr.wg_stay[blockIdx.x + work.boff] : 0u;
+        s_rbase = mine ? atomicAdd(kr.fill + key, mine) : 0u, s_rslot = 0;
+    }
+    // REB: the first BLK entries of the tile's incoming list are fetched NOW -- index, then (below, once it has arrived)
+    // the particle's nine floats from wherever it sits in the old stream -- and ride in registers to the end of the
+    // kernel: served there by loads of their own, the list cost the workgroup two exposed memory latencies with
+    // nothing left to hide them behind
+    int64_t pinc = -1;
+    if (REB && (unsigned)tid < ninc) pinc = kr.entries[kr.segstart[key] + tid];
     __syncthreads();
+    float xi[3] = {0.f, 0.f, 0.f}, vi[3] = {0.f, 0.f, 0.f}, ai[3] = {0.f, 0.f, 0.f};
+    if (REB && pinc >= 0) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) xi[m] = pos[3 * pinc + m], vi[m] = vel[3 * pinc + m], ai[m] = acc[3 * pinc + m];
+    }
     const unsigned seg = (blockIdx.x % PM_NSUB) * subcap;
     auto append = [&](unsigned k, unsigned p) {  // past the staging area: straight to the global list
         const unsigned g = atomicAdd(sub_counter(counts), 1u);
         if (g < subcap) lkeys[seg + g] = k, lidx[seg + g] = p;
     };
     // a range well above one particle per cell: lanes of a wave share cells (deposit_lds<..., ROTATE>)
-    const bool dense = (e - s) >= PM_DENSE_RANGE;
+    const bool dense = (e - s) + (int64_t)ninc >= PM_DENSE_RANGE;
+    if constexpr (REB) {
+        // kick, drift, wrap, deposit and the write into the NEW stream of one particle (old index p, new index d64)
+        auto place = [&](float x[3], float v[3], const float a[3], int64_t d64, int64_t p) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) pm_kick_drift_wrap_one(x[m], v[m], a[m], mhalf_dt, dt);
+            const pm_v3f vx = {x[0], x[1], x[2]}, vv = {v[0], v[1], v[2]};
+            __builtin_nontemporal_store(vv, reinterpret_cast<pm_v3fu *>(kr.vel_out + 3 * d64));
+            __builtin_nontemporal_store(vx, reinterpret_cast<pm_v3fu *>(kr.pos_out + 3 * d64));
+            if (kr.id) kr.id_out[d64] = kr.id[p];
+            const float xp = x[0] * nf, yp = x[1] * nf, zp = x[2] * nf;
+            const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+            if (in_tile(i, j, k, t)) {
+                if (dense)
+                    deposit_lds<SCHEME, true>(xp, yp, zp, i, j, k, t, tile);
+                else
+                    deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
+            } else {  // the guess of this step was off for it: served by the tile it is in, from that tile's list
+                const unsigned k2 = tile_key(i >> PM_LI, j >> PM_LJ, k >> PM_LK);
+                const unsigned slot = atomicAdd(&s_cnt, 1u);
+                if (slot < PM_SCAP)
+                    s_k[slot] = k2, s_p[slot] = (unsigned)d64;
+                else
+                    append(k2, (unsigned)d64);
+            }
+        };
+        const unsigned lane = (unsigned)tid & 63u;
+        const int64_t nbase = kr.newstart[key] + (int64_t)s_rbase;
+        // the stayers of the range, compacted in order: one LDS atomic per wave and iteration hands out their slots
+#pragma unroll 1
+        for (int64_t p0 = s + tid; p0 - lane < e; p0 += 2 * BLK) {
+            float x[2][3], v[2][3], a[2][3];
+            unsigned fl[2] = {0u, 0u};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t p = p0 + u * BLK;
+                if (p < e) {
+                    fl[u] = kr.flag[p];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                        x[u][m] = __builtin_nontemporal_load(pos + 3 * p + m), v[u][m] = __builtin_nontemporal_load(vel + 3 * p + m),
+                        a[u][m] = __builtin_nontemporal_load(acc + 3 * p + m);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t p = p0 + u * BLK;
+                const bool act = p < e && fl[u] == 13u;
+                const unsigned long long m = __ballot(act);
+                if (m == 0ull) continue;
+                const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                unsigned wb = 0;
+                if (act && before == 0) wb = atomicAdd(&s_rslot, (unsigned)__popcll(m));
+                wb = __shfl((int)wb, __ffsll((long long)m) - 1, 64);
+                if (act) place(x[u], v[u], a[u], nbase + (int64_t)(wb + before), p);
+            }
+        }
+        // the tile's incoming list (first workgroup of the tile): behind all its stayers
+        if (ninc) {
+            const int64_t ibase = kr.newstart[key] + (int64_t)kr.tile_stay[key];
+            const unsigned *const ent = kr.entries + kr.segstart[key];
+            if (pinc >= 0) place(xi, vi, ai, ibase + tid, pinc);
+#pragma unroll 1
+            for (unsigned jn = tid + BLK; jn < ninc; jn += BLK) {  // (a long list: the rest where it is needed)
+                const int64_t p = ent[jn];
+                float x[3], v[3], a[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) x[m] = pos[3 * p + m], v[m] = vel[3 * p + m], a[m] = acc[3 * p + m];
+                place(x, v, a, ibase + jn, p);
+            }
+        }
+    } else {
     // two particles per iteration: 18 dword loads in flight per lane
 #pragma unroll 1
     for (int64_t p0 = s + tid; p0 < e; p0 += 2 * BLK) {
@@ -1554,6 +1670,7 @@ __global__ __launch_bounds__(BLK) void kdw_deposit_kernel(float *__restrict__ po
             }
         }
     }
+    }  // (!REB)
     __syncthreads();
     // Flush.  The global float atomics execute at the memory side as 64-byte read-modify-writes, one per
     // touched 64-byte sector whatever it carries (at 1024^3 the flush was 5.0 of the kernel's 16.8 ms: 2.5 the
@@ -2088,18 +2205,49 @@ __device__ __forceinline__ pm_gfloat *select_ptr(unsigned long long mask, float 
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(qhi), "v"(phi), "s"(mask));
     return (pm_gfloat *)(((uintptr_t)hi << 32) | lo);
 }
-typedef float pm_v3f __attribute__((ext_vector_type(3)));
-typedef float pm_v3fu __attribute__((ext_vector_type(3), aligned(4)));  // a 12-byte particle record: one dwordx3 access
 typedef __attribute__((address_space(1))) pm_v3fu pm_gv3fu;
+
+// "The kick re-buckets" (round 3): the gather stays IN PLACE -- it writes the kicked velocity and the acceleration
+// where it read the particle, contiguous 12-byte records, and not the position at all -- and only DECIDES where every
+// particle goes: the tile it is expected to be in after the next drift, x + dt' (v + kick - dt'/2 a) with the
+// acceleration it has just computed (exactly what the next fused kick will do, but for the guess dt' of the step).
+// A particle that stays in the tile it is filed under gets a flag byte; one that goes elsewhere has its index
+// appended to the incoming list of its destination tile.  The NEXT fused kick + drift + deposit, which rewrites
+// position and velocity anyway, writes them out of place: a tile's workgroup compacts its stayers to the front of
+// the tile's new range and serves its incoming list behind them (kdw_deposit_kernel<SCHEME, true>).  Against the
+// re-bucketing gather this drops the 12.9 GB of re-written positions and every scattered store of the step.
+struct Codes {
+    unsigned char *flag;       // [np] 13: stays in the tile it is filed under; 0: it is in its destination's incoming list
+    unsigned *wg_stay;         // [workgroups] stayers served from the workgroup's range
+    unsigned *tile_stay;       // [ntiles] cleared: stayers per tile
+    unsigned *inc_count;       // [ntiles] cleared: movers appended to the tile's incoming list
+    const unsigned *segstart;  // [ntiles + 1] where a tile's incoming list lives in `entries`
+    unsigned *entries;         // stream indices of the movers, by destination tile
+    unsigned *overflow;        // raised when a list was full (the caller then takes an in-place step)
+    float dtp;                 // the caller's guess of the next dt (pm_set_predicted_dt)
+};
+constexpr int PM_MOV_STAGE = 288;  // movers a workgroup stages in LDS before it books their list slots (more: one by one)
+
+// byte pointer p for the lanes set in `mask`, q for the others (see select_ptr)
+__device__ __forceinline__ __attribute__((address_space(1))) unsigned char *select_byte_ptr(unsigned long long mask,
+                                                                                           unsigned char *p, unsigned char *q) {
+    const unsigned plo = (unsigned)(uintptr_t)p, phi = (unsigned)((uintptr_t)p >> 32);
+    const unsigned qlo = (unsigned)(uintptr_t)q, qhi = (unsigned)((uintptr_t)q >> 32);
+    unsigned lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(qlo), "v"(plo), "s"(mask));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(qhi), "v"(phi), "s"(mask));
+    return (__attribute__((address_space(1))) unsigned char *)(((uintptr_t)hi << 32) | lo);
+}
 
 // One workgroup per tile: gather + second kick + CFL maxima.  ORDER == 0: `src` is the [.,n,n,3] force
 // grid; ORDER in {2,3,5,7}: `src` is the potential and the force tile is differentiated in LDS.
-template <int SCHEME, int ORDER, bool KICK, bool REBUCKET = false>
+template <int SCHEME, int ORDER, bool KICK, bool REBUCKET = false, bool CODES = false>
 __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restrict__ src,
                                                             const float *__restrict__ pos, TileWork work,
                                                             TileLists lists, pm_geom geo, float *__restrict__ out,
                                                             float *__restrict__ vel, float mhalf_dt,
-                                                            unsigned *__restrict__ maxbits, Rebucket rb) {
+                                                            unsigned *__restrict__ maxbits, Rebucket rb, Codes cd = Codes{}) {
+    static_assert(!(REBUCKET && CODES) && (!CODES || KICK), "one re-sort scheme at a time; the codes need the kicked velocity");
     // The tile of a first-chunk workgroup follows from blockIdx alone, so its fill loads are issued
     // together with the range lookup instead of one memory latency after it.
     unsigned key = 0;
@@ -2118,10 +2266,17 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     // next free slot in it
     __shared__ int64_t s_dest[27];
     __shared__ unsigned s_mine[27], s_slot[27];
+    // CODES: movers of the workgroup, staged as destination (5 bits) | rank among the workgroup's movers to that
+    // destination (11) | index in the range (16), and the booking of their list slots
+    __shared__ unsigned s_mov[CODES ? PM_MOV_STAGE : 1], s_nmov, s_dcnt[27], s_dbase[27], s_dkey[27], s_nstay;
     const int tid = threadIdx.x;
     const int n = geo.n;
     const float nf = (float)n;
     const float scale = grad_scale<ORDER>(n);
+    if constexpr (CODES) {
+        if (tid < 27) s_dcnt[tid] = 0;
+        if (tid == 0) s_nmov = 0, s_nstay = 0;  // (ordered before their first use by the barriers of the tile fill)
+    }
     const TileId t = tile_of_key(key);
     constexpr int R = GradReach<ORDER>::R;
     // Potential tile: DX x DY rows of DZ = 24 floats, row r starting at global k = 16 tk - 4.  A row is six
@@ -2334,20 +2489,117 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
         } else if (!skip) {
             float *op = o + 3 * p, *wp = w3 + 3 * p;
             sabs += fabsf(a[0]), scnt += 1.0f;
+            float w[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 op[m] = a[m];
                 ma = max(ma, __float_as_uint(a[m]) & 0x7fffffffu);
                 if (KICK) {
-                    const float w = v[m] + mhalf_dt * a[m];
-                    wp[m] = w;
-                    mv = max(mv, __float_as_uint(w) & 0x7fffffffu);
+                    w[m] = v[m] + mhalf_dt * a[m];
+                    wp[m] = w[m];
+                    mv = max(mv, __float_as_uint(w[m]) & 0x7fffffffu);
                 }
+            }
+            if constexpr (CODES) {
+                // a listed particle (filed under another tile, served here): always a mover -- into the incoming list
+                // of the tile it is expected in after the next drift, one slot at a time (they are few)
+                const float xs[3] = {x, y, z};
+                float veff[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) veff[m] = w[m] + (-0.5f * cd.dtp) * a[m];
+                const DestCode dd = dest_of(xs, veff, cd.dtp, nf, n, tile_of_cell(i, j, k));
+                const unsigned slot = atomicAdd(cd.inc_count + dd.key, 1u);
+                if (slot < cd.segstart[dd.key + 1] - cd.segstart[dd.key])
+                    cd.entries[cd.segstart[dd.key] + slot] = (unsigned)src_index;
+                else
+                    *cd.overflow = 1u;
             }
         }
     };
     constexpr int QD = 2;  // queue slots in use (measured at 1024^3: 4 slots 16.3 ms, 3: 16.3, 2: 15.95, 1: 16.4)
-    if constexpr (REBUCKET) {
+    if constexpr (CODES) {
+        // The range of a pass that stays in place and decides (struct Codes): the memory pipeline of the re-bucketing
+        // loop below -- four register slots two particles ahead, one basic block as far as vector memory goes -- with
+        // stores that need no slot: velocity and acceleration go where the particle was read (a wave's 64 records are
+        // 768 contiguous bytes), the flag byte beside them.
+        if (has_range) {
+            const unsigned cnt = (unsigned)(e - s), last = cnt - 1u;
+            const unsigned lane = (unsigned)tid & 63u;
+            float *const sink = rb.sink + 3u * lane;
+            unsigned char *const bsink = reinterpret_cast<unsigned char *>(rb.sink + PM_SINK_BYTES_AT) + lane;
+            float *const vout = vel + 3 * s, *const aout = out + 3 * s;
+            unsigned char *const fout = cd.flag + s;
+            const float kick_next = -0.5f * cd.dtp;
+            constexpr int NS = 4;
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), once (see the re-bucketing loop)
+            unsigned nstay = 0;
+#pragma unroll 1
+            for (unsigned r0 = tid; (unsigned)__builtin_amdgcn_readfirstlane((int)r0) < cnt; r0 += NS * BLK) {
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    const unsigned r = r0 + u * BLK;
+                    const float x = q.x[u], y = q.y[u], z = q.z[u];
+                    const float v[3] = {qv.q.x[u], qv.q.y[u], qv.q.z[u]};
+                    q.load((u + 2) % NS, r + 2 * BLK);
+                    qv.q.load((u + 2) % NS, r + 2 * BLK);
+                    float a[3] = {0.f, 0.f, 0.f};
+                    bool mine = false, stay = false;
+                    int dcode = 13;
+                    if ((unsigned)__builtin_amdgcn_readfirstlane((int)r) < cnt) {
+                        const float xp = x * nf, yp = y * nf, zp = z * nf;
+                        const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+                        // (a stranger in the own range is served by the tile it is in now, from its list)
+                        mine = r < cnt && in_tile(i, j, k, t);
+                        gather_lds<SCHEME>(xp, yp, zp, mine ? i : t.ti * PM_TI, mine ? j : t.tj * PM_TJ, mine ? k : t.tk * PM_TK,
+                                           t, tile, a);
+                    }
+                    float w[3];
+#pragma unroll
+                    for (int mm = 0; mm < 3; ++mm) w[mm] = v[mm] + mhalf_dt * a[mm];
+                    if (mine) {
+#pragma unroll
+                        for (int mm = 0; mm < 3; ++mm) {
+                            ma = max(ma, __float_as_uint(a[mm]) & 0x7fffffffu);
+                            mv = max(mv, __float_as_uint(w[mm]) & 0x7fffffffu);
+                        }
+                        sabs += fabsf(a[0]), scnt += 1.0f;
+                        // where the next drift takes it: x + dt' (w - dt'/2 a), clamped to one cell (dest_of)
+                        const float xs[3] = {x, y, z};
+                        float veff[3];
+#pragma unroll
+                        for (int mm = 0; mm < 3; ++mm) veff[mm] = w[mm] + kick_next * a[mm];
+                        dcode = dest_of(xs, veff, cd.dtp, nf, n, t).d;
+                        stay = dcode == 13;
+                        nstay += stay ? 1u : 0u;
+                        if (!stay) {  // (LDS only: a branch the counted waits need not know about)
+                            const unsigned at = atomicAdd(&s_nmov, 1u);
+                            if (at < (unsigned)PM_MOV_STAGE) {
+                                const unsigned rank = atomicAdd(&s_dcnt[dcode], 1u);  // (< PM_MOV_STAGE: 11 bits)
+                                s_mov[at] = ((unsigned)dcode << 27) | (rank << 16) | r;
+                            } else {  // the staging area is full: book the slot now
+                                const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
+                                const unsigned dkey = tile_key((t.ti + dcode / 9 - 1 + Ti) % Ti, (t.tj + (dcode / 3) % 3 - 1 + Tj) % Tj,
+                                                               (t.tk + dcode % 3 - 1 + Tk) % Tk);
+                                const unsigned slot = atomicAdd(cd.inc_count + dkey, 1u);
+                                if (slot < cd.segstart[dkey + 1] - cd.segstart[dkey])
+                                    cd.entries[cd.segstart[dkey] + slot] = (unsigned)(s + r);
+                                else
+                                    *cd.overflow = 1u;
+                            }
+                        }
+                    }
+                    const pm_v3f va = {a[0], a[1], a[2]}, vw = {w[0], w[1], w[2]};
+                    const unsigned long long mm_ = __ballot(mine);
+                    __builtin_nontemporal_store(va, (pm_gv3fu *)select_ptr(mm_, aout + 3u * r, sink));
+                    __builtin_nontemporal_store(vw, (pm_gv3fu *)select_ptr(mm_, vout + 3u * r, sink));
+                    *select_byte_ptr(__ballot(r < cnt), fout + r, bsink) = stay ? (unsigned char)13 : (unsigned char)0;
+                }
+            }
+            // stayers of the range: one count per workgroup, added to the tile's
+            for (int off = 32; off > 0; off >>= 1) nstay += (unsigned)__shfl_down((int)nstay, off, 64);
+            if (lane == 0) atomicAdd(&s_nstay, nstay);
+        }
+    } else if constexpr (REBUCKET) {
         // The range of a re-bucketing pass.  What this loop is made for is that a wave NEVER drains its memory queue:
         // vector-memory operations retire in order, so a wait for one load is a wait for every load and every STORE
         // issued before it.  (Until round 3 the destination byte was loaded inside the iteration that used it and the
@@ -2496,6 +2748,29 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
     if constexpr (REBUCKET) {  // (never, unless positions or codes were changed behind the prepared counts)
         const unsigned long long lm = __ballot(lost != 0u);
         if (lm && (tid & 63) == 0) atomicAdd(maxbits + PM_SAMPLE_WORD + 3, (unsigned)__popcll(lm));
+    }
+    if constexpr (CODES) {
+        // (the barrier above has every lane's staging and counting behind it)
+        if (tid == 0) {
+            cd.wg_stay[blockIdx.x + work.boff] = has_range ? s_nstay : 0u;
+            if (has_range && s_nstay) atomicAdd(cd.tile_stay + key, s_nstay);
+        }
+        if (tid < 27 && s_dcnt[tid]) {  // one booking per destination: the workgroup's movers there sit side by side
+            const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
+            const unsigned dkey = tile_key((t.ti + tid / 9 - 1 + Ti) % Ti, (t.tj + (tid / 3) % 3 - 1 + Tj) % Tj,
+                                           (t.tk + tid % 3 - 1 + Tk) % Tk);
+            s_dkey[tid] = dkey, s_dbase[tid] = atomicAdd(cd.inc_count + dkey, s_dcnt[tid]);
+        }
+        __syncthreads();
+        const unsigned nm = min(s_nmov, (unsigned)PM_MOV_STAGE);
+        for (unsigned i = tid; i < nm; i += BLK) {
+            const unsigned m = s_mov[i], d = m >> 27, rank = (m >> 16) & 2047u, r = m & 0xffffu;
+            const unsigned dkey = s_dkey[d], slot = s_dbase[d] + rank;
+            if (slot < cd.segstart[dkey + 1] - cd.segstart[dkey])
+                cd.entries[cd.segstart[dkey] + slot] = (unsigned)(s + r);
+            else
+                *cd.overflow = 1u;
+        }
     }
 }
 
@@ -2849,6 +3124,269 @@ extern "C" int pm_gradient_interp_kick_rebucket_slab(pm_ctx *c, int order, int s
                                          d_acc_out, d_id, d_id_out);
 }
 
+// ---- "the kick re-buckets" (struct Codes / struct KickReb): host side -------------------------------------------
+
+struct KrBufs {
+    unsigned *tile_stay, *inc_count, *segcap, *segstart, *wg_stay, *overflow, *entries;
+    int64_t *start, *xstart;  // the ranges the gather decided on: the very table the re-bucketing kick must walk
+    unsigned char *flag;
+    void *scan_tmp;
+    size_t scan_tmp_bytes;
+};
+
+static int kr_bufs(pm_ctx *c, unsigned ntiles, int64_t np, KrBufs *b) {
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t maxblocks = (size_t)ntiles + (size_t)(np / PM_RANGE_CHUNK) + 2;
+    const size_t t32 = up(((size_t)ntiles + 1) * sizeof(unsigned)), w32 = up(maxblocks * sizeof(unsigned));
+    const size_t nent = (size_t)256 * ntiles + (size_t)(np / 4) + ntiles;  // sum of the list capacities (kr_segcap_kernel)
+    size_t tmp = 0;
+    unsigned *nullp = nullptr;
+    PM_HIP(rocprim::exclusive_scan(nullptr, tmp, nullp, nullp, 0u, (size_t)ntiles + 1, rocprim::plus<unsigned>(), c->stream));
+    const size_t t64 = up(((size_t)ntiles + 1) * sizeof(int64_t));
+    const size_t need = 4 * t32 + w32 + 256 + up(tmp) + up((size_t)np) + up(nent * sizeof(unsigned)) + 2 * t64;
+    if (c->kr_buf_bytes < need) {
+        if (c->kr_buf) {
+            PM_HIP(hipStreamSynchronize(c->stream));
+            PM_HIP(hipFree(c->kr_buf));
+        }
+        c->kr_buf = nullptr, c->kr_buf_bytes = 0, c->kr_valid = 0;
+        PM_HIP(hipMalloc(&c->kr_buf, need + need / 16));
+        c->kr_buf_bytes = need + need / 16;
+    }
+    char *p = (char *)c->kr_buf;
+    b->tile_stay = (unsigned *)p, b->inc_count = (unsigned *)(p + t32), b->segcap = (unsigned *)(p + 2 * t32);
+    b->segstart = (unsigned *)(p + 3 * t32);
+    b->wg_stay = (unsigned *)(p + 4 * t32), b->overflow = (unsigned *)(p + 4 * t32 + w32);
+    b->scan_tmp = p + 4 * t32 + w32 + 256, b->scan_tmp_bytes = tmp;
+    b->flag = (unsigned char *)(p + 4 * t32 + w32 + 256 + up(tmp));
+    b->entries = (unsigned *)(p + 4 * t32 + w32 + 256 + up(tmp) + up((size_t)np));
+    b->start = (int64_t *)(p + 4 * t32 + w32 + 256 + up(tmp) + up((size_t)np) + up(nent * sizeof(unsigned)));
+    b->xstart = (int64_t *)((char *)b->start + t64);
+    return PM_OK;
+}
+
+// capacity of a tile's incoming list: a quarter of what the tile holds now, and 256 (movers are a few per cent of a
+// tile's particles per step; a list that overflows all the same raises Codes::overflow and the step is taken in place)
+__global__ __launch_bounds__(BLK) void kr_segcap_kernel(const int64_t *__restrict__ start, unsigned ntiles,
+                                                        unsigned *__restrict__ cap) {
+    const unsigned t = blockIdx.x * BLK + threadIdx.x;
+    if (t > ntiles) return;
+    cap[t] = t < ntiles ? 256u + (unsigned)((start[t + 1] - start[t]) >> 2) : 0u;
+}
+
+// a tile's population in the new stream: its stayers + its incoming list
+__global__ __launch_bounds__(BLK) void kr_counts_kernel(const unsigned *__restrict__ tile_stay, const unsigned *__restrict__ inc_count,
+                                                        const unsigned *__restrict__ segstart, unsigned ntiles,
+                                                        int64_t *__restrict__ cnt) {
+    const unsigned t = blockIdx.x * BLK + threadIdx.x;
+    if (t > ntiles) return;
+    cnt[t] = t < ntiles ? (int64_t)tile_stay[t] + (int64_t)min(inc_count[t], segstart[t + 1] - segstart[t]) : 0;
+}
+
+template <int SCHEME, int ORDER>
+static int codes_launch(pm_ctx *c, const float *phi, pm_geom geo, const float *pos, float *vel, int64_t np, float half_dt,
+                        float *acc, const TileWork &work, const TileLists &lists, unsigned nblk, const Codes &cd) {
+    Rebucket rb{};
+    rb.sink = reinterpret_cast<float *>(c->d_scratch + PM_SCRATCH_SINK);
+    hipLaunchKernelGGL((interp_ranges_kernel<SCHEME, ORDER, true, false, true>), dim3(nblk), dim3(BLK), 0, c->stream, phi, pos,
+                       work, lists, geo, acc, vel, -half_dt, c->d_scratch + 8, rb, cd);
+    PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+template <int SCHEME>
+static int codes_order(pm_ctx *c, int order, const float *phi, pm_geom geo, const float *pos, float *vel, int64_t np,
+                       float half_dt, float *acc, const TileWork &work, const TileLists &lists, unsigned nblk, const Codes &cd) {
+    switch (order) {
+        case 0: return codes_launch<SCHEME, 0>(c, phi, geo, pos, vel, np, half_dt, acc, work, lists, nblk, cd);
+        case 2: return codes_launch<SCHEME, 2>(c, phi, geo, pos, vel, np, half_dt, acc, work, lists, nblk, cd);
+        case 3: return codes_launch<SCHEME, 3>(c, phi, geo, pos, vel, np, half_dt, acc, work, lists, nblk, cd);
+        case 5: return codes_launch<SCHEME, 5>(c, phi, geo, pos, vel, np, half_dt, acc, work, lists, nblk, cd);
+        case 7: return codes_launch<SCHEME, 7>(c, phi, geo, pos, vel, np, half_dt, acc, work, lists, nblk, cd);
+    }
+    pm_set_error("gradient order %d, should be 0 (force grid), 2, 3, 5 or 7", order);
+    return PM_EINVAL;
+}
+
+// pm_gradient_interp_kick with the kick, IN PLACE (d_vel kicked, d_acc written, in the order of d_pos), which also decides
+// where the next fused kick + drift + deposit files every particle (struct Codes; pm_set_predicted_dt's guess of the next
+// dt): the first half of "the kick re-buckets".  Needs complete tile lists for exactly d_pos / np.
+extern "C" int pm_gradient_interp_kick_codes(pm_ctx *c, int order, int scheme, const float *d_phi, const float *d_pos,
+                                             float *d_vel, int64_t np, float half_dt, float *d_acc) {
+    PM_REQUIRE(c && d_phi && d_pos && d_vel && d_acc && np > 0 && np < 4294967296LL, "bad argument");
+    PM_REQUIRE(c->slab_nx == c->n && c->tile_nx == c->n, "pm_gradient_interp_kick_codes is the single-GPU form");
+    PM_REQUIRE(c->n >= 16, "needs n >= 16");
+    PM_REQUIRE(order == 0 || ((uintptr_t)d_phi & 15u) == 0, "d_phi must be 16-byte aligned (the tile fill reads float4)");
+    PM_REQUIRE(c->lists_pos == d_pos && c->lists_np == np && c->lists_use == 1,
+               "no complete tile lists prepared for these positions (the fused kick + drift + deposit, or pm_tile_lists, first)");
+    const unsigned ntiles = (unsigned)(((int64_t)c->n * c->n * c->n) >> (PM_LI + PM_LJ + PM_LK));
+    KrBufs b;
+    int rc = kr_bufs(c, ntiles, np, &b);
+    if (rc) return rc;
+    TileWork work;
+    TileLists lists;
+    unsigned nblk = 0;
+    rc = tile_work_for(c, d_pos, np, &work, &lists, &nblk);
+    if (rc) return rc;
+    const unsigned tb = (ntiles + 1 + BLK - 1) / BLK;
+    hipLaunchKernelGGL(kr_segcap_kernel, dim3(tb), dim3(BLK), 0, c->stream, work.start, ntiles, b.segcap);
+    PM_LAUNCH_CHECK();
+    size_t tmp = b.scan_tmp_bytes;
+    PM_HIP(rocprim::exclusive_scan(b.scan_tmp, tmp, b.segcap, b.segstart, 0u, (size_t)ntiles + 1, rocprim::plus<unsigned>(), c->stream));
+    PM_HIP(hipMemsetAsync(b.tile_stay, 0, 2 * (((size_t)(ntiles + 1) * sizeof(unsigned) + 255) & ~(size_t)255), c->stream));  // + inc_count
+    PM_HIP(hipMemsetAsync(c->d_scratch + 8, 0, 2 * sizeof(unsigned), c->stream));
+    PM_HIP(hipMemsetAsync(c->d_scratch + 8 + PM_SAMPLE_WORD, 0, 5 * sizeof(unsigned), c->stream));
+    Codes cd;
+    cd.flag = b.flag, cd.wg_stay = b.wg_stay, cd.tile_stay = b.tile_stay, cd.inc_count = b.inc_count, cd.segstart = b.segstart;
+    // (the overflow word sits with the CFL maxima: pm_last_maxabs, which every step calls anyway, reads it along)
+    cd.entries = b.entries, cd.overflow = c->d_scratch + 8 + PM_SAMPLE_WORD + 4, cd.dtp = c->dt_pred;
+    const pm_geom geo = pm_ctx_geom(c);
+    switch (scheme) {
+        case PM_NGP: rc = codes_order<PM_NGP>(c, order, d_phi, geo, d_pos, d_vel, np, half_dt, d_acc, work, lists, nblk, cd); break;
+        case PM_CIC: rc = codes_order<PM_CIC>(c, order, d_phi, geo, d_pos, d_vel, np, half_dt, d_acc, work, lists, nblk, cd); break;
+        case PM_TSC: rc = codes_order<PM_TSC>(c, order, d_phi, geo, d_pos, d_vel, np, half_dt, d_acc, work, lists, nblk, cd); break;
+        default: pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme); rc = PM_EINVAL;
+    }
+    if (rc) return rc;
+    // (an in-place stream is only roughly tile-sorted: ranges looked up again after the next drift would come out
+    // different, and the per-workgroup counts belong to THESE)
+    PM_HIP(hipMemcpyAsync(b.start, work.start, ((size_t)ntiles + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    PM_HIP(hipMemcpyAsync(b.xstart, work.xstart, ((size_t)ntiles + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    c->kr_valid = 1, c->kr_checked = 0, c->kr_pos = d_pos, c->kr_np = np, c->kr_blocks = nblk;
+    return PM_OK;
+}
+
+// *h_ready = 1 if pm_kick_drift_wrap_deposit_rebucket can take the next step of d_pos / np: the last gather left its
+// decisions for exactly these arrays and no incoming list overflowed (one small read-back, once).
+extern "C" int pm_rebucket_kick_ready(pm_ctx *c, const float *d_pos, int64_t np, int *h_ready) {
+    PM_REQUIRE(c && h_ready, "NULL argument");
+    *h_ready = 0;
+    if (!c->kr_valid || c->kr_pos != d_pos || c->kr_np != np || !c->kr_buf) return PM_OK;
+    if (!c->kr_checked) {
+        const unsigned ntiles = (unsigned)(((int64_t)c->n * c->n * c->n) >> (PM_LI + PM_LJ + PM_LK));
+        KrBufs b;
+        int rc = kr_bufs(c, ntiles, np, &b);
+        if (rc) return rc;
+        unsigned over = 0;
+        rc = pm_read_back(c, &over, c->d_scratch + 8 + PM_SAMPLE_WORD + 4, sizeof(over));
+        if (rc) return rc;
+        c->kr_checked = 1;
+        if (over) c->kr_valid = 0;
+    }
+    *h_ready = c->kr_valid;
+    return PM_OK;
+}
+
+template <int SCHEME>
+static int kdw_rebucket_launch(pm_ctx *c, const float *pos, const float *vel, const float *acc, float half_dt, float dt,
+                               int64_t np, float *rho, float *khalo, float *pos_out, float *vel_out, const unsigned *id,
+                               unsigned *id_out) {
+    const unsigned ntiles = (unsigned)(((int64_t)c->n * c->n * c->n) >> (PM_LI + PM_LJ + PM_LK));
+    KrBufs kb;
+    int rc = kr_bufs(c, ntiles, np, &kb);
+    if (rc) return rc;
+    RbBufs rb;
+    rc = rebucket_bufs(c, ntiles, np, &rb);  // (before the ranges are looked up: it may move the table on file)
+    if (rc) return rc;
+    PM_REQUIRE(c->kr_valid, "the re-sort's buffers moved under the gather's decisions");
+    TileWork work;
+    tile_lists_drop(c);
+    tile_window(c, &work);
+    work.start = kb.start, work.xstart = kb.xstart;  // the old stream's ranges: the very table the gather decided on
+    const unsigned blocks = c->kr_blocks;
+    ListBufs lb;
+    rc = list_bufs(c, np, ntiles, &lb);
+    if (rc) return rc;
+    // layout of the new stream
+    int64_t *table = rb.table[c->rb_cur ^ 1];
+    const unsigned tb = (ntiles + 1 + BLK - 1) / BLK;
+    hipLaunchKernelGGL(kr_counts_kernel, dim3(tb), dim3(BLK), 0, c->stream, kb.tile_stay, kb.inc_count, kb.segstart, ntiles, rb.cnt);
+    PM_LAUNCH_CHECK();
+    size_t tmp = rb.scan_tmp_bytes;
+    PM_HIP(rocprim::exclusive_scan(rb.scan_tmp, tmp, rb.cnt, table, (int64_t)0, (size_t)ntiles + 1, rocprim::plus<int64_t>(), c->stream));
+    PM_HIP(hipMemsetAsync(rb.fill, 0, ((size_t)ntiles + 1) * sizeof(unsigned), c->stream));
+    KickReb kr;
+    kr.flag = kb.flag, kr.wg_stay = kb.wg_stay, kr.tile_stay = kb.tile_stay, kr.inc_count = kb.inc_count, kr.segstart = kb.segstart;
+    kr.entries = kb.entries, kr.newstart = table, kr.fill = rb.fill, kr.pos_out = pos_out, kr.vel_out = vel_out, kr.id = id, kr.id_out = id_out;
+    const size_t cells = (size_t)c->n * c->n * c->n;
+    const HaloBuf halo = halo_parts(khalo, c->n);
+    const size_t halo_bytes = (size_t)halo_floats(c->n, halo.nti) * sizeof(float);
+    if (!khalo) PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));
+    PM_HIP(hipMemsetAsync(lb.counts, 0, PM_NSUB * PM_SUB_STRIDE * sizeof(unsigned), c->stream));
+    const Leavers lv{0.f, 0.f, nullptr, 0, nullptr};
+    const DestCount dcount{nullptr, nullptr, nullptr, 0.f, 0.f};
+    float *posw = const_cast<float *>(pos), *velw = const_cast<float *>(vel);  // (read only by this instantiation)
+    hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME, true>), dim3(khalo ? work.nlaunch : blocks), dim3(BLK), 0, c->stream, posw, velw, acc,
+                       -half_dt, dt, work, pm_ctx_geom(c), rho, lb.k_in, lb.i_in, (unsigned)lb.subcap, lb.counts, lv, halo, dcount, kr);
+    if (khalo && blocks > work.nlaunch) {  // owners first (plain stores), then the surplus workgroups (atomics)
+        TileWork extra = work;
+        extra.boff = work.nlaunch;
+        hipLaunchKernelGGL((kdw_deposit_kernel<SCHEME, true>), dim3(blocks - work.nlaunch), dim3(BLK), 0, c->stream, posw, velw,
+                           acc, -half_dt, dt, extra, pm_ctx_geom(c), rho, lb.k_in, lb.i_in, (unsigned)lb.subcap, lb.counts, lv, halo,
+                           dcount, kr);
+    }
+    PM_LAUNCH_CHECK();
+    // the new stream: its offsets are on file, its ranges and straggler lists are what the gather of this step needs
+    c->rb_cur ^= 1;
+    c->sorted_pos = pos_out, c->sorted_np = np, c->sorted_ntiles = ntiles, c->sorted_table = table;
+    c->kr_valid = 0;
+    TileWork nwork;
+    unsigned nblocks = 0;
+    rc = tile_ranges(c, pos_out, np, &nwork, &nblocks);
+    if (rc) return rc;
+    const unsigned *idx = nullptr;
+    unsigned listed = 0;
+    int complete = 0;
+    rc = list_group(c, lb, ntiles, &idx, &listed, &complete);
+    if (rc) return rc;
+    c->lists_ptr[0] = nwork.start, c->lists_ptr[1] = nwork.xstart, c->lists_ptr[2] = idx, c->lists_ptr[3] = lb.lstart;
+    c->lists_blocks = nblocks;
+    if (!complete) {  // (stragglers bunched up beyond the lists: deposit the new stream again from scratch)
+        c->lists_pos = nullptr;
+        PM_HIP(hipMemsetAsync(rho, 0, cells * sizeof(float), c->stream));
+        if (khalo) PM_HIP(hipMemsetAsync(khalo, 0, halo_bytes, c->stream));
+        hipLaunchKernelGGL((deposit_tiled_kernel<SCHEME>), dim3((unsigned)((np + PM_CHUNK - 1) / PM_CHUNK)), dim3(BLK), 0, c->stream,
+                           pos_out, np, pm_ctx_geom(c), rho);
+        PM_LAUNCH_CHECK();
+        return PM_OK;
+    }
+    TileLists lists;
+    lists.idx = idx, lists.lstart = lb.lstart, lists.use = 1;
+    if (listed > 0 && (int64_t)listed * 400 < np) {
+        hipLaunchKernelGGL((deposit_list_flat_kernel<SCHEME>), dim3(pm_stream_blocks((int64_t)listed * 64, BLK)), dim3(BLK), 0, c->stream,
+                           pos_out, idx, listed, pm_ctx_geom(c), rho, halo);
+        PM_LAUNCH_CHECK();
+    } else if (listed > 0) {
+        hipLaunchKernelGGL((deposit_list_kernel<SCHEME>), dim3(ntiles), dim3(BLK), 0, c->stream, pos_out, lists, pm_ctx_geom(c), rho, halo);
+        PM_LAUNCH_CHECK();
+    }
+    c->lists_pos = pos_out, c->lists_np = np, c->lists_use = 1, c->lists_sticky = 1, c->stay_valid = 0, c->stay_codes = nullptr;
+    return PM_OK;
+}
+
+// The second half of "the kick re-buckets": pm_kick_drift_wrap_deposit[_khalo] (d_khalo NULL: plain flush) writing position
+// and velocity OUT OF PLACE into d_pos_out / d_vel_out, tile after tile, as the last pm_gradient_interp_kick_codes on
+// exactly d_pos / np decided (pm_rebucket_kick_ready).  d_pos / d_vel / d_acc are only read.  Leaves the new stream's
+// tile offsets on file and its ranges + straggler lists prepared, like the in-place form.
+extern "C" int pm_kick_drift_wrap_deposit_rebucket(pm_ctx *c, int scheme, const float *d_pos, const float *d_vel,
+                                                   const float *d_acc, float half_dt, float dt, int64_t np, float *d_rho,
+                                                   float *d_khalo, float *d_pos_out, float *d_vel_out, const unsigned *d_id,
+                                                   unsigned *d_id_out) {
+    PM_REQUIRE(c && d_pos && d_vel && d_acc && d_rho && d_pos_out && d_vel_out && np > 0 && np < 4294967296LL, "bad argument");
+    PM_REQUIRE(c->slab_nx == c->n && c->tile_nx == c->n && c->n >= 16, "single-GPU form, n >= 16");
+    PM_REQUIRE(d_pos_out != d_pos && d_vel_out != d_vel, "the new stream is written out of place");
+    PM_REQUIRE((!d_id) == (!d_id_out), "d_id / d_id_out must come as a pair");
+    PM_REQUIRE(c->kr_valid && c->kr_pos == d_pos && c->kr_np == np,
+               "no decisions on file for these arrays (pm_gradient_interp_kick_codes on the same d_pos first; pm_rebucket_kick_ready)");
+    switch (scheme) {
+        case PM_NGP: return kdw_rebucket_launch<PM_NGP>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, d_khalo, d_pos_out, d_vel_out, d_id, d_id_out);
+        case PM_CIC: return kdw_rebucket_launch<PM_CIC>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, d_khalo, d_pos_out, d_vel_out, d_id, d_id_out);
+        case PM_TSC: return kdw_rebucket_launch<PM_TSC>(c, d_pos, d_vel, d_acc, half_dt, dt, np, d_rho, d_khalo, d_pos_out, d_vel_out, d_id, d_id_out);
+    }
+    pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme);
+    return PM_EINVAL;
+}
+
 // A slab's migration changes the particle count of a stream that was written tile by tile: leavers' slots are refilled
 // (by arrivals or from the tail) and the surplus arrivals appended.  The tile offsets on file stay a partition of the
 // stream if they are clamped to the new count and the last one set to it -- the few particles that changed slots are
@@ -2900,7 +3438,7 @@ extern "C" int pm_set_predicted_acc_scale(pm_ctx *c, float scale) {
 
 extern "C" int pm_last_maxabs(pm_ctx *c, float *h_max_acc, float *h_max_vel) {
     PM_REQUIRE(c && h_max_acc && h_max_vel, "NULL argument");
-    unsigned bits[PM_SAMPLE_WORD + 4];
+    unsigned bits[PM_SAMPLE_WORD + 5];
     memset(bits, 0, sizeof(bits));
     if (int rb_rc = pm_read_back(c, bits, c->d_scratch + 8, sizeof(bits))) return rb_rc;
     memcpy(h_max_acc, &bits[0], sizeof(float));
@@ -2909,6 +3447,10 @@ extern "C" int pm_last_maxabs(pm_ctx *c, float *h_max_acc, float *h_max_vel) {
     memcpy(&sum, &bits[PM_SAMPLE_WORD], sizeof(double));
     const unsigned cnt = bits[PM_SAMPLE_WORD + 2];
     c->last_acc_meanabs = cnt >= 1024u ? sum / (double)cnt : 0.0;  // (came with the same copy; a handful of particles is no sample)
+    if (c->kr_valid && !c->kr_checked) {  // an incoming list of pm_gradient_interp_kick_codes overflowed: its decisions are void
+        c->kr_checked = 1;
+        if (bits[PM_SAMPLE_WORD + 4] != 0u) c->kr_valid = 0;
+    }
     if (bits[PM_SAMPLE_WORD + 3] != 0u) {
         // the re-bucketing gather found no slot for some particles: their records were NOT written (positions or
         // destination codes changed between the count and the gather).  The output arrays are incomplete.

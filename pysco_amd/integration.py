@@ -119,6 +119,9 @@ def euler(position, velocity, acceleration, potential, additional_field, dt, tab
 
 
 _PREDICT = True       # incremental re-sort: file particles under the tile they are expected to be in NEXT step
+_KICK_REBUCKETS = True  # ... decided by the gather (in place), carried out by the next fused kick + deposit, which
+                        # rewrites position and velocity anyway (pmstep.h: pm_gradient_interp_kick_codes); False: the
+                        # gather itself writes the three arrays out of place (pm_gradient_interp_kick_rebucket)
 _FUSE_DEPOSIT = True  # tests flip this to compare with the separate kick-drift-wrap and deposit
 _USE_KHALO = True     # ... and this for the plain flush (every tile cell through global atomics)
 _khalo_buffers = {}
@@ -140,6 +143,7 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
     the periodic wrap are one fused pass over the particle arrays."""
     half_dt = np.float32(0.5 * dt)
     acceleration_in = acceleration
+    kick_rebucketed = False
     fused = L.is_device_array(position) and L.is_device_array(velocity) and L.is_device_array(acceleration)
     density = None
     if fused:
@@ -167,7 +171,25 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
                               and param["linear_newton_solver"].casefold() in ("fft", "fft_7pt")
                               and 32 <= ncells_1d <= 1024 and solver._USE_FUSED_FFT
                               and param["save_power_spectrum"].casefold() == "no")
-            if _USE_KHALO and (khalo_consumer or _USE_KHALO == "always"):
+            use_khalo = bool(_USE_KHALO and (khalo_consumer or _USE_KHALO == "always"))
+            from . import mesh as _mesh
+
+            if (param.get("rebucket_straggler_fraction") is not None and _KICK_REBUCKETS
+                    and _mesh.kick_rebucket_ready(position, ncells_1d)):
+                # "the kick re-buckets": the last gather decided where every particle goes; this pass, which rewrites
+                # position and velocity anyway, writes them out of place in that order.  The arrays read become the
+                # next step's output arrays.
+                khalo = _khalo_buffer(torch, ncells_1d, position.device) if use_khalo else None
+                position_in, velocity_in = position, velocity
+                position, velocity, ids = _mesh.kick_drift_wrap_deposit_rebucket(
+                    scheme, position, velocity, acceleration, half_dt, dt, density, khalo, param.get("particle_id"))
+                _mesh.pool_give(position_in, velocity_in)
+                kick_rebucketed = True
+                if ids is not None:
+                    param["particle_id"] = ids
+                if use_khalo:
+                    density = (density, khalo)
+            elif use_khalo:
                 # the tiles' halo cells go to a side buffer and the own cells to the density, all with plain
                 # stores instead of memory-side atomics; solver.pm hands the buffer to the FFT solve (or has
                 # it added to the density)
@@ -191,11 +213,17 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
         utils.periodic_wrap(position)
     logging.info(f"{param['t']=} {param['aexp']=}")
     if fused:  # second kick fused into the interpolation kernel
-        rebucket = _rebucket_request(density, param, position)
+        rebucket = _rebucket_request(density, param, position, kick_rebucketed)
         acceleration, potential, additional_field = solver.pm(position, param, potential, additional_field, tables,
                                                               _kick=(velocity, half_dt), _density=density,
                                                               _rebucket=rebucket)
-        if rebucket is not None and "position" in rebucket:
+        if rebucket is not None and rebucket.get("mode") == "codes" and rebucket.get("done"):
+            # the gather stayed in place (a new acceleration array from the pool, the old one goes back): nothing permuted
+            from . import mesh
+
+            if acceleration_in.data_ptr() != acceleration.data_ptr():
+                mesh.pool_give(acceleration_in)
+        elif rebucket is not None and "position" in rebucket:
             # the gather wrote the arrays out of place, tile after tile (pmstep.h: pm_gradient_interp_kick_rebucket);
             # the arrays it read are stale from here on: they become the next step's output arrays
             from . import mesh
@@ -228,7 +256,7 @@ def _warn_if_aging(param) -> None:
                         "step's gather keep the stream tile-sorted (integrate() then returns new, permuted tensors)")
 
 
-def _rebucket_request(density, param, position):
+def _rebucket_request(density, param, position, kick_rebucketed=False):
     """Incremental re-sort policy (no reference counterpart; the reference re-sorts every n_reorder steps,
     main.py:146-150).  With param["rebucket_straggler_fraction"] = f set (main.run_nbody sets it to 0: every step), a
     step whose fused kick + drift + deposit found more than f of the particles outside the tile they are filed under has
@@ -246,6 +274,10 @@ def _rebucket_request(density, param, position):
     # stream left as it is hands the next step every tile crosser of that drift (a perfect prediction at 32^3 used
     # to be punished that way every other step)
     if float(thr) > 0.0 and frac <= float(thr):
+        return None
+    if _KICK_REBUCKETS and _PREDICT and float(thr) <= 0.0 and (param.get("_dt_pred") or 0.0) > 0.0:
+        return {"mode": "codes"}  # the gather decides, the next fused kick carries it out (every step: f <= 0 only)
+    if kick_rebucketed:  # (this step's fused kick already re-sorted, and left no counts for a re-bucketing gather)
         return None
     return {"ids": param.get("particle_id")}
 

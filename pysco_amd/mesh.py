@@ -247,3 +247,45 @@ def derivative_interp_vec_kick_rebucket(scheme_name: str, potential, order: int,
              L.ptr(ids_out))
     utils.register_fused_maxabs(ctx, acc, vel_out)
     return acc, pos_out, vel_out, ids_out
+
+
+def derivative_interp_vec_kick_codes(scheme_name: str, potential, order: int, position, velocity, half_dt):
+    """derivative_interp_vec_kick with the kick, in place (velocity kicked, acceleration returned, nothing permuted),
+    which also decides where the NEXT fused kick + drift + deposit files every particle (pmstep.h:
+    pm_gradient_interp_kick_codes; "the kick re-buckets").  Needs the tile lists the fused kick left prepared."""
+    from . import utils
+
+    n = potential.shape[1]
+    scheme = {"cic": L.CIC, "tsc": L.TSC, "ngp": L.NGP}[scheme_name]
+    if order not in (0, 2, 3, 5, 7):
+        raise ValueError(f"{order=}, should be 2, 3, 5 or 7")
+    ctx = L.context(n)
+    acc = _pool_take(position)
+    ctx.call("pm_gradient_interp_kick_codes", int(order), scheme, L.ptr(potential), L.ptr(position), L.ptr(velocity),
+             position.shape[0], float(np.float32(half_dt)), L.ptr(acc))
+    utils.register_fused_maxabs(ctx, acc, velocity)
+    return acc
+
+
+def kick_rebucket_ready(position, ncells_1d: int) -> bool:
+    """True if the last gather left its decisions for exactly these positions (pm_rebucket_kick_ready)."""
+    import ctypes as C
+
+    ready = C.c_int(0)
+    L.context(ncells_1d).call("pm_rebucket_kick_ready", L.ptr(position), position.shape[0], C.byref(ready))
+    return bool(ready.value)
+
+
+def kick_drift_wrap_deposit_rebucket(scheme: int, position, velocity, acceleration, half_dt, dt, density, khalo, ids=None):
+    """The fused first kick + drift + wrap + deposit writing the new position and velocity out of place, tile after tile,
+    as the last gather decided (pmstep.h: pm_kick_drift_wrap_deposit_rebucket).  Returns (position, velocity, ids) as NEW
+    tensors; the inputs are only read."""
+    torch = L.require_gpu()
+    n = density.shape[0]
+    pos_out, vel_out = _pool_take(position), _pool_take(velocity)
+    ids_out = None if ids is None else torch.empty_like(ids)
+    L.context(n).call("pm_kick_drift_wrap_deposit_rebucket", int(scheme), L.ptr(position), L.ptr(velocity), L.ptr(acceleration),
+                      float(np.float32(half_dt)), float(np.float32(dt)), position.shape[0], L.ptr(density), L.ptr(khalo),
+                      L.ptr(pos_out), L.ptr(vel_out), L.ptr(ids), L.ptr(ids_out))
+    return pos_out, vel_out, ids_out
+

@@ -95,7 +95,12 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
 
         if fuse_gradient:
             vel, half_dt = (None, 0.0) if _kick is None else _kick
-            if _rebucket is not None and vel is not None and L.is_device_array(position):
+            if (_rebucket is not None and _rebucket.get("mode") == "codes" and vel is not None
+                    and L.is_device_array(position)):
+                acceleration = mesh.derivative_interp_vec_kick_codes(MASS_SCHEME, potential_d, param["gradient_stencil_order"],
+                                                                     pos_d, vel, half_dt)
+                _rebucket["done"] = True
+            elif _rebucket is not None and vel is not None and L.is_device_array(position):
                 acceleration, _rebucket["position"], _rebucket["velocity"], _rebucket["ids"] = (
                     mesh.derivative_interp_vec_kick_rebucket(MASS_SCHEME, potential_d, param["gradient_stencil_order"],
                                                              pos_d, vel, half_dt, _rebucket.get("ids")))
@@ -106,7 +111,11 @@ def pm(position, param, potential=None, additional_field=None, tables: List = ()
             if not lists_complete:
                 ctx.call("pm_set_gather_mode", 2)  # chunk / anchor kernel: any particle order through LDS
             try:
-                if _rebucket is not None and lists_complete and L.is_device_array(position):
+                if (_rebucket is not None and _rebucket.get("mode") == "codes" and lists_complete
+                        and L.is_device_array(position)):
+                    acceleration = mesh.derivative_interp_vec_kick_codes(MASS_SCHEME, force, 0, pos_d, _kick[0], _kick[1])
+                    _rebucket["done"] = True
+                elif _rebucket is not None and lists_complete and L.is_device_array(position):
                     acceleration, _rebucket["position"], _rebucket["velocity"], _rebucket["ids"] = (
                         mesh.derivative_interp_vec_kick_rebucket(MASS_SCHEME, force, 0, pos_d, _kick[0], _kick[1],
                                                                  _rebucket.get("ids")))

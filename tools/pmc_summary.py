@@ -18,6 +18,10 @@ STAGES = {
     "pm_kick_drift_wrap_deposit_khalo": ["kdw_deposit_kernel", "deposit_list_kernel", "deposit_list_flat_kernel", "tile_extra_kernel",
                                          "tile_bounds_kernel", "list_compact_kernel", "list_bounds_kernel", "rocprim"],
     "pm_gradient_interp_kick_rebucket": ["interp_ranges_kernel<3, 5, true, true>", "rebucket_counts_kernel"],
+    # round 3, "the kick re-buckets": the gather in place + decisions, the fused kick writing the new stream
+    "pm_gradient_interp_kick_codes": ["interp_ranges_kernel<3, 5, true, false, true>", "kr_segcap_kernel"],
+    "pm_kick_drift_wrap_deposit_rebucket": ["kdw_deposit_kernel<3, true>", "kr_counts_kernel", "deposit_list_kernel", "deposit_list_flat_kernel",
+                                            "tile_extra_kernel", "list_compact_kernel", "list_bounds_kernel", "rocprim"],
     "pm_gradient_interp_kick": ["interp_ranges_kernel<3, 5, true, false>"],
     "pm_poisson_fft_fused_khalo": ["fftp_z_r2c", "fftp_y<", "fftp_x_green", "fftp_z_c2r"],
 }
@@ -67,8 +71,10 @@ for stage, pats in STAGES.items():
     if not ks:
         continue
     calls = a.steps if stage != "pm_gradient_interp_kick" else max(1, sum(v["launches"] for v in ks.values()))
-    if stage == "pm_gradient_interp_kick_rebucket":
+    if stage in ("pm_gradient_interp_kick_rebucket", "pm_gradient_interp_kick_codes"):
         calls = max(1, sum(v["launches"] for k, v in ks.items() if "interp_ranges" in k))
+    if stage == "pm_kick_drift_wrap_deposit_rebucket":
+        calls = max(1, sum(v["launches"] for k, v in ks.items() if "kr_counts_kernel" in k))
     f, w = sum(v["fetch"] for v in ks.values()), sum(v["write"] for v in ks.values())
     stages[stage] = {"calls": calls, "fetch_bytes_per_call": f / calls, "write_bytes_per_call": w / calls,
                      "hbm_bytes_per_call": (f + w) / calls,

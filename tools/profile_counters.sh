@@ -12,6 +12,6 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFL
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/wait -- python3 $R/bench.py --gpus 1 --steps 3 --warmup 9 --no-cpu-baseline --no-secondary > $OUT/wait.log 2>&1 || true
 for p in valu lds wait; do
   f=$(ls $OUT/$p/*/*_counter_collection.csv 2>/dev/null | head -1)
-  [ -n "$f" ] && python3 $R/tools/pmc_table.py $f "interp_ranges_kernel<3, 5, true, true>" "kdw_deposit_kernel" "fftp_x_green" >> $OUT/table.txt
+  [ -n "$f" ] && python3 $R/tools/pmc_table.py $f "interp_ranges_kernel<3, 5, true, false, true>" "kdw_deposit_kernel<3, true>" "fftp_x_green" >> $OUT/table.txt
 done
 cat $OUT/table.txt
