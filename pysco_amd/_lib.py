@@ -110,6 +110,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_vcycle_graph_stats": (_vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)),
     "pm_lap_smoothing": (_vp, _vp, _vp, _i, _i),
     "pm_fr_vcycle": (_vp, _i, _vp, _vp, _f, _i, _i, _i),
+    "pm_fr_smoothing": (_vp, _i, _vp, _vp, _f, _vp, _i, _i),
     "pm_set_fused_sweep": (_vp, _i),
     "pm_lap_gauss_seidel": (_vp, _vp, _vp, _i, _f),
     "pm_cubic_operator": (_vp, _vp, _vp, _f, _vp, _i, _vp),
@@ -221,7 +222,7 @@ def require_gpu():
 
 # entry points that run on a level of a multigrid hierarchy: position of their grid-size argument (after the context),
 # so that the stage profiler files the calls per level ("pm_lap_gauss_seidel@512")
-_PROFILE_SIZE_ARG = {"pm_lap_gauss_seidel": 2, "pm_lap_smoothing": 2, "pm_fr_vcycle": 4, "pm_lap_vcycle": 2, "pm_lap_solve": 2, "pm_fr_solve": 4, "pm_lap_restrict_residual": 2, "pm_lap_operator": 2,
+_PROFILE_SIZE_ARG = {"pm_lap_gauss_seidel": 2, "pm_lap_smoothing": 2, "pm_fr_smoothing": 5, "pm_fr_vcycle": 4, "pm_lap_vcycle": 2, "pm_lap_solve": 2, "pm_fr_solve": 4, "pm_lap_restrict_residual": 2, "pm_lap_operator": 2,
                      "pm_lap_residual_error": 2, "pm_prolongation": 2, "pm_restriction": 1, "pm_cubic_gauss_seidel": 4,
                      "pm_quartic_gauss_seidel": 4, "pm_cubic_operator": 4, "pm_quartic_operator": 4,
                      "pm_cubic_residual_error": 3, "pm_quartic_residual_error": 3, "pm_mond_rhs": 2}

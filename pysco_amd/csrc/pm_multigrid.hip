@@ -815,12 +815,24 @@ __device__ __forceinline__ float gs_update_cls(int cls, float xm, float xp, floa
     }
 }
 
+// The cell update of the linear sweep: gs_update with the summation order of the cell's parity class.
+struct LapCell {
+    static constexpr bool HAS_RHS = false;
+    float h2, invsix, f_relax;
+    __device__ __forceinline__ float operator()(int cls, float xm, float xp, float ym, float yp, float zm, float zp, float bval,
+                                                float, float xc) const {
+        return gs_update_cls(cls, xm, xp, ym, yp, zm, zp, -(h2 * bval), xc, invsix, f_relax);
+    }
+};
+
 // GF_LX planes per workgroup: 32, or 64 from 512^3 up (three planes of lead-in per segment instead of three per 32:
-// 0.42 -> 0.40 ms per sweep at 512^3; at 256^3 64 planes leave 256 workgroups for 256 CUs and the V-cycle loses 4 %)
-template <int GF_LX>
-__global__ __launch_bounds__(BLK) void lap_gs_fused_kernel(const float *__restrict__ xin, const float *__restrict__ b,
-                                                           float *__restrict__ xout, int log2n, float h2, float invsix,
-                                                           float f_relax) {
+// 0.42 -> 0.40 ms per sweep at 512^3; at 256^3 64 planes leave 256 workgroups for 256 CUs and the V-cycle loses 4 %).
+// CELL: the update of one cell from its six neighbours, its density term b (and right-hand side, CELL::HAS_RHS) and
+// its own value -- LapCell here, FrCell (the f(R) scalaron's cubic / quartic root) further down.
+template <int GF_LX, class CELL>
+__global__ __launch_bounds__(BLK) void gs_fused_kernel(const float *__restrict__ xin, const float *__restrict__ b,
+                                                       const float *__restrict__ rhs, float *__restrict__ xout, int log2n,
+                                                       CELL cell) {
     __shared__ __attribute__((aligned(16))) float pl[GF_SLOTS][GF_PLANE];  // 28.8 KB
     const int n = 1 << log2n, m = n - 1, tid = threadIdx.x;
     const int ncol_k = n / GF_TK, ncol_j = n / GF_TJ;
@@ -844,6 +856,10 @@ __global__ __launch_bounds__(BLK) void lap_gs_fused_kernel(const float *__restri
     auto b_quad = [&](int p) -> float4 {
         return *reinterpret_cast<const float4 *>(b + cidx((i0 + p) & m, jq, k0 + 4 * kq, log2n));
     };
+    auto r_quad = [&](int p) -> float4 {
+        if constexpr (CELL::HAS_RHS) return *reinterpret_cast<const float4 *>(rhs + cidx((i0 + p) & m, jq, k0 + 4 * kq, log2n));
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
     // the thread's cell of the ring around the own region (tid < GF_RING): LDS row / column and global j, k
     int ring_r = 0, ring_c = 0;
     if (tid < GF_TK + 2) ring_r = 1, ring_c = 3 + tid;
@@ -854,24 +870,28 @@ __global__ __launch_bounds__(BLK) void lap_gs_fused_kernel(const float *__restri
     auto b_ring = [&](int p) -> float {
         return tid < GF_RING ? b[cidx((i0 + p) & m, ring_j, ring_k, log2n)] : 0.f;
     };
+    auto r_ring = [&](int p) -> float {
+        if constexpr (CELL::HAS_RHS) return tid < GF_RING ? rhs[cidx((i0 + p) & m, ring_j, ring_k, log2n)] : 0.f;
+        return 0.f;
+    };
     // new value of the cell at LDS (row offset ro, column c) of plane p (relative), parities from the global indices
-    auto update = [&](int p, int ro, int c, int gj, int gk, float bval) -> float {
+    auto update = [&](int p, int ro, int c, int gj, int gk, float bval, float rval) -> float {
         const float *vm = slot(p - 1), *v0 = slot(p), *vp = slot(p + 1);
         const int o = ro + c;
         const int cls = ((((i0 + p) & 1) << 2) | ((gj & 1) << 1) | (gk & 1));
-        return gs_update_cls(cls, vm[o], vp[o], v0[o - GF_ROW], v0[o + GF_ROW], v0[o - 1], v0[o + 1], -(h2 * bval), v0[o],
-                             invsix, f_relax);
+        return cell(cls, vm[o], vp[o], v0[o - GF_ROW], v0[o + GF_ROW], v0[o - 1], v0[o + 1], bval, rval, v0[o]);
     };
     // red cells (i + j + k odd) of plane p, in place in LDS: the two of the own quad + the ring cell if it is red
-    auto red_phase = [&](int p, float4 bq, float br) {
+    auto red_phase = [&](int p, float4 bq, float br, float4 rq4, float rring) {
         const int e0 = ((i0 + p) + jq + 1) & 1;  // k offsets e0, e0 + 2 of the quad are red
         const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+        const float rb[4] = {rq4.x, rq4.y, rq4.z, rq4.w};
         float *v0 = slot(p);
-        const float r0 = update(p, lrow, lcol + e0, jq, e0, bb[e0]);
-        const float r1 = update(p, lrow, lcol + e0 + 2, jq, e0, bb[e0 + 2]);
+        const float r0 = update(p, lrow, lcol + e0, jq, e0, bb[e0], rb[e0]);
+        const float r1 = update(p, lrow, lcol + e0 + 2, jq, e0, bb[e0 + 2], rb[e0 + 2]);
         float rr = 0.f;
         const bool ring_red = tid < GF_RING && (((i0 + p) + ring_j + ring_k) & 1);
-        if (ring_red) rr = update(p, ring_r * GF_ROW, ring_c, ring_j, ring_k, br);
+        if (ring_red) rr = update(p, ring_r * GF_ROW, ring_c, ring_j, ring_k, br, rring);
         v0[lrow + lcol + e0] = r0, v0[lrow + lcol + e0 + 2] = r1;
         if (ring_red) v0[ring_r * GF_ROW + ring_c] = rr;
     };
@@ -882,21 +902,23 @@ __global__ __launch_bounds__(BLK) void lap_gs_fused_kernel(const float *__restri
         q_put(p, f0, *q_src(p, f0));
         if (f1 < GF_Q4) q_put(p, f1, *q_src(p, f1));
     }
-    float4 bq_m1 = b_quad(-1), bq_0 = b_quad(0);
-    float br_m1 = b_ring(-1), br_0 = b_ring(0);
+    float4 bq_m1 = b_quad(-1), bq_0 = b_quad(0), rq_m1 = r_quad(-1), rq_0 = r_quad(0);
+    float br_m1 = b_ring(-1), br_0 = b_ring(0), rr_m1 = r_ring(-1), rr_0 = r_ring(0);
     pf0 = *q_src(1, f0);
     if (f1 < GF_Q4) pf1 = *q_src(1, f1);
     __syncthreads();
-    red_phase(-1, bq_m1, br_m1);
+    red_phase(-1, bq_m1, br_m1, rq_m1, rr_m1);
     q_put(1, f0, pf0);
     if (f1 < GF_Q4) q_put(1, f1, pf1);
     pf0 = *q_src(2, f0);
     if (f1 < GF_Q4) pf1 = *q_src(2, f1);
     float4 bq_next = b_quad(1);  // b of plane i + 1 (red phase of step i), then of plane i (black phase of step i + 1)
     float br_next = b_ring(1);
+    float4 rq_next = r_quad(1);
+    float rr_next = r_ring(1);
     __syncthreads();
-    red_phase(0, bq_0, br_0);
-    float4 bq_cur = bq_0;  // b of plane i for the black phase
+    red_phase(0, bq_0, br_0, rq_0, rr_0);
+    float4 bq_cur = bq_0, rq_cur = rq_0;  // b (and rhs) of plane i for the black phase
 
 #pragma unroll 1
     for (int i = 0; i < GF_LX; ++i) {
@@ -907,25 +929,26 @@ __global__ __launch_bounds__(BLK) void lap_gs_fused_kernel(const float *__restri
             pf0 = *q_src(i + 3, f0);
             if (f1 < GF_Q4) pf1 = *q_src(i + 3, f1);
         }
-        const float4 bq_r = bq_next;
-        const float br_r = br_next;
-        if (i + 1 < GF_LX) bq_next = b_quad(i + 2), br_next = b_ring(i + 2);
+        const float4 bq_r = bq_next, rq_r = rq_next;
+        const float br_r = br_next, rr_r = rr_next;
+        if (i + 1 < GF_LX) bq_next = b_quad(i + 2), br_next = b_ring(i + 2), rq_next = r_quad(i + 2), rr_next = r_ring(i + 2);
         __syncthreads();
         // c. red cells of plane i + 1
-        red_phase(i + 1, bq_r, br_r);
+        red_phase(i + 1, bq_r, br_r, rq_r, rr_r);
         __syncthreads();
         // e. black cells of plane i (own quad), then the whole quad of plane i leaves
         {
             const int e0 = ((i0 + i) + jq + 1) & 1;  // reds at e0, e0 + 2; blacks at 1 - e0, 3 - e0
             const float bb[4] = {bq_cur.x, bq_cur.y, bq_cur.z, bq_cur.w};
+            const float rb[4] = {rq_cur.x, rq_cur.y, rq_cur.z, rq_cur.w};
             const float *v0 = slot(i);
             float q[4];
             q[e0] = v0[lrow + lcol + e0], q[e0 + 2] = v0[lrow + lcol + e0 + 2];
-            q[1 - e0] = update(i, lrow, lcol + 1 - e0, jq, 1 - e0, bb[1 - e0]);
-            q[3 - e0] = update(i, lrow, lcol + 3 - e0, jq, 1 - e0, bb[3 - e0]);
+            q[1 - e0] = update(i, lrow, lcol + 1 - e0, jq, 1 - e0, bb[1 - e0], rb[1 - e0]);
+            q[3 - e0] = update(i, lrow, lcol + 3 - e0, jq, 1 - e0, bb[3 - e0], rb[3 - e0]);
             *reinterpret_cast<float4 *>(xout + cidx((i0 + i) & m, jq, k0 + 4 * kq, log2n)) = make_float4(q[0], q[1], q[2], q[3]);
         }
-        bq_cur = bq_r;
+        bq_cur = bq_r, rq_cur = rq_r;
     }
 }
 
@@ -944,17 +967,17 @@ static int lap_smooth_pp(pm_ctx *c, float *cur, float *other, const float *b, in
             if ((rc = pm_lap_gauss_seidel(c, cur, b, n, f_relax))) return rc;
         return PM_OK;
     }
-    const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
+    const LapCell cell{(float)(1.0 / ((double)n * n)), (float)(1.0 / 6), f_relax};
     const int lx = n >= 512 ? 64 : 32;
     const unsigned blocks = (unsigned)((n / GF_TJ) * (n / GF_TK) * (n / lx));
     float *src = cur, *dst = other;
     for (int s = 0; s < n_sweeps; ++s) {
         if (lx == 64)
-            hipLaunchKernelGGL(lap_gs_fused_kernel<64>, dim3(blocks), dim3(BLK), 0, c->stream, src, b, dst, ilog2(n), h2, invsix,
-                               f_relax);
+            hipLaunchKernelGGL((gs_fused_kernel<64, LapCell>), dim3(blocks), dim3(BLK), 0, c->stream, src, b, (const float *)nullptr,
+                               dst, ilog2(n), cell);
         else
-            hipLaunchKernelGGL(lap_gs_fused_kernel<32>, dim3(blocks), dim3(BLK), 0, c->stream, src, b, dst, ilog2(n), h2, invsix,
-                               f_relax);
+            hipLaunchKernelGGL((gs_fused_kernel<32, LapCell>), dim3(blocks), dim3(BLK), 0, c->stream, src, b, (const float *)nullptr,
+                               dst, ilog2(n), cell);
         PM_LAUNCH_CHECK();
         float *t = src;
         src = dst, dst = t;
@@ -1226,6 +1249,21 @@ __device__ __forceinline__ float fr_lead(float x) {
     return FRN == 1 ? x * x * x : (x * x) * (x * x);
 }
 
+// One Newton step of t^3 + p t + d1 / 27 from the fp32 estimate t0: the residual in fp64 (it is a difference of terms
+// 10^6 times its size), the slope and the quotient in fp32 -- the correction is ~1e-6 of t0, so its own 1e-7 relative
+// error is 1e-13 of the root -- and the sum rounded once.  Against the all-fp64 step this is the same float but for
+// rounding-boundary cases, without the fp64 division (35 half-rate instructions of the ~150 of a root).  Returns false
+// where the step is more than 1 % of t0 (a bad start: near-double roots, cancellation): the caller then evaluates the
+// reference's closed form in fp64.
+__device__ __forceinline__ bool cubic_newton(float t0, float pf, double p, double d1, float *out) {
+    const double t = (double)t0;
+    const double f = fma(fma(t, t, p), t, d1 * (1.0 / 27));
+    const float slope = fmaf(3.0f * t0, t0, pf);
+    const float delta = (float)f / slope;
+    *out = t0 - delta;
+    return fabsf(delta) <= 0.01f * fabsf(t0);
+}
+
 // cubic.py:162-207 solution_cubic_equation: fp64, same branch structure (NaNs included)
 __device__ __forceinline__ double cubic_root(float pf, float d1f) {
     const double inv3 = 1.0 / 3;
@@ -1241,10 +1279,8 @@ __device__ __forceinline__ double cubic_root(float pf, float d1f) {
             const float hf = d1f >= 0.0f ? 0.5f * (d1f + sf) : 54.0f * (pf * pf * pf) / (sf - d1f);
             if (hf > 1.0e-30f && hf < 1.0e30f) {
                 const float Cf = cbrtf(hf);
-                double t = (double)(-0.33333334f * (Cf - 3.0f * pf / Cf));
-                const double q = d1 * (1.0 / 27);
-                t -= ((t * t + p) * t + q) / (3.0 * (t * t) + p);
-                return t;
+                float t;
+                if (cubic_newton(-0.33333334f * (Cf - 3.0f * pf / Cf), pf, p, d1, &t)) return (double)t;
             }
         }
         d = d1 + sqrt(d);
@@ -1261,10 +1297,9 @@ __device__ __forceinline__ double cubic_root(float pf, float d1f) {
         {
             const float d0f = -3.0f * pf, sd0f = sqrtf(d0f), df = d1f / (2.0f * (d0f * sd0f));
             if (fabsf(df) < 0.875f) {
-                double t = (double)(-0.66666667f * sd0f * cosf(0.33333333f * (acosf(df) + 6.2831853f)));
-                const double q = d1 * (1.0 / 27);
-                t -= ((t * t + p) * t + q) / (3.0 * (t * t) + p);
-                return (double)(float)t;
+                float t;
+                if (cubic_newton(-0.66666667f * sd0f * cosf(0.33333333f * (acosf(df) + 6.2831853f)), pf, p, d1, &t))
+                    return (double)t;
             }
         }
         const double d0 = -3.0 * p;  // > 0 here (d < 0 needs p < 0)
@@ -1649,6 +1684,14 @@ static void fr_gauss_seidel_launch(pm_ctx *c, bool rows, float *d_x, const float
     }
 }
 
+// c_q of the f(R) sweeps: 27 h^2 q for the cubic (d1 = c_q - 27 rhs), q h^2 for the quartic (qq = c_q - rhs)
+template <int FRN>
+static float fr_c_q(float q, float h2, bool with_rhs) {
+    if (FRN == 2) return q * h2;                 // quartic.py:306, 488
+    if (with_rhs) return 27.0f * h2 * q;         // cubic.py:487 (all fp32)
+    return (float)(27.0 * (double)h2 * (double)q);  // cubic.py:305 (int * f4 -> f8, then f4)
+}
+
 template <int FRN>
 static int fr_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, const float *d_rhs, int n, float f_relax,
                            XRange xr, int gpar, int colours) {
@@ -1658,13 +1701,7 @@ static int fr_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, con
     const int blocks = pm_stream_blocks(total, BLK);
     const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
     const int l2 = ilog2(n);
-    float c_q;
-    if (FRN == 2)
-        c_q = q * h2;  // quartic.py:306, 488
-    else if (d_rhs)
-        c_q = 27.0f * h2 * q;  // cubic.py:487 (all fp32)
-    else
-        c_q = (float)(27.0 * (double)h2 * (double)q);  // cubic.py:305 (int * f4 -> f8, then f4)
+    const float c_q = fr_c_q<FRN>(q, h2, d_rhs != nullptr);
     const bool red = colours == 3 || colours == 1, black = colours == 3 || colours == 0;
     const bool rows = c->fr_rows_sweep && n >= 16 && pm_aligned16(d_x) && pm_aligned16(d_b) && (!d_rhs || pm_aligned16(d_rhs));
     (void)total, (void)blocks;
@@ -1676,6 +1713,83 @@ static int fr_gauss_seidel(pm_ctx *c, float *d_x, const float *d_b, float q, con
         if (black) fr_gauss_seidel_launch<0, false, FRN>(c, rows, d_x, d_b, c_q, d_rhs, l2, h2, invsix, f_relax, xr, gpar);
     }
     PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// The cell update of the f(R) sweeps for the single-pass kernel (gs_fused_kernel): cubic_p's sum in its order, the root,
+// the relaxation -- the expression of the two kernels above.
+template <bool WITH_RHS, int FRN>
+struct FrCell {
+    static constexpr bool HAS_RHS = WITH_RHS;
+    float h2, invsix, f_relax, c_q;
+    __device__ __forceinline__ float operator()(int, float xm, float xp, float ym, float yp, float zm, float zp, float bval,
+                                                float rval, float xc) const {
+        const float p = h2 * bval - invsix * (fr_pw<FRN>(xm) + fr_pw<FRN>(ym) + fr_pw<FRN>(zm) + fr_pw<FRN>(zp) + fr_pw<FRN>(yp) +
+                                              fr_pw<FRN>(xp));
+        float sol;
+        if (FRN == 1) {
+            const float d1 = WITH_RHS ? c_q - 27.0f * rval : c_q;
+            sol = (float)cubic_root(p, d1);
+        } else {
+            const float qq = WITH_RHS ? c_q - rval : c_q;
+            sol = (float)quartic_root(p, qq);
+        }
+        return xc + f_relax * (sol - xc);
+    }
+};
+
+// n_sweeps red + black sweeps of the scalaron starting from `cur`: the single-pass kernel ping-ponging between `cur` and
+// `other` where it applies (n >= 256, as lap_smooth_pp), the two half-sweep launches in place otherwise.  *where = the
+// array that holds the result.
+template <int FRN>
+static int fr_smooth_pp(pm_ctx *c, float *cur, float *other, const float *b, float q, const float *rhs, int n, int n_sweeps,
+                        float f_relax, float **where) {
+    int rc;
+    *where = cur;
+    if (!lap_fused_applies(c, n, cur, b, other) || (rhs && !pm_aligned16(rhs))) {
+        for (int s = 0; s < n_sweeps; ++s)
+            if ((rc = fr_gauss_seidel<FRN>(c, cur, b, q, rhs, n, f_relax, xr_cube(n), 0, 3))) return rc;
+        return PM_OK;
+    }
+    const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
+    const float c_q = fr_c_q<FRN>(q, h2, rhs != nullptr);
+    const int lx = n >= 512 ? 64 : 32;
+    const unsigned blocks = (unsigned)((n / GF_TJ) * (n / GF_TK) * (n / lx));
+    float *src = cur, *dst = other;
+    for (int s = 0; s < n_sweeps; ++s) {
+#define FR_FUSED(LX, WITH)                                                                                                   \
+    hipLaunchKernelGGL((gs_fused_kernel<LX, FrCell<WITH, FRN>>), dim3(blocks), dim3(BLK), 0, c->stream, src, b, rhs, dst, ilog2(n), \
+                       FrCell<WITH, FRN>{h2, invsix, f_relax, c_q})
+        if (lx == 64) {
+            if (rhs) FR_FUSED(64, true);
+            else FR_FUSED(64, false);
+        } else {
+            if (rhs) FR_FUSED(32, true);
+            else FR_FUSED(32, false);
+        }
+#undef FR_FUSED
+        PM_LAUNCH_CHECK();
+        float *t = src;
+        src = dst, dst = t;
+    }
+    *where = src;
+    return PM_OK;
+}
+
+// cubic.py:1065 smoothing / :1100 smoothing_with_rhs (quartic.py:1066, 1101) on device arrays: n_smoothing sweeps with
+// omega = 1.25, result in d_x
+extern "C" int pm_fr_smoothing(pm_ctx *c, int fr_n, float *d_x, const float *d_b, float q, const float *d_rhs, int n,
+                               int n_smoothing) {
+    PM_REQUIRE(c && d_x && d_b && n_smoothing >= 0 && (fr_n == 1 || fr_n == 2), "bad argument");
+    PM_CHECK_GRID(n);
+    float *tmp = nullptr, *where = d_x;
+    int rc;
+    if (n >= 256 && (rc = mg_arena(c, ((size_t)n * n * n + 1024) * sizeof(float), &tmp))) return rc;
+    rc = fr_n == 1 ? fr_smooth_pp<1>(c, d_x, tmp, d_b, q, d_rhs, n, n_smoothing, 1.25f, &where)
+                   : fr_smooth_pp<2>(c, d_x, tmp, d_b, q, d_rhs, n, n_smoothing, 1.25f, &where);
+    if (rc) return rc;
+    if (where != d_x)
+        PM_HIP(hipMemcpyAsync(d_x, where, (size_t)n * n * n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return PM_OK;
 }
 
@@ -1715,17 +1829,20 @@ static int fr_vcycle_level(pm_ctx *c, float *x, const float *b, float q, const f
                            float *scratch) {
     const float f_relax = 1.25f;  // cubic.py:1092 / quartic.py
     int rc;
-    for (int s = 0; s < npre; ++s)
-        if ((rc = fr_gauss_seidel<FRN>(c, x, b, q, rhs, n, f_relax, xr_cube(n), 0, 3))) return rc;
     const int nc = n / 2;
     const int64_t cells = (int64_t)n * n * n, ccells = (int64_t)nc * nc * nc;
-    // scratch of this level: one fine grid (operator / residual), five coarse ones
+    // scratch of this level: one fine grid (the single-pass sweeps' ping-pong partner, then operator / residual), five
+    // coarse ones
     float *fine = scratch, *res_c = fine + cells, *x_c = res_c + ccells, *x_corr_c = x_c + ccells, *b_c = x_corr_c + ccells,
           *L_c = b_c + ccells, *next = L_c + ccells;
+    const bool pingpong = lap_fused_applies(c, n, x, b, fine) && (!rhs || pm_aligned16(rhs));
+    float *cur = x;  // the array that holds the level's solution at the moment; the other of (x, fine) is free
+    if ((rc = fr_smooth_pp<FRN>(c, x, fine, b, q, rhs, n, npre, f_relax, &cur))) return rc;
+    float *op = cur == x ? fine : x;
     // multigrid.restrict_residual (:282): no rhs -> minus_restriction(operator); rhs -> restriction(rhs - operator)
-    if ((rc = fr_operator<FRN>(c, x, b, q, rhs, n, fine, xr_cube(n)))) return rc;
-    if ((rc = pm_restriction(c, fine, n, rhs ? 0.125f : -0.125f, res_c))) return rc;
-    if ((rc = pm_restriction(c, x, n, 0.125f, x_c))) return rc;
+    if ((rc = fr_operator<FRN>(c, cur, b, q, rhs, n, op, xr_cube(n)))) return rc;
+    if ((rc = pm_restriction(c, op, n, rhs ? 0.125f : -0.125f, res_c))) return rc;
+    if ((rc = pm_restriction(c, cur, n, 0.125f, x_c))) return rc;
     PM_HIP(hipMemcpyAsync(x_corr_c, x_c, (size_t)ccells * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     if ((rc = pm_restriction(c, b, n, 0.125f, b_c))) return rc;
     if ((rc = fr_operator<FRN>(c, x_c, b_c, q, nullptr, nc, L_c, xr_cube(nc)))) return rc;
@@ -1738,9 +1855,12 @@ static int fr_vcycle_level(pm_ctx *c, float *x, const float *b, float q, const f
         return rc;
     }
     if ((rc = pm_axpy(c, x_corr_c, x_c, -1.0f, ccells))) return rc;
-    if ((rc = pm_prolongation(c, x, x_corr_c, nc, 1))) return rc;
-    for (int s = 0; s < npost; ++s)
-        if ((rc = fr_gauss_seidel<FRN>(c, x, b, q, rhs, n, f_relax, xr_cube(n), 0, 3))) return rc;
+    // the corrected solution goes where an odd / even number of ping-pong sweeps will leave the result in x
+    float *target = pingpong && (npost & 1) ? fine : x;
+    if ((rc = prolongation_launch(c, target, x_corr_c, nc, 1, xr_cube(n), xr_cube(nc), cur))) return rc;
+    float *where = target;
+    if ((rc = fr_smooth_pp<FRN>(c, target, target == x ? fine : x, b, q, rhs, n, npost, f_relax, &where))) return rc;
+    if (where != x) PM_HIP(hipMemcpyAsync(x, where, (size_t)cells * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return PM_OK;
 }
 
@@ -1752,8 +1872,10 @@ extern "C" int pm_fr_vcycle(pm_ctx *c, int fr_n, float *d_x, const float *d_b, f
     float *scratch = nullptr;
     int rc = mg_arena(c, ((size_t)n * n * n * 13 / 7 + 4096) * sizeof(float), &scratch);
     if (rc) return rc;
-    return fr_n == 1 ? fr_vcycle_level<1>(c, d_x, d_b, q, nullptr, n, npre, npost, scratch)
-                     : fr_vcycle_level<2>(c, d_x, d_b, q, nullptr, n, npre, npost, scratch);
+    return vcycle_graphed(c, 4 * fr_n + (c->mg_fused_sweep ? 1 : 0) + (c->fr_rows_sweep ? 2 : 0), d_x, d_b, q, n, npre, npost, [&]() {
+        return fr_n == 1 ? fr_vcycle_level<1>(c, d_x, d_b, q, nullptr, n, npre, npost, scratch)
+                         : fr_vcycle_level<2>(c, d_x, d_b, q, nullptr, n, npre, npost, scratch);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------

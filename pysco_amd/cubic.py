@@ -63,14 +63,20 @@ def gauss_seidel_with_rhs(x, b, q, rhs, f_relax) -> None:  # cubic.py:446
     _gs(x, b, q, f_relax, rhs)
 
 
-def smoothing(x, b, q, n_smoothing: int) -> None:  # cubic.py:1065
+def _smooth(x, b, q, n_smoothing, rhs) -> None:
+    if L.is_device_array(x) and L.is_device_array(b) and (rhs is None or L.is_device_array(rhs)):
+        L.context(4).call("pm_fr_smoothing", 1, L.ptr(x), L.ptr(b), float(np.float32(q)), L.ptr(rhs), x.shape[0], int(n_smoothing))
+        return
     for _ in range(int(n_smoothing)):
-        gauss_seidel(x, b, q, np.float32(1.25))
+        _gs(x, b, q, np.float32(1.25), rhs)
+
+
+def smoothing(x, b, q, n_smoothing: int) -> None:  # cubic.py:1065
+    _smooth(x, b, q, n_smoothing, None)
 
 
 def smoothing_with_rhs(x, b, q, n_smoothing: int, rhs) -> None:  # cubic.py:1100
-    for _ in range(int(n_smoothing)):
-        gauss_seidel_with_rhs(x, b, q, rhs, np.float32(1.25))
+    _smooth(x, b, q, n_smoothing, rhs)
 
 
 def residual_error(x, b, q) -> np.float32:  # cubic.py:844

@@ -455,6 +455,43 @@ def test_single_pass_sweep_is_the_two_half_sweeps(amd, n, sweeps):
         assert bool((vc[1] == vc[0]).all())
 
 
+@pytest.mark.parametrize("n,fr_n,with_rhs,sweeps", [(256, 1, False, 1), (256, 1, False, 2), (256, 1, True, 3), (256, 2, True, 1),
+                                                   (256, 2, False, 2), (512, 1, False, 2)])
+def test_fr_single_pass_sweep_is_the_two_half_sweeps(amd, n, fr_n, with_rhs, sweeps):
+    """The f(R) smoothers' single-pass red + black sweep (pm_fr_smoothing, n >= 256: the marching kernel of the linear
+    sweep with the cubic / quartic cell update) against the two half-sweep launches per sweep: the same bits, whole
+    grid; and a whole FAS V-cycle (pm_fr_vcycle: ping-pong sweeps, out-of-place prolongation, graph replay) through
+    both."""
+    from pysco_amd import _lib as L
+
+    t = amd.torch
+    g = t.Generator(device="cuda")
+    g.manual_seed(3 * n + 7 * fr_n + sweeps)
+    b = t.rand((n, n, n), generator=g, device="cuda") * 0.5 + 0.2
+    x0 = t.rand((n, n, n), generator=g, device="cuda") * 0.2 + 0.9
+    rhs = (t.rand((n, n, n), generator=g, device="cuda") - 0.5) * 1e-3 if with_rhs else None
+    ctx = L.context(4)
+    out, vc = {}, {}
+    try:
+        for fused in (1, 0):
+            ctx.call("pm_set_fused_sweep", fused)
+            x = x0.clone()
+            ctx.call("pm_fr_smoothing", fr_n, L.ptr(x), L.ptr(b), -0.1, L.ptr(rhs), n, sweeps)
+            out[fused] = x
+            if sweeps == 2 and not with_rhs:
+                x = x0.clone()
+                for _ in range(2):  # the second call replays the captured graph
+                    ctx.call("pm_fr_vcycle", fr_n, L.ptr(x), L.ptr(b), -0.1, n, 2, 1)
+                vc[fused] = x
+    finally:
+        ctx.call("pm_set_fused_sweep", 1)
+    assert bool(t.isfinite(out[1]).all()) and float((out[1] - x0).abs().max()) > 0
+    assert bool((out[1] == out[0]).all()), float((out[1] - out[0]).abs().max())
+    if vc:
+        assert bool(t.isfinite(vc[1]).all()) and float((vc[1] - x0).abs().max()) > 0
+        assert bool((vc[1] == vc[0]).all()), float((vc[1] - vc[0]).abs().max())
+
+
 def test_mond_and_fR_at_benchmark_size(amd):
     """BASELINE configs 4 and 5 at their full 512^3, where the oracle cannot follow: size-independent properties.
     QUMOND: the multigrid and the fft_7pt solver solve the same two discrete Poisson problems (Newtonian potential,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-step kernel durations from a rocprofv3 --kernel-trace CSV of bench.py: one column per step (a step starts at
-its tile_bounds_kernel / tile_extra_kernel launch), one row per kernel, milliseconds.
+its tile_bounds_kernel / tile_extra_kernel launch, or at kr_counts_kernel when the fused kick re-buckets), one row per kernel, milliseconds.
     python tools/trace_per_step.py <kernel_trace.csv> [every]"""
 import collections
 import csv
@@ -19,7 +19,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 steps, cur = [], None
 for r in rows:
     nm = r["Kernel_Name"]
-    if "tile_bounds_kernel" in nm or ("tile_extra_kernel" in nm and (cur is None or "kdw_deposit_kernel<3>" in cur)):
+    if ("tile_bounds_kernel" in nm or "kr_counts_kernel" in nm
+            or ("tile_extra_kernel" in nm and (cur is None or "kdw_deposit_kernel<3>" in cur))):
         cur = collections.OrderedDict()
         steps.append(cur)
     if cur is None or nm.startswith("void at::") or "at::native" in nm:
