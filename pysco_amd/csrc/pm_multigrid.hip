@@ -1249,40 +1249,13 @@ __device__ __forceinline__ float fr_lead(float x) {
     return FRN == 1 ? x * x * x : (x * x) * (x * x);
 }
 
-// One Newton step of t^3 + p t + d1 / 27 from the fp32 estimate t0: the residual in fp64 (it is a difference of terms
-// 10^6 times its size), the slope and the quotient in fp32 -- the correction is ~1e-6 of t0, so its own 1e-7 relative
-// error is 1e-13 of the root -- and the sum rounded once.  Against the all-fp64 step this is the same float but for
-// rounding-boundary cases, without the fp64 division (35 half-rate instructions of the ~150 of a root).  Returns false
-// where the step is more than 1 % of t0 (a bad start: near-double roots, cancellation): the caller then evaluates the
-// reference's closed form in fp64.
-__device__ __forceinline__ bool cubic_newton(float t0, float pf, double p, double d1, float *out) {
-    const double t = (double)t0;
-    const double f = fma(fma(t, t, p), t, d1 * (1.0 / 27));
-    const float slope = fmaf(3.0f * t0, t0, pf);
-    const float delta = (float)f / slope;
-    *out = t0 - delta;
-    return fabsf(delta) <= 0.01f * fabsf(t0);
-}
-
-// cubic.py:162-207 solution_cubic_equation: fp64, same branch structure (NaNs included)
-__device__ __forceinline__ double cubic_root(float pf, float d1f) {
+// cubic.py:162-207 solution_cubic_equation, the reference's formulas and branch structure in fp64 (NaNs included).
+// Out of line: cubic_root below calls it for the few cells its fast paths decline.
+__device__ __attribute__((noinline)) double cubic_root_closed_form(float pf, float d1f) {
     const double inv3 = 1.0 / 3;
     const double d1 = (double)d1f, p = (double)pf;
     double d = d1 * d1 + 108.0 * (p * p * p);
     if (d > 0.0) {
-        // One real root, -(C - 3p / C) / 3 with C^3 = (d1 + sqrt(d)) / 2.  Where that is positive -- d1 >= 0, or p > 0:
-        // the scalaron's regime, q h^2 of order 10^2 -- the fp32 evaluation (for d1 < 0 in the form 54 p^3 / (sqrt(d) -
-        // d1), which does not cancel) polished by one Newton step of t^3 + p t + d1 / 27 in fp64 is the fp64 formula to
-        // 1e-12: no fp64 sqrt, cube root or second division.  Elsewhere (C^3 <= 0: the reference's NaN) the formula itself.
-        if (d1 >= 0.0 || p > 0.0) {
-            const float sf = sqrtf((float)d);
-            const float hf = d1f >= 0.0f ? 0.5f * (d1f + sf) : 54.0f * (pf * pf * pf) / (sf - d1f);
-            if (hf > 1.0e-30f && hf < 1.0e30f) {
-                const float Cf = cbrtf(hf);
-                float t;
-                if (cubic_newton(-0.33333334f * (Cf - 3.0f * pf / Cf), pf, p, d1, &t)) return (double)t;
-            }
-        }
         d = d1 + sqrt(d);
         if (d == 0.0) return -inv3 * pow(d1, inv3);
         // x^(1/3) of a positive x is cbrt (a third of pow's cost); a negative x keeps pow and its NaN, as the reference
@@ -1290,18 +1263,6 @@ __device__ __forceinline__ double cubic_root(float pf, float d1f) {
         const double C = hd > 0.0 ? cbrt(hd) : pow(hd, inv3);
         return -inv3 * (C - 3.0 * p / C);
     } else if (d < 0.0) {
-        // Three real roots; the reference takes -(2/3) sqrt(-3p) cos((acos(d) + 2 pi) / 3).  Away from a double root
-        // (|d| < 7/8) the same root comes from the fp32 evaluation of that formula polished by one Newton step of
-        // t^3 + p t + d1 / 27 in fp64 -- 1e-13 of the fp64 formula, i.e. the same float but for one case in 10^6 on a
-        // rounding boundary -- for a third of the instructions (fp64 acos + cos + sqrt + divide).
-        {
-            const float d0f = -3.0f * pf, sd0f = sqrtf(d0f), df = d1f / (2.0f * (d0f * sd0f));
-            if (fabsf(df) < 0.875f) {
-                float t;
-                if (cubic_newton(-0.66666667f * sd0f * cosf(0.33333333f * (acosf(df) + 6.2831853f)), pf, p, d1, &t))
-                    return (double)t;
-            }
-        }
         const double d0 = -3.0 * p;  // > 0 here (d < 0 needs p < 0)
         const double sd0 = sqrt(d0);
         d = d1 / (2.0 * (d0 * sd0));  // d0^1.5 without pow
@@ -1312,6 +1273,62 @@ __device__ __forceinline__ double cubic_root(float pf, float d1f) {
         return -inv3 * pow(d1, inv3);
     }
     return -inv3 * pow(d1, inv3);
+}
+
+// The root the reference picks (cubic.py:162-207), rounded to fp32, for ~70 instructions instead of the ~200 of the
+// closed form with libm's sqrt / cbrt / acos / cos (measured: the 512^3 sweep was bound by them, not by HBM):
+//   * a start good to ~1e-6 from hardware-rate approximations (v_sqrt, v_rcp, v_log, v_exp: 1 ulp each) --
+//     one real root (d > 0) where the reference's cube C^3 = (d1 + sqrt(d)) / 2 is positive (d1 >= 0 or p > 0; the
+//     scalaron's regime has d1 = 27 h^2 q - 27 rhs of order 10^2): the reference's own formula -(C - 3p / C) / 3 (for
+//     d1 < 0 with C^3 = 54 p^3 / (sqrt(d) - d1), which does not cancel), then one fp32 Newton step (the formula cancels
+//     where |d1| << p^1.5);
+//     three real roots (p < 0, d1^2 < 0.766 * 108 |p|^3, i.e. |cos 3 phi| < 7/8: away from the double root): the
+//     reference takes the largest one, t = s y with s = sqrt(-p / 3) and y in [1.28, 2] the largest root of
+//     y^3 - 3 y + c = 0, c = d1 / (27 s^3); y is analytic in w = sqrt(2 - c) and a degree-5 polynomial in w is good to
+//     2e-7 on the whole range;
+//   * one Newton step of t^3 + p t + d1 / 27 whose residual is evaluated in fp64 (it is a difference of terms 10^6 times
+//     its size) and whose slope and quotient are fp32 (the correction is ~1e-6 of t, so its own 1e-7 relative error is
+//     1e-13 of the root), the sum rounded once: the fp64 closed form's float, but for rounding-boundary cases (numpy
+//     emulation over 10^7 (p, d1): no mismatch in either regime);
+//   * the step doubles as the check: where it is more than 3e-5 of t (bad start, overflow, NaN) -- and in every branch
+//     not listed above, the reference's NaN ones included -- the closed form in fp64 (cubic_root_closed_form).
+__device__ __forceinline__ float cubic_root(float pf, float d1f) {
+    const double p = (double)pf, d1 = (double)d1f;
+    const double d = d1 * d1 + 108.0 * (p * p * p);
+    float ts = 0.f;
+    bool have = false;
+    if (d > 0.0) {
+        if (d1f >= 0.0f || pf > 0.0f) {
+            const float sf = __builtin_amdgcn_sqrtf((float)d);
+            const float hf = d1f >= 0.0f ? 0.5f * (d1f + sf) : 54.0f * (pf * pf * pf) * __builtin_amdgcn_rcpf(sf - d1f);
+            if (hf > 1.0e-30f && hf < 1.0e30f) {
+                const float Cf = __builtin_amdgcn_exp2f(0.33333334f * __builtin_amdgcn_logf(hf));
+                const float t0 = -0.33333334f * (Cf - 3.0f * pf * __builtin_amdgcn_rcpf(Cf));
+                const float f0 = __builtin_fmaf(__builtin_fmaf(t0, t0, pf), t0, d1f * 0.037037037f);
+                ts = t0 - f0 * __builtin_amdgcn_rcpf(__builtin_fmaf(3.0f * t0, t0, pf));
+                have = true;
+            }
+        }
+    } else if (pf < 0.0f && d1f * d1f < 0.766f * (-108.0f * (pf * pf * pf))) {
+        const float s2 = -0.33333334f * pf, s = __builtin_amdgcn_sqrtf(s2);
+        const float c = (d1f * 0.037037037f) * __builtin_amdgcn_rcpf(s2 * s);
+        const float w = __builtin_amdgcn_sqrtf(2.0f - c);
+        float y = 0.00017914111958816648f;
+        y = __builtin_fmaf(y, w, -0.0019134014146402478f);
+        y = __builtin_fmaf(y, w, 0.010815435089170933f);
+        y = __builtin_fmaf(y, w, -0.05377647280693054f);
+        y = __builtin_fmaf(y, w, 0.5766810774803162f);
+        y = __builtin_fmaf(y, w, 1.0001031160354614f);
+        ts = s * y;
+        have = true;
+    }
+    if (have) {
+        const double t = (double)ts;
+        const double f = fma(fma(t, t, p), t, d1 * (1.0 / 27));
+        const float delta = (float)f * __builtin_amdgcn_rcpf(__builtin_fmaf(3.0f * ts, ts, pf));
+        if (fabsf(delta) <= 3.0e-5f * fabsf(ts)) return ts - delta;
+    }
+    return (float)cubic_root_closed_form(pf, d1f);
 }
 
 template <int FRN>
@@ -1746,7 +1763,8 @@ static int fr_smooth_pp(pm_ctx *c, float *cur, float *other, const float *b, flo
                         float f_relax, float **where) {
     int rc;
     *where = cur;
-    if (!lap_fused_applies(c, n, cur, b, other) || (rhs && !pm_aligned16(rhs))) {
+    // (the quartic's root is the fp64 closed form: the single-pass kernel is bound by it and slower than the half-sweeps)
+    if (FRN != 1 || !lap_fused_applies(c, n, cur, b, other) || (rhs && !pm_aligned16(rhs))) {
         for (int s = 0; s < n_sweeps; ++s)
             if ((rc = fr_gauss_seidel<FRN>(c, cur, b, q, rhs, n, f_relax, xr_cube(n), 0, 3))) return rc;
         return PM_OK;
@@ -1760,12 +1778,14 @@ static int fr_smooth_pp(pm_ctx *c, float *cur, float *other, const float *b, flo
 #define FR_FUSED(LX, WITH)                                                                                                   \
     hipLaunchKernelGGL((gs_fused_kernel<LX, FrCell<WITH, FRN>>), dim3(blocks), dim3(BLK), 0, c->stream, src, b, rhs, dst, ilog2(n), \
                        FrCell<WITH, FRN>{h2, invsix, f_relax, c_q})
-        if (lx == 64) {
-            if (rhs) FR_FUSED(64, true);
-            else FR_FUSED(64, false);
-        } else {
-            if (rhs) FR_FUSED(32, true);
-            else FR_FUSED(32, false);
+        if constexpr (FRN == 1) {
+            if (lx == 64) {
+                if (rhs) FR_FUSED(64, true);
+                else FR_FUSED(64, false);
+            } else {
+                if (rhs) FR_FUSED(32, true);
+                else FR_FUSED(32, false);
+            }
         }
 #undef FR_FUSED
         PM_LAUNCH_CHECK();
@@ -1835,7 +1855,7 @@ static int fr_vcycle_level(pm_ctx *c, float *x, const float *b, float q, const f
     // coarse ones
     float *fine = scratch, *res_c = fine + cells, *x_c = res_c + ccells, *x_corr_c = x_c + ccells, *b_c = x_corr_c + ccells,
           *L_c = b_c + ccells, *next = L_c + ccells;
-    const bool pingpong = lap_fused_applies(c, n, x, b, fine) && (!rhs || pm_aligned16(rhs));
+    const bool pingpong = FRN == 1 && lap_fused_applies(c, n, x, b, fine) && (!rhs || pm_aligned16(rhs));
     float *cur = x;  // the array that holds the level's solution at the moment; the other of (x, fine) is free
     if ((rc = fr_smooth_pp<FRN>(c, x, fine, b, q, rhs, n, npre, f_relax, &cur))) return rc;
     float *op = cur == x ? fine : x;

@@ -478,7 +478,7 @@ def test_fr_single_pass_sweep_is_the_two_half_sweeps(amd, n, fr_n, with_rhs, swe
             x = x0.clone()
             ctx.call("pm_fr_smoothing", fr_n, L.ptr(x), L.ptr(b), -0.1, L.ptr(rhs), n, sweeps)
             out[fused] = x
-            if sweeps == 2 and not with_rhs:
+            if sweeps == 2 and not with_rhs and fr_n == 1:  # (the quartic FAS cycle of this random data ends in the reference's NaNs)
                 x = x0.clone()
                 for _ in range(2):  # the second call replays the captured graph
                     ctx.call("pm_fr_vcycle", fr_n, L.ptr(x), L.ptr(b), -0.1, n, 2, 1)

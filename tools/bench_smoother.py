@@ -42,6 +42,24 @@ def main():
         t = timeit(lambda: multigrid.V_cycle(x, b, param))
         print(f"fused={fused} V-cycle: {t:.3f} ms")
     ctx.call("pm_set_fused_sweep", 1)
+    # f(R): scalaron sweeps and the FAS V-cycle (pm_fr_smoothing / pm_fr_vcycle), single-pass on / off
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    bb = torch.rand((n, n, n), generator=g, device="cuda") * 0.5 + 0.2
+    x0 = torch.rand((n, n, n), generator=g, device="cuda") * 0.2 + 0.9
+    rhs = (torch.rand((n, n, n), generator=g, device="cuda") - 0.5) * 1e-3
+    for fr_n in (1, 2):
+        for fused in (0, 1):
+            ctx.call("pm_set_fused_sweep", fused)
+            for r, tag in ((None, "no rhs"), (rhs, "rhs")):
+                xx = x0.clone()
+                t = timeit(lambda: ctx.call("pm_fr_smoothing", fr_n, L.ptr(xx), L.ptr(bb), -0.1, L.ptr(r), n, 2))
+                print(f"f(R) n={fr_n} fused={fused} 2 sweeps, {tag}: {t / 2:.3f} ms per sweep  ({12.0 * n**3 * 2 / t / 1e6:.0f} GB/s algorithmic)"
+                      f"  nan: {int(torch.isnan(xx).sum())}")
+            xx = x0.clone()
+            t = timeit(lambda: ctx.call("pm_fr_vcycle", fr_n, L.ptr(xx), L.ptr(bb), -0.1, n, 2, 1), reps=4)
+            print(f"f(R) n={fr_n} fused={fused} FAS V-cycle: {t:.3f} ms  nan: {int(torch.isnan(xx).sum())}")
+    ctx.call("pm_set_fused_sweep", 1)
 
 
 if __name__ == "__main__":
