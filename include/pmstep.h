@@ -349,6 +349,10 @@ int pm_set_fused_coarse(pm_ctx *ctx, int on);
 /* on (default): the f(R) smoothers (pm_cubic / pm_quartic_gauss_seidel, pm_fr_vcycle) run their row kernels for
  * n >= 16 -- eight consecutive k-cells per thread, 16-byte accesses, same expression per cell; off: a cell per thread. */
 int pm_set_fr_rows_sweep(pm_ctx *ctx, int on);
+/* on (default): pm_mond_rhs evaluates the simple interpolating function (mond.py:16-34, kind 0) as
+ * 1/2 + sqrt(1/4 + g0 / |grad|) with the hardware's 1-ulp reciprocal square root and square root (1.5e-7 relative, the
+ * size of the exact chain's own roundings); off: IEEE sqrt, divide, sqrt as the reference writes it (comparison). */
+int pm_set_mond_fast_nu(pm_ctx *ctx, int on);
 int pm_set_vcycle_graphs(pm_ctx *ctx, int mode);
 int pm_vcycle_graph_stats(pm_ctx *ctx, unsigned *replayed, unsigned *captured);
 /* laplacian.gauss_seidel :844: one red + one black sweep with over-relaxation f_relax, in place */

@@ -1923,10 +1923,21 @@ __device__ __forceinline__ float mond_nu(float y, float alpha) {
     return powf(1.0f - expf(-powf(y, (float)(0.5 * alpha))), (float)(-1.0 / alpha));
 }
 
+// nu of y = |grad| / g0 from the SQUARED gradient norm s.  FAST (the simple function only, the default): nu = 1/2 +
+// sqrt(1/4 + g0 rsq(s)) with the hardware's 1-ulp v_rsq_f32 / v_sqrt_f32 -- 1.5e-7 relative, the size of the six
+// roundings of the exact chain sqrt, * 1/g0, 1/y, + 1/4, sqrt, + 1/2 -- instead of two IEEE square roots and an IEEE
+// division (12 + 12 + 10 instructions, six times per cell: the 512^3 kernel was bound by them at 0.10 of the HBM
+// roofline).  s = 0 gives inf either way.  pm_set_mond_fast_nu(ctx, 0) restores the exact chain (comparison).
+template <int KIND, bool FAST>
+__device__ __forceinline__ float mond_nu_sq(float s, float inv_g0, float g0, float alpha) {
+    if (FAST && KIND == 0) return 0.5f + __builtin_amdgcn_sqrtf(0.25f + g0 * __builtin_amdgcn_rsqf(s));
+    return mond_nu<KIND>(sqrtf(s) * inv_g0, alpha);
+}
+
 // mond.py:171-316 rhs_simple and its four siblings
-template <int KIND>
+template <int KIND, bool FAST>
 __global__ __launch_bounds__(BLK) void mond_rhs_kernel(const float *__restrict__ pot, float *__restrict__ out,
-                                                       int log2n, float inv_g0, float alpha, XRange xr) {
+                                                       int log2n, float inv_g0, float g0, float alpha, XRange xr) {
     const int n = 1 << log2n, m = n - 1;
     const float invh = (float)n, inv4h = (float)(0.25 * n);
     const int64_t total = (int64_t)xr.ni << (2 * log2n);
@@ -1939,30 +1950,30 @@ __global__ __launch_bounds__(BLK) void mond_rhs_kernel(const float *__restrict__
         const float Axx = invh * (p000 - P(im1, j, k));
         const float Axy = inv4h * (P(i, jp1, k) - P(i, jm1, k) + P(im1, jp1, k) - P(im1, jm1, k));
         const float Axz = inv4h * (P(i, j, kp1) - P(i, j, km1) + P(im1, j, kp1) - P(im1, j, km1));
-        const float fAx = sqrtf(Axx * Axx + Axy * Axy + Axz * Axz);
+        const float sAx = Axx * Axx + Axy * Axy + Axz * Axz;
         const float Bxx = invh * (-p000 + P(ip1, j, k));
         const float Bxy = inv4h * (P(ip1, jp1, k) - P(ip1, jm1, k) + P(i, jp1, k) - P(i, jm1, k));
         const float Bxz = inv4h * (P(ip1, j, kp1) - P(ip1, j, km1) + P(i, j, kp1) - P(i, j, km1));
-        const float fBx = sqrtf(Bxx * Bxx + Bxy * Bxy + Bxz * Bxz);
+        const float sBx = Bxx * Bxx + Bxy * Bxy + Bxz * Bxz;
         const float Ayy = invh * (p000 - P(i, jm1, k));
         const float Ayx = inv4h * (P(ip1, j, k) - P(im1, j, k) + P(ip1, jm1, k) - P(im1, jm1, k));
         const float Ayz = inv4h * (P(i, j, kp1) - P(i, j, km1) + P(i, jm1, kp1) - P(i, jm1, km1));
-        const float fAy = sqrtf(Ayx * Ayx + Ayy * Ayy + Ayz * Ayz);
+        const float sAy = Ayx * Ayx + Ayy * Ayy + Ayz * Ayz;
         const float Byy = invh * (-p000 + P(i, jp1, k));
         const float Byx = inv4h * (P(ip1, jp1, k) - P(im1, jp1, k) + P(ip1, j, k) - P(im1, j, k));
         const float Byz = inv4h * (P(i, jp1, kp1) - P(i, jp1, km1) + P(i, j, kp1) - P(i, j, km1));
-        const float fBy = sqrtf(Byx * Byx + Byy * Byy + Byz * Byz);
+        const float sBy = Byx * Byx + Byy * Byy + Byz * Byz;
         const float Azz = invh * (p000 - P(i, j, km1));
         const float Azx = inv4h * (P(ip1, j, k) - P(im1, j, k) + P(ip1, j, km1) - P(im1, j, km1));
         const float Azy = inv4h * (P(i, jp1, k) - P(i, jm1, k) + P(i, jp1, km1) - P(i, jm1, km1));
-        const float fAz = sqrtf(Azx * Azx + Azy * Azy + Azz * Azz);
+        const float sAz = Azx * Azx + Azy * Azy + Azz * Azz;
         const float Bzz = invh * (-p000 + P(i, j, kp1));
         const float Bzx = inv4h * (P(ip1, j, kp1) - P(im1, j, kp1) + P(ip1, j, k) - P(im1, j, k));
         const float Bzy = inv4h * (P(i, jp1, kp1) - P(i, jm1, kp1) + P(i, jp1, k) - P(i, jm1, k));
-        const float fBz = sqrtf(Bzx * Bzx + Bzy * Bzy + Bzz * Bzz);
-        const float nAx = mond_nu<KIND>(fAx * inv_g0, alpha), nAy = mond_nu<KIND>(fAy * inv_g0, alpha),
-                    nAz = mond_nu<KIND>(fAz * inv_g0, alpha), nBx = mond_nu<KIND>(fBx * inv_g0, alpha),
-                    nBy = mond_nu<KIND>(fBy * inv_g0, alpha), nBz = mond_nu<KIND>(fBz * inv_g0, alpha);
+        const float sBz = Bzx * Bzx + Bzy * Bzy + Bzz * Bzz;
+        const float nAx = mond_nu_sq<KIND, FAST>(sAx, inv_g0, g0, alpha), nAy = mond_nu_sq<KIND, FAST>(sAy, inv_g0, g0, alpha),
+                    nAz = mond_nu_sq<KIND, FAST>(sAz, inv_g0, g0, alpha), nBx = mond_nu_sq<KIND, FAST>(sBx, inv_g0, g0, alpha),
+                    nBy = mond_nu_sq<KIND, FAST>(sBy, inv_g0, g0, alpha), nBz = mond_nu_sq<KIND, FAST>(sBz, inv_g0, g0, alpha);
         out[t] = invh * (nBx * Bxx - nAx * Axx + nBy * Byy - nAy * Ayy + nBz * Bzz - nAz * Azz);
     }
 #undef P
@@ -1971,9 +1982,9 @@ __global__ __launch_bounds__(BLK) void mond_rhs_kernel(const float *__restrict__
 // Four consecutive k-cells per thread (n >= 16): the nine rows (i-1..i+1, j-1..j+1) as one aligned float4 each, the
 // five rows of the "plus" stencil with their k-1 / k+4 neighbours -- 19 loads for four cells where the cell-per-thread
 // kernel issues 76 -- and the same expressions per cell (1.49 -> ms at 512^3).
-template <int KIND>
+template <int KIND, bool FAST>
 __global__ __launch_bounds__(BLK) void mond_rhs_rows_kernel(const float *__restrict__ pot, float *__restrict__ out,
-                                                            int log2n, float inv_g0, float alpha, XRange xr) {
+                                                            int log2n, float inv_g0, float g0, float alpha, XRange xr) {
     const int n = 1 << log2n, m = n - 1, lq = log2n - 2;
     const float invh = (float)n, inv4h = (float)(0.25 * n);
     const int64_t total = ((int64_t)xr.ni << log2n) << lq;
@@ -1999,47 +2010,47 @@ __global__ __launch_bounds__(BLK) void mond_rhs_rows_kernel(const float *__restr
         const float Axx = invh * (p000 - Pl[0][1][kk]);
         const float Axy = inv4h * (Pl[1][2][kk] - Pl[1][0][kk] + Pl[0][2][kk] - Pl[0][0][kk]);
         const float Axz = inv4h * (Pl[1][1][kk + 1] - Pl[1][1][kk - 1] + Pl[0][1][kk + 1] - Pl[0][1][kk - 1]);
-        const float fAx = sqrtf(Axx * Axx + Axy * Axy + Axz * Axz);
+        const float sAx = Axx * Axx + Axy * Axy + Axz * Axz;
         const float Bxx = invh * (-p000 + Pl[2][1][kk]);
         const float Bxy = inv4h * (Pl[2][2][kk] - Pl[2][0][kk] + Pl[1][2][kk] - Pl[1][0][kk]);
         const float Bxz = inv4h * (Pl[2][1][kk + 1] - Pl[2][1][kk - 1] + Pl[1][1][kk + 1] - Pl[1][1][kk - 1]);
-        const float fBx = sqrtf(Bxx * Bxx + Bxy * Bxy + Bxz * Bxz);
+        const float sBx = Bxx * Bxx + Bxy * Bxy + Bxz * Bxz;
         const float Ayy = invh * (p000 - Pl[1][0][kk]);
         const float Ayx = inv4h * (Pl[2][1][kk] - Pl[0][1][kk] + Pl[2][0][kk] - Pl[0][0][kk]);
         const float Ayz = inv4h * (Pl[1][1][kk + 1] - Pl[1][1][kk - 1] + Pl[1][0][kk + 1] - Pl[1][0][kk - 1]);
-        const float fAy = sqrtf(Ayx * Ayx + Ayy * Ayy + Ayz * Ayz);
+        const float sAy = Ayx * Ayx + Ayy * Ayy + Ayz * Ayz;
         const float Byy = invh * (-p000 + Pl[1][2][kk]);
         const float Byx = inv4h * (Pl[2][2][kk] - Pl[0][2][kk] + Pl[2][1][kk] - Pl[0][1][kk]);
         const float Byz = inv4h * (Pl[1][2][kk + 1] - Pl[1][2][kk - 1] + Pl[1][1][kk + 1] - Pl[1][1][kk - 1]);
-        const float fBy = sqrtf(Byx * Byx + Byy * Byy + Byz * Byz);
+        const float sBy = Byx * Byx + Byy * Byy + Byz * Byz;
         const float Azz = invh * (p000 - Pl[1][1][kk - 1]);
         const float Azx = inv4h * (Pl[2][1][kk] - Pl[0][1][kk] + Pl[2][1][kk - 1] - Pl[0][1][kk - 1]);
         const float Azy = inv4h * (Pl[1][2][kk] - Pl[1][0][kk] + Pl[1][2][kk - 1] - Pl[1][0][kk - 1]);
-        const float fAz = sqrtf(Azx * Azx + Azy * Azy + Azz * Azz);
+        const float sAz = Azx * Azx + Azy * Azy + Azz * Azz;
         const float Bzz = invh * (-p000 + Pl[1][1][kk + 1]);
         const float Bzx = inv4h * (Pl[2][1][kk + 1] - Pl[0][1][kk + 1] + Pl[2][1][kk] - Pl[0][1][kk]);
         const float Bzy = inv4h * (Pl[1][2][kk + 1] - Pl[1][0][kk + 1] + Pl[1][2][kk] - Pl[1][0][kk]);
-        const float fBz = sqrtf(Bzx * Bzx + Bzy * Bzy + Bzz * Bzz);
-        const float nAx = mond_nu<KIND>(fAx * inv_g0, alpha), nAy = mond_nu<KIND>(fAy * inv_g0, alpha),
-                    nAz = mond_nu<KIND>(fAz * inv_g0, alpha), nBx = mond_nu<KIND>(fBx * inv_g0, alpha),
-                    nBy = mond_nu<KIND>(fBy * inv_g0, alpha), nBz = mond_nu<KIND>(fBz * inv_g0, alpha);
+        const float sBz = Bzx * Bzx + Bzy * Bzy + Bzz * Bzz;
+        const float nAx = mond_nu_sq<KIND, FAST>(sAx, inv_g0, g0, alpha), nAy = mond_nu_sq<KIND, FAST>(sAy, inv_g0, g0, alpha),
+                    nAz = mond_nu_sq<KIND, FAST>(sAz, inv_g0, g0, alpha), nBx = mond_nu_sq<KIND, FAST>(sBx, inv_g0, g0, alpha),
+                    nBy = mond_nu_sq<KIND, FAST>(sBy, inv_g0, g0, alpha), nBz = mond_nu_sq<KIND, FAST>(sBz, inv_g0, g0, alpha);
         res[c2] = invh * (nBx * Bxx - nAx * Axx + nBy * Byy - nAy * Ayy + nBz * Bzz - nAz * Azz);
         }
         *reinterpret_cast<float4 *>(out + cidx(i, j, k0, log2n)) = make_float4(res[0], res[1], res[2], res[3]);
     }
 }
 
-template <int KIND>
-static void mond_rhs_launch_kind(pm_ctx *c, bool rows, const float *d_pot, float *d_out, int l2, float inv_g0, float alpha,
-                                 XRange xr) {
+template <int KIND, bool FAST>
+static void mond_rhs_launch_kind(pm_ctx *c, bool rows, const float *d_pot, float *d_out, int l2, float inv_g0, float g0,
+                                 float alpha, XRange xr) {
     const int n = 1 << l2;
     const int64_t total = (int64_t)xr.ni * n * n;
     if (rows)
-        hipLaunchKernelGGL((mond_rhs_rows_kernel<KIND>), dim3(pm_stream_blocks(total / 4, BLK)), dim3(BLK), 0, c->stream, d_pot,
-                           d_out, l2, inv_g0, alpha, xr);
+        hipLaunchKernelGGL((mond_rhs_rows_kernel<KIND, FAST>), dim3(pm_stream_blocks(total / 4, BLK)), dim3(BLK), 0, c->stream,
+                           d_pot, d_out, l2, inv_g0, g0, alpha, xr);
     else
-        hipLaunchKernelGGL((mond_rhs_kernel<KIND>), dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_pot, d_out, l2,
-                           inv_g0, alpha, xr);
+        hipLaunchKernelGGL((mond_rhs_kernel<KIND, FAST>), dim3(pm_stream_blocks(total, BLK)), dim3(BLK), 0, c->stream, d_pot,
+                           d_out, l2, inv_g0, g0, alpha, xr);
 }
 
 static int mond_rhs_launch(pm_ctx *c, const float *d_pot, float *d_out, int n, float g0, int kind, float alpha,
@@ -2049,16 +2060,26 @@ static int mond_rhs_launch(pm_ctx *c, const float *d_pot, float *d_out, int n, f
     // (the row form shares the switch of the f(R) smoothers' row kernels: pm_set_fr_rows_sweep)
     const bool rows = c->fr_rows_sweep && n >= 16 && pm_aligned16(d_pot) && pm_aligned16(d_out);
     switch (kind) {
-        case 0: mond_rhs_launch_kind<0>(c, rows, d_pot, d_out, l2, inv_g0, alpha, xr); break;
-        case 1: mond_rhs_launch_kind<1>(c, rows, d_pot, d_out, l2, inv_g0, alpha, xr); break;
-        case 2: mond_rhs_launch_kind<2>(c, rows, d_pot, d_out, l2, inv_g0, alpha, xr); break;
-        case 3: mond_rhs_launch_kind<3>(c, rows, d_pot, d_out, l2, inv_g0, alpha, xr); break;
-        case 4: mond_rhs_launch_kind<4>(c, rows, d_pot, d_out, l2, inv_g0, alpha, xr); break;
+        case 0:
+            if (c->mond_fast_nu) mond_rhs_launch_kind<0, true>(c, rows, d_pot, d_out, l2, inv_g0, g0, alpha, xr);
+            else mond_rhs_launch_kind<0, false>(c, rows, d_pot, d_out, l2, inv_g0, g0, alpha, xr);
+            break;
+        case 1: mond_rhs_launch_kind<1, false>(c, rows, d_pot, d_out, l2, inv_g0, g0, alpha, xr); break;
+        case 2: mond_rhs_launch_kind<2, false>(c, rows, d_pot, d_out, l2, inv_g0, g0, alpha, xr); break;
+        case 3: mond_rhs_launch_kind<3, false>(c, rows, d_pot, d_out, l2, inv_g0, g0, alpha, xr); break;
+        case 4: mond_rhs_launch_kind<4, false>(c, rows, d_pot, d_out, l2, inv_g0, g0, alpha, xr); break;
         default:
             pm_set_error("MOND function %d, should be 0..4 (simple, n, beta, gamma, delta)", kind);
             return PM_EINVAL;
     }
     PM_LAUNCH_CHECK();
+    return PM_OK;
+}
+
+// 1 (default): the simple interpolating function through the hardware's rsq / sqrt (mond_nu_sq); 0: the exact chain
+extern "C" int pm_set_mond_fast_nu(pm_ctx *c, int on) {
+    PM_REQUIRE(c, "NULL argument");
+    c->mond_fast_nu = on ? 1 : 0;
     return PM_OK;
 }
 

@@ -681,6 +681,38 @@ def test_mond_rhs_rows_is_the_cell_kernel(amd, kind, alpha):
     np.testing.assert_array_equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("n", [64, 256])
+def test_mond_fast_nu_is_the_exact_chain_to_rounding(amd, n):
+    """pm_mond_rhs for the simple function with the hardware's rsq / sqrt (the default) against the exact chain (IEEE
+    sqrt, divide, sqrt): the 1.5e-7 relative difference of nu, seen through the divergence's cancellation -- a few 1e-6
+    of the largest |nu grad phi| / h term per cell -- on a smooth potential with the dynamic range of a real one."""
+    torch = amd.torch
+    from pysco_amd import _lib as L
+
+    ctx = L.context(4)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n)
+    k = torch.arange(n, device="cuda", dtype=torch.float32) * (2 * np.pi / n)
+    pot = (torch.sin(k)[:, None, None] * torch.cos(2 * k)[None, :, None] + 0.3 * torch.sin(3 * k + 1)[None, None, :]
+           + 0.05 * torch.randn((n, n, n), generator=g, device="cuda")).contiguous() * 1e-2
+    out = {}
+    try:
+        for fast in (1, 0):
+            ctx.call("pm_set_mond_fast_nu", fast)
+            o = torch.empty_like(pot)
+            ctx.call("pm_mond_rhs", L.ptr(pot), L.ptr(o), n, 1e-2, 0, 1.0)
+            out[fast] = o.double()
+    finally:
+        ctx.call("pm_set_mond_fast_nu", 1)
+    assert bool(torch.isfinite(out[0]).all()) and float(out[0].abs().max()) > 0
+    # the terms that cancel in a cell are nu * grad / h ~ n * nu * |grad phi|: bound them by n^2 * max |delta phi| * nu_max
+    dphi = float((pot - torch.roll(pot, 1, 0)).abs().max())
+    scale = float(out[0].abs().max())
+    err = float((out[1] - out[0]).abs().max())
+    assert err <= 2e-6 * max(scale, n * n * dphi), (err, scale)
+    assert float((out[1] - out[0]).abs().mean()) <= 2e-7 * float(out[0].abs().mean())
+
+
 @pytest.mark.parametrize("n", [16, 64])
 def test_native_solve_loops_are_the_python_loops(amd, golden, n):
     """pm_lap_solve / pm_fr_solve (the stopping loops of multigrid.linear / multigrid.FAS issued from C: V-cycle, residual
