@@ -478,7 +478,7 @@ def main():
             dist.init_process_group(backend)
 
     from pysco_amd import _lib as L
-    from pysco_amd import integration, solver, utils
+    from pysco_amd import integration, real64, solver, utils
     from pysco_amd import main as pm_main
 
     n = args.ncells or CONFIGS[args.config][0]
@@ -510,11 +510,11 @@ def main():
     # the product's own loop body (pysco_amd.main.run_nbody): integrate() + the particle-order policy, with its
     # incremental re-sorts and any full re-sort INSIDE the timed region
     rebucket = pm_main.REBUCKET_FRACTION if args.rebucket_fraction is None else args.rebucket_fraction
-    if world == 1 and rebucket >= 0 and not f64:  # (the fp64 mode steps in place: chunks of the sorted stream, re-anchored)
+    if world == 1 and rebucket >= 0:  # (fp64 mode: the key switches on the tile re-sort inside integrate, real64.integrate)
         param["rebucket_straggler_fraction"] = rebucket
     acc, phi, extra = solver.pm(pos, param, tables=tables)
     t_far = np.float32(3.0e38)  # no snapshot inside the run: every step takes its own dt
-    if "rebucket_straggler_fraction" in param:
+    if "rebucket_straggler_fraction" in param and not f64:
         # the product loop's set-up (pysco_amd.main.run_nbody): particle arrays and the gather's output set in the
         # best-placed allocations it can find, no allocation inside the step loop
         if npart >= 2**24 and not args.no_placement:
@@ -532,6 +532,8 @@ def main():
     def step(pos, vel, acc, phi, extra):
         param["nsteps"] += 1
         pos, vel, acc, phi, extra = integration.integrate(pos, vel, acc, phi, extra, tables, param, t_far)
+        if world == 1 and f64:  # (the fp64 mode: a sort to cell resolution once the gather reports an aged stream)
+            pos, vel, acc = pm_main.reorder_policy(pos, vel, acc, param)
         if world == 1 and not f64:
             pos, vel, acc = pm_main.reorder_policy(pos, vel, acc, param)
             if resort_at and param["nsteps"] == resort_at:  # development: does a fresh full sort change the step time?
@@ -550,6 +552,7 @@ def main():
     t0 = time.perf_counter()
     dt_series = []
     straggler_frac, step_events = [], [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    passes_per_chunk = []
     step_events[0].record()
     prof = None
     if os.environ.get("PMSTEP_HOST_PROFILE"):  # development: where does the host spend the timed loop
@@ -562,7 +565,12 @@ def main():
         if world > 1:
             straggler_frac.append(utils.straggler_fraction(n)[0])  # of this rank's stream, as the gather found it
         if world == 1:
-            straggler_frac.append(None if f64 else utils.straggler_fraction(n)[0])
+            if f64:  # (direct-served share, tile passes per chunk) of the gather; None right after a re-sort
+                age = real64.stream_age(n)
+                straggler_frac.append(None if age is None else age[0])
+                passes_per_chunk.append(None if age is None else round(age[1], 2))
+            else:
+                straggler_frac.append(utils.straggler_fraction(n)[0])
             dt_series.append((float(param.get("_dt_last", 0.0)), float(param.get("_dt_pred", 0.0) or 0.0)))
         L.profile_mark()
         step_events[i + 1].record()
@@ -682,8 +690,10 @@ def main():
                                   + f"order-5 gradient, leapfrog KDK, Zel'dovich ICs rms {args.rms_cells} cell, "
                                   "Morton-sorted once, then the product loop's order policy inside the timed steps ("
                                   + (f"incremental tile re-sort above {param['rebucket_straggler_fraction']:g} stragglers"
-                                     if "rebucket_straggler_fraction" in param else
-                                     "fp64 device mode: in-place steps over re-anchored chunks of the sorted stream" if f64 else
+                                     if "rebucket_straggler_fraction" in param and not f64 else
+                                     "fp64 device mode: steps over 2048-particle chunks of the sorted stream (dense tiles through LDS, "
+                                     f"sparse ones through L2), tile re-sort inside the step above {real64.RESORT_PASSES_PER_CHUNK:g} "
+                                     "tile passes per chunk" if f64 else
                                      ("every rank's stream re-bucketed by its gather every step"
                                       + (", halo buffer of the fused kick + deposit on the slab" if slab._SLAB_KHALO else "")
                                       if world > 1 and slab._SLAB_REBUCKET else "in-place steps"))
@@ -709,8 +719,10 @@ def main():
             out["placement_probe_ms"] = probe
     if pm_main.last_placement_probe_ms:  # in-place pass over each candidate particle array [ms], ascending: the first six are in use
         out["placement_probe_ms"] = pm_main.last_placement_probe_ms
-    if straggler_frac and straggler_frac[0] is not None:  # every timed step: stragglers found, dt taken, dt guessed for the next
-        out["straggler_series"] = [round(f, 5) for f in straggler_frac]
+    if straggler_frac and any(f is not None for f in straggler_frac):  # every timed step: stragglers found, dt taken, dt guessed for the next
+        out["straggler_series"] = [None if f is None else round(f, 5) for f in straggler_frac]
+        if passes_per_chunk:
+            out["passes_per_chunk_series"] = passes_per_chunk  # fp64 mode: the gather's tile passes per 2048-particle chunk (None: re-sorted)
         if dt_series:
             out["dt_series"] = [[float(f"{a:.6g}"), float(f"{b:.6g}")] for a, b in dt_series]
     if not args.no_cpu_baseline and rank == 0 and world == 1 and f64:

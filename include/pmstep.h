@@ -496,6 +496,19 @@ int pm_real64_interp_kick(pm_ctx *ctx, int scheme, const double *d_force, const 
                           double *d_vel, double half_dt, double *h_max_acc, double *h_max_vel);
 /* fourier.fourier_grid_to_Pk :22-100 of fft_3D_real(d_rho): per-bin sums of |k|, |delta_k|^2 W^(-2p), mode counts (n each) */
 int pm_real64_pk(pm_ctx *ctx, int p, double *d_rho, const double *h_sinc, double *h_ksum, double *h_pksum, double *h_nmodes);
+/* utils.reorder_particles (utils.py:1019-1116) for float64 arrays: stable sort by Morton key (morton.py:42-137), the
+ * optional velocity / acceleration carried along (in/out pairs), d_perm (optional, int64[np]): new[i] = old[perm[i]].
+ * key_bits in 1..21: only the top key_bits bits per axis decide the order; -1: only the 8 x 16 x 16-cell tile of the
+ * context's mesh does (all the kernels care about; two radix passes at 512^3); 0: all 21 bits, the reference's key. */
+int pm_real64_reorder_particles(pm_ctx *ctx, int64_t np, const double *d_pos, const double *d_vel, const double *d_acc,
+                                double *d_pos_out, double *d_vel_out, double *d_acc_out, int64_t *d_perm, int key_bits);
+/* What the last pm_real64_interp_kick (with a read-back of the maxima) saw of the stream's order: *h_aged particles of
+ * *h_np were served one by one through L2 because fewer than 32 particles of their 2048-particle chunk shared their
+ * tile, and the *h_chunks workgroups made *h_passes tile passes (a sorted stream: the few particles of near-empty tiles,
+ * and at most tiles + chunks passes; a shuffled one: nearly every particle).  A performance measure only -- every kernel
+ * serves every particle whatever the order -- on which the host loop decides to re-sort
+ * (pysco_amd.main.reorder_policy).  *h_np = -1: no gather since the context was created / re-sorted. */
+int pm_real64_stream_age(pm_ctx *ctx, int64_t *h_aged, int64_t *h_np, int64_t *h_passes, int64_t *h_chunks);
 
 #ifdef __cplusplus
 }

@@ -226,6 +226,7 @@ struct pm_ctx {
     // sort workspace (grown on demand)
     void *sort_tmp;
     size_t sort_tmp_bytes;
+    int64_t age64_count, age64_np, age64_passes;  // fp64 mode: what the last gather saw of the stream's age (pm_real64_stream_age)
 };
 
 static inline pm_geom pm_ctx_geom(const pm_ctx *c) {

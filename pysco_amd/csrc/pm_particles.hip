@@ -2568,7 +2568,9 @@ __global__ __launch_bounds__(BLK) void interp_ranges_kernel(const float *__restr
                         float veff[3];
 #pragma unroll
                         for (int mm = 0; mm < 3; ++mm) veff[mm] = w[mm] + kick_next * a[mm];
+#ifndef PM_EXP_NODEST
                         dcode = dest_of(xs, veff, cd.dtp, nf, n, t).d;
+#endif
                         stay = dcode == 13;
                         nstay += stay ? 1u : 0u;
                         if (!stay) {  // (LDS only: a branch the counted waits need not know about)

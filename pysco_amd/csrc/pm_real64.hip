@@ -18,6 +18,8 @@
 // 10 x 18 x 18 force tile of its chunk in LDS (3 x 25.9 KB).  rocFFT double-precision plans do the transforms.
 #include "pm_common.h"
 
+#include <rocprim/rocprim.hpp>
+
 #define BLK 256
 
 namespace {
@@ -25,7 +27,7 @@ namespace {
 constexpr int TI = 8, TJ = 16, TK = 16, LI = 3, LJ = 4, LK = 4;  // tile of 8 x 16 x 16 cells: 2048 Morton codes
 constexpr int HI = TI + 2, HJ = TJ + 2, HK = TK + 2;
 constexpr int TILE = HI * HJ * HK;   // 3240 cells with the one-cell halo TSC / CIC reach
-constexpr int PPT = 8, CHUNK = BLK * PPT, MAX_PASSES = 6;
+constexpr int PPT = 8, CHUNK = BLK * PPT;
 
 __device__ __forceinline__ int cell_of(double xp, int n) {
     const int i = (int)xp;  // np.int16(x_part): truncation (mesh.py:2506)
@@ -146,22 +148,99 @@ __device__ __forceinline__ void deposit_lds(double xp, double yp, double zp, int
     }
 }
 
-// the tile of the first still-unserved particle of the chunk (uniform); false when nothing is left
-__device__ __forceinline__ bool next_anchor(unsigned todo, const double *chunk_pos, double nf, int n, int *s_first,
-                                            int *s_anchor, Tile &t) {
+// A workgroup serves its chunk of the stream tile by tile.  Every thread keeps its particles' tile keys in registers.
+// First the chunk is classified: a small hash table in LDS (in the tile's own storage, before it is used) counts the
+// chunk's particles per tile, and a particle whose tile holds fewer than DENSE_MIN of them is SPARSE: it is served one
+// by one through L2 (global atomics / global loads) in one sweep at the end, every lane busy.  The dense tiles -- at
+// most CHUNK / DENSE_MIN of them -- get a pass each through the LDS tile.  A tile pass moves a tile's worth of data
+// whatever it serves (25.9 KB zeroed and flushed, or 77.8 KB of force staged) and runs the service code for every wave
+// with a member: a chunk in a void (forty tiles with fifty particles each) or of an aged stream must not pay that
+// forty times for one or two busy lanes per wave.  Measured at 512^3, twenty steps into the run (clustered): gather
+// 19.0 -> ms, deposit 8.2 -> ms with a tile pass for every tile of the chunk.
+constexpr int DENSE_MIN = 32, PASS_MAX = 64, HASH_SLOTS = 1024, HASH_PROBES = 8;
+static_assert(PASS_MAX * DENSE_MIN >= 2048 && HASH_SLOTS * 2 * sizeof(int) <= TILE * sizeof(double), "chunk classification");
+
+__device__ __forceinline__ int tile_key_of(int i, int j, int k) { return ((i >> LI) << 20) | ((j >> LJ) << 10) | (k >> LK); }
+__device__ __forceinline__ Tile tile_of_key(int key) { return Tile{key >> 20, (key >> 10) & 1023, key & 1023}; }
+__device__ __forceinline__ unsigned hash_of_key(int key) { return ((unsigned)key * 2654435761u) >> 22; }  // 10 bits
+
+// Classifies the thread's NP particles (key[r] >= 0 where todo has bit r): returns the mask of the SPARSE ones.  `table`
+// is HASH_SLOTS x {key, count} ints of LDS scratch; two barriers inside, one more needed before the storage is reused.
+template <int NT, int NP>
+__device__ __forceinline__ unsigned classify_sparse(unsigned todo, const int (&key)[NP], int *table) {
     const int tid = threadIdx.x;
-    if (tid == 0) *s_first = 0x7fffffff;
+    for (int c = tid; c < HASH_SLOTS; c += NT) table[2 * c] = -1, table[2 * c + 1] = 0;
     __syncthreads();
-    if (todo) atomicMin(s_first, (__ffs((int)todo) - 1) * BLK + tid);
-    __syncthreads();
-    const int first = *s_first;
-    if (first == 0x7fffffff) return false;
-    if (tid == 0) {
-        const double *q = chunk_pos + 3 * first;
-        s_anchor[0] = cell_of(q[0] * nf, n) >> LI, s_anchor[1] = cell_of(q[1] * nf, n) >> LJ, s_anchor[2] = cell_of(q[2] * nf, n) >> LK;
+    // (a wave of the sorted stream holds one or two different keys: the lanes that share the first lane's key count
+    // as one insertion -- 2048 single insertions of the same key were 2048 same-address LDS atomics in a row)
+    int slot[NP];
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+        slot[r] = -1;
+        bool pending = todo >> r & 1u;
+        for (int round = 0; round < 3 && __ballot(pending); ++round) {
+            const unsigned long long act = __ballot(pending);
+            const int lead = __ffsll((long long)act) - 1;
+            const int k0 = __shfl(key[r], lead, 64);
+            const unsigned long long same = __ballot(pending && key[r] == k0);
+            int found = -1;
+            if ((int)(tid & 63) == lead) {
+                unsigned h = hash_of_key(k0);
+                for (int probe = 0; probe < HASH_PROBES; ++probe, h = (h + 1) & (HASH_SLOTS - 1)) {
+                    const int old = atomicCAS(&table[2 * h], -1, k0);
+                    if (old == -1 || old == k0) {
+                        atomicAdd(&table[2 * h + 1], __popcll(same));
+                        found = (int)h;
+                        break;
+                    }
+                }
+            }
+            found = __shfl(found, lead, 64);
+            if (pending && key[r] == k0) slot[r] = found, pending = false;
+        }
+        if (pending) {  // a wave with many different keys (an unsorted stream): one by one
+            unsigned h = hash_of_key(key[r]);
+            for (int probe = 0; probe < HASH_PROBES; ++probe, h = (h + 1) & (HASH_SLOTS - 1)) {
+                const int old = atomicCAS(&table[2 * h], -1, key[r]);
+                if (old == -1 || old == key[r]) {
+                    atomicAdd(&table[2 * h + 1], 1);
+                    slot[r] = (int)h;
+                    break;
+                }
+            }
+        }
     }
     __syncthreads();
-    t.ti = s_anchor[0], t.tj = s_anchor[1], t.tk = s_anchor[2];
+    unsigned sparse = 0;
+#pragma unroll
+    for (int r = 0; r < NP; ++r)
+        if ((todo >> r & 1u) && (slot[r] < 0 || table[2 * slot[r] + 1] < DENSE_MIN)) sparse |= 1u << r;  // (no slot: a crowded table)
+    return sparse;
+}
+
+// One pass's choice among the particles of `todo` (the dense ones): the tile key of the first of the chunk (uniform) and
+// this thread's slots in that tile.  Returns false when nothing is left.  NT threads, NP slots each; three barriers.
+template <int NT, int NP>
+__device__ __forceinline__ bool next_tile(unsigned todo, const int (&key)[NP], int *s_pick, int &akey, unsigned &mine) {
+    const int tid = threadIdx.x;
+    if (tid == 0) s_pick[0] = 0x7fffffff;
+    __syncthreads();
+    if (todo) atomicMin(&s_pick[0], (__ffs((int)todo) - 1) * NT + tid);
+    __syncthreads();
+    const int first = s_pick[0];
+    if (first == 0x7fffffff) return false;
+    if (first % NT == tid) {
+        int kk = 0;
+#pragma unroll
+        for (int r = 0; r < NP; ++r) kk = (first / NT == r) ? key[r] : kk;
+        s_pick[2] = kk;
+    }
+    __syncthreads();
+    akey = s_pick[2];
+    mine = 0;
+#pragma unroll
+    for (int r = 0; r < NP; ++r)
+        if ((todo >> r & 1u) && key[r] == akey) mine |= 1u << r;
     return true;
 }
 
@@ -169,43 +248,61 @@ template <int SCHEME>
 __global__ __launch_bounds__(BLK) void deposit64_kernel(const double *__restrict__ pos, int64_t np, int n, int log2n,
                                                         double *__restrict__ rho) {
     __shared__ double tile[TILE];  // 25.9 KB
-    __shared__ int s_first, s_anchor[3];
+    __shared__ int s_pick[3];
     const int tid = threadIdx.x;
     const double nf = (double)n;
-    for (int c = tid; c < TILE; c += BLK) tile[c] = 0.0;
     const int64_t base = (int64_t)blockIdx.x * CHUNK;
+    // (the tile keys stay in registers over the passes; the positions are read again where a particle is served: the
+    // service loops stay rolled -- eight unrolled copies of 27 atomics were 512 registers and a 35 KB kernel)
+    int key[PPT];
     unsigned todo = 0;
 #pragma unroll
-    for (int r = 0; r < PPT; ++r)
-        if (base + r * BLK + tid < np) todo |= 1u << r;
-    Tile t;
+    for (int r = 0; r < PPT; ++r) {
+        const int64_t p = base + r * BLK + tid;
+        key[r] = -1;
+        if (p < np) {
+            const double xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
+            key[r] = tile_key_of(cell_of(xp, n), cell_of(yp, n), cell_of(zp, n));
+            todo |= 1u << r;
+        }
+    }
     const bool tiled = n >= 16;
-    for (int pass = 0; tiled && pass < MAX_PASSES; ++pass) {
-        if (!next_anchor(todo, pos + 3 * base, nf, n, &s_first, s_anchor, t)) break;
+    unsigned left = todo;  // served through L2 at the end: the sparse ones (everything when n < 16)
+    if (tiled) {
+        left = classify_sparse<BLK, PPT>(todo, key, reinterpret_cast<int *>(tile));  // (the table's storage is the tile's)
+        todo &= ~left;
+        __syncthreads();
+        for (int c = tid; c < TILE; c += BLK) tile[c] = 0.0;
+    }
+    for (int pass = 0; tiled && pass < PASS_MAX; ++pass) {
+        int akey;
+        unsigned mine;
+        if (!next_tile<BLK, PPT>(todo, key, s_pick, akey, mine)) break;  // (its barriers close the zeroing / the last flush)
+        const Tile t = tile_of_key(akey);
 #pragma unroll 1
         for (int r = 0; r < PPT; ++r)
-            if (todo >> r & 1u) {
+            if (mine >> r & 1u) {
                 const double *q = pos + 3 * (base + r * BLK + tid);
                 const double xp = q[0] * nf, yp = q[1] * nf, zp = q[2] * nf;
-                const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
-                if ((i >> LI) == t.ti && (j >> LJ) == t.tj && (k >> LK) == t.tk) {
-                    deposit_lds<SCHEME>(xp, yp, zp, i, j, k, t, tile);
-                    todo &= ~(1u << r);
-                }
+                deposit_lds<SCHEME>(xp, yp, zp, cell_of(xp, n), cell_of(yp, n), cell_of(zp, n), t, tile);
             }
-        __syncthreads();
-        for (int c = tid; c < TILE; c += BLK) {  // flush: one global atomic per touched cell, rows of 18 along k
-            const double v = tile[c];
-            if (v != 0.0) {
-                const int lk = c % HK, lij = c / HK, lj = lij % HJ, li = lij / HJ;
-                atomicAdd(rho + cell_index(n, log2n, t.ti * TI - 1 + li, t.tj * TJ - 1 + lj, t.tk * TK - 1 + lk), v);
-                tile[c] = 0.0;
+        todo &= ~mine;
+        {
+            __syncthreads();
+            for (int c = tid; c < TILE; c += BLK) {  // flush: one global atomic per touched cell, rows of 18 along k
+                const double v = tile[c];
+                if (v != 0.0) {
+                    const int lk = c % HK, lij = c / HK, lj = lij % HJ, li = lij / HJ;
+                    atomicAdd(rho + cell_index(n, log2n, t.ti * TI - 1 + li, t.tj * TJ - 1 + lj, t.tk * TK - 1 + lk), v);
+                    tile[c] = 0.0;
+                }
             }
         }
     }
+    left |= todo;
 #pragma unroll 1
-    for (int r = 0; r < PPT; ++r)  // what the tiles did not take (an unsorted stream): straight to global atomics
-        if (todo >> r & 1u) {
+    for (int r = 0; r < PPT; ++r)  // the sparse ones
+        if (left >> r & 1u) {
             const double *q = pos + 3 * (base + r * BLK + tid);
             const double xp = q[0] * nf, yp = q[1] * nf, zp = q[2] * nf;
             deposit_global<SCHEME>(xp, yp, zp, cell_of(xp, n), cell_of(yp, n), cell_of(zp, n), n, log2n, rho);
@@ -313,99 +410,120 @@ __device__ __forceinline__ void gather27(double xp, double yp, double zp, int i,
     }
 }
 
+// The workgroup is 512 threads with four particles each (the 2048-particle chunk of the deposit): the 78 KB tile allows
+// two workgroups per CU either way, and with 256 threads that was two waves per SIMD to hide every latency of the
+// kernel behind.  Positions (and the velocities the kick updates) are loaded once, up front, and stay in registers
+// over the passes (deposit64_kernel's scheme: dense tiles through LDS, sparse ones through L2).
+constexpr int IB = 512, IPT = CHUNK / IB, FILL_U = 10, AGE_SAMPLE = 16;
+
 template <int SCHEME, bool KICK>
-__global__ __launch_bounds__(BLK) void interp64_kernel(const double *__restrict__ force, const double *__restrict__ pos,
-                                                       int64_t np, int n, int log2n, double *__restrict__ out,
-                                                       double *__restrict__ vel, double mhalf_dt,
-                                                       unsigned long long *__restrict__ maxbits) {
+__global__ __launch_bounds__(IB) void interp64_kernel(const double *__restrict__ force, const double *__restrict__ pos,
+                                                      int64_t np, int n, int log2n, double *__restrict__ out,
+                                                      double *__restrict__ vel, double mhalf_dt,
+                                                      unsigned long long *__restrict__ maxbits) {
     extern __shared__ double tile[];  // [3][TILE]: 77.8 KB (two workgroups per CU)
-    __shared__ int s_first, s_anchor[3];
+    __shared__ int s_pick[3];
     const int tid = threadIdx.x;
     const double nf = (double)n;
     const int64_t base = (int64_t)blockIdx.x * CHUNK;
+    // (the tile keys stay in registers over the passes; position and velocity are read where a particle is served, in
+    // rolled loops: one copy each of the LDS gather and of the L2 gather)
+    int key[IPT];
     unsigned todo = 0;
 #pragma unroll
-    for (int r = 0; r < PPT; ++r)
-        if (base + r * BLK + tid < np) todo |= 1u << r;
-    unsigned long long ma = 0, mv = 0;
-    // A thread's particles (r * BLK + tid of the chunk) come through a two-deep register queue -- position, and the
-    // velocity the kick updates, of particles r + 1 and r + 2 are in flight while r is gathered: loaded where they are
-    // used, each particle waits one memory latency for its position and another for its velocity, with only two
-    // workgroups per CU (the 78 KB tile) to hide them: 12.2 ms at 512^3, most of it those waits.
-    struct Slot {
-        double x[3], v[3];
-    };
-    auto load = [&](int r) {
-        Slot q;
-        const int64_t p = min(base + (int64_t)min(r, PPT - 1) * BLK + tid, np - 1);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            q.x[m] = __builtin_nontemporal_load(pos + 3 * p + m);
-            q.v[m] = KICK ? __builtin_nontemporal_load(vel + 3 * p + m) : 0.0;
+    for (int r = 0; r < IPT; ++r) {
+        const int64_t p = base + r * IB + tid;
+        key[r] = -1;
+        if (p < np) {
+            const double xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
+            key[r] = tile_key_of(cell_of(xp, n), cell_of(yp, n), cell_of(zp, n));
+            todo |= 1u << r;
         }
-        return q;
-    };
-    auto finish = [&](const Slot &q, int64_t p, const double a[3]) {
+    }
+    unsigned long long ma = 0, mv = 0;
+    unsigned direct = 0, npass = 0;  // particles served through L2, tile passes: what pm_real64_stream_age reports
+    // serves particle slot r: dense -> from the LDS tile of t, else through L2
+    auto serve = [&](int r, bool dense, const Tile &t) {
+        const int64_t p = base + r * IB + tid;
+        double v[3] = {0.0, 0.0, 0.0};
+        const double xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
+        if (KICK) v[0] = __builtin_nontemporal_load(vel + 3 * p), v[1] = __builtin_nontemporal_load(vel + 3 * p + 1),
+                  v[2] = __builtin_nontemporal_load(vel + 3 * p + 2);
+        const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
+        double a[3];
+        if (dense) {
+            const int c0 = ((i - t.ti * TI + 1) * HJ + (j - t.tj * TJ + 1)) * HK + (k - t.tk * TK + 1);
+            gather27<SCHEME>(xp, yp, zp, i, j, k, [&](int da, int db, int dc, int m) { return tile[m * TILE + c0 + (da * HJ + db) * HK + dc]; }, a);
+        } else {
+            gather27<SCHEME>(xp, yp, zp, i, j, k,
+                             [&](int da, int db, int dc, int m) { return force[3 * cell_index(n, log2n, i + da, j + db, k + dc) + m]; }, a);
+            ++direct;
+        }
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             __builtin_nontemporal_store(a[m], out + 3 * p + m);
             ma = max(ma, (unsigned long long)__double_as_longlong(a[m]) & 0x7fffffffffffffffull);
             if (KICK) {
-                const double v = q.v[m] + mhalf_dt * a[m];
-                __builtin_nontemporal_store(v, vel + 3 * p + m);
-                mv = max(mv, (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull);
+                const double w = v[m] + mhalf_dt * a[m];
+                __builtin_nontemporal_store(w, vel + 3 * p + m);
+                mv = max(mv, (unsigned long long)__double_as_longlong(w) & 0x7fffffffffffffffull);
             }
         }
     };
-    Tile t;
-    const bool tiled = n >= 16;  // (measured at 512^3: 13.0 ms tiled, 12.1 ms with every cell read through L2: no contest either way)
-    for (int pass = 0; tiled && pass < MAX_PASSES; ++pass) {
-        if (!next_anchor(todo, pos + 3 * base, nf, n, &s_first, s_anchor, t)) break;  // (its barriers also close the last pass's reads)
-        Slot q0 = load(0), q1 = load(1);
-        for (int f = tid; f < 3 * TILE; f += BLK) {  // consecutive lanes, consecutive doubles of a row of 18 x 3
-            const int c = f / 3, m = f - 3 * c;
-            const int lk = c % HK, lij = c / HK, lj = lij % HJ, li = lij / HJ;
-            tile[m * TILE + c] = force[3 * cell_index(n, log2n, t.ti * TI - 1 + li, t.tj * TJ - 1 + lj, t.tk * TK - 1 + lk) + m];
-        }
-        __syncthreads();
+    const bool tiled = n >= 16;
+    unsigned left = todo;  // served through L2 at the end: the sparse ones (everything when n < 16)
+    if (tiled) {
+        left = classify_sparse<IB, IPT>(todo, key, reinterpret_cast<int *>(tile));
+        todo &= ~left;
+    }
+    for (int pass = 0; tiled && pass < PASS_MAX; ++pass) {
+        int akey;
+        unsigned mine;
+        if (!next_tile<IB, IPT>(todo, key, s_pick, akey, mine)) break;  // (its barriers close the table's / the last pass's reads)
+        const Tile t = tile_of_key(akey);
+        ++npass;
+        const bool dense = true;
+        {
+            // the force tile: consecutive lanes, consecutive doubles of a row of 18 x 3; FILL_U loads in flight per thread
+            // before the first is stored (one load per trip was 38 memory latencies in a row per pass: most of the kernel)
 #pragma unroll 1
-        for (int r = 0; r < PPT; ++r) {
-            const Slot q = q0;
-            q0 = q1, q1 = load(r + 2);
-            if (todo >> r & 1u) {
-                const int64_t p = base + r * BLK + tid;
-                const double xp = q.x[0] * nf, yp = q.x[1] * nf, zp = q.x[2] * nf;
-                const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
-                if ((i >> LI) == t.ti && (j >> LJ) == t.tj && (k >> LK) == t.tk) {
-                    const int c0 = ((i - t.ti * TI + 1) * HJ + (j - t.tj * TJ + 1)) * HK + (k - t.tk * TK + 1);
-                    double a[3];
-                    gather27<SCHEME>(xp, yp, zp, i, j, k,
-                                     [&](int da, int db, int dc, int m) { return tile[m * TILE + c0 + (da * HJ + db) * HK + dc]; }, a);
-                    finish(q, p, a);
-                    todo &= ~(1u << r);
+            for (int f0 = tid; f0 < 3 * TILE; f0 += IB * FILL_U) {
+                double fv[FILL_U];
+#pragma unroll
+                for (int u = 0; u < FILL_U; ++u) {
+                    const int f = min(f0 + u * IB, 3 * TILE - 1);
+                    const int c = f / 3, m = f - 3 * c;
+                    const int lk = c % HK, lij = c / HK, lj = lij % HJ, li = lij / HJ;
+                    fv[u] = force[3 * cell_index(n, log2n, t.ti * TI - 1 + li, t.tj * TJ - 1 + lj, t.tk * TK - 1 + lk) + m];
+                }
+#pragma unroll
+                for (int u = 0; u < FILL_U; ++u) {
+                    const int f = f0 + u * IB;
+                    if (f < 3 * TILE) tile[(f % 3) * TILE + f / 3] = fv[u];
                 }
             }
+            __syncthreads();
         }
-    }
 #pragma unroll 1
-    for (int r = 0; r < PPT; ++r)  // what the tiles did not take: through L2
-        if (todo >> r & 1u) {
-            const int64_t p = base + r * BLK + tid;
-            const Slot q = load(r);
-            const double xp = q.x[0] * nf, yp = q.x[1] * nf, zp = q.x[2] * nf;
-            const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
-            double a[3];
-            gather27<SCHEME>(xp, yp, zp, i, j, k,
-                             [&](int da, int db, int dc, int m) { return force[3 * cell_index(n, log2n, i + da, j + db, k + dc) + m]; }, a);
-            finish(q, p, a);
-        }
+        for (int r = 0; r < IPT; ++r)
+            if (mine >> r & 1u) serve(r, dense, t);
+        todo &= ~mine;
+    }
+    left |= todo;
+#pragma unroll 1
+    for (int r = 0; r < IPT; ++r)  // the sparse ones
+        if (left >> r & 1u) serve(r, false, Tile{0, 0, 0});
     for (int off = 32; off > 0; off >>= 1) {
         ma = max(ma, (unsigned long long)__shfl_down((long long)ma, off, 64));
         mv = max(mv, (unsigned long long)__shfl_down((long long)mv, off, 64));
+        direct += (unsigned)__shfl_down((int)direct, off, 64);
     }
     if ((tid & 63) == 0) {
         if (ma > __atomic_load_n(maxbits, __ATOMIC_RELAXED)) atomicMax(maxbits, ma);
         if (KICK && mv > __atomic_load_n(maxbits + 1, __ATOMIC_RELAXED)) atomicMax(maxbits + 1, mv);
+        // (one workgroup in AGE_SAMPLE reports: every one of them on one address was 5 ms of the kernel at 512^3)
+        if (direct && tiled && blockIdx.x % AGE_SAMPLE == 0) atomicAdd(maxbits + 2, (unsigned long long)direct * AGE_SAMPLE);
+        if (tid == 0 && npass && blockIdx.x % AGE_SAMPLE == 0) atomicAdd(maxbits + 3, (unsigned long long)npass * AGE_SAMPLE);
     }
 }
 
@@ -580,12 +698,12 @@ static int interp64_launch(pm_ctx *c, const double *force, const double *pos, in
     if (vel) {
         PM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&interp64_kernel<SCHEME, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((interp64_kernel<SCHEME, true>), grid, dim3(BLK), lds, c->stream, force, pos, np, c->n, c->log2n, out,
+        hipLaunchKernelGGL((interp64_kernel<SCHEME, true>), grid, dim3(IB), lds, c->stream, force, pos, np, c->n, c->log2n, out,
                            vel, -half_dt, bits);
     } else {
         PM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&interp64_kernel<SCHEME, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((interp64_kernel<SCHEME, false>), grid, dim3(BLK), lds, c->stream, force, pos, np, c->n, c->log2n, out,
+        hipLaunchKernelGGL((interp64_kernel<SCHEME, false>), grid, dim3(IB), lds, c->stream, force, pos, np, c->n, c->log2n, out,
                            vel, 0.0, bits);
     }
     PM_LAUNCH_CHECK();
@@ -599,7 +717,7 @@ extern "C" int pm_real64_interp_kick(pm_ctx *c, int scheme, const double *d_forc
     PM_REQUIRE_F64(c);
     PM_REQUIRE(d_force && d_pos && d_acc && np > 0, "bad argument");
     unsigned long long *d_bits = reinterpret_cast<unsigned long long *>(c->d_scratch + 48);
-    PM_HIP(hipMemsetAsync(d_bits, 0, 2 * sizeof(unsigned long long), c->stream));
+    PM_HIP(hipMemsetAsync(d_bits, 0, 4 * sizeof(unsigned long long), c->stream));
     int rc;
     switch (scheme) {
         case PM_NGP: rc = interp64_launch<PM_NGP>(c, d_force, d_pos, np, d_acc, d_vel, half_dt, d_bits); break;
@@ -608,13 +726,111 @@ extern "C" int pm_real64_interp_kick(pm_ctx *c, int scheme, const double *d_forc
         default: pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme); return PM_EINVAL;
     }
     if (rc) return rc;
-    double m[2] = {0.0, 0.0};
+    double m[4] = {0.0, 0.0, 0.0, 0.0};
+    c->age64_np = -1;
     if (h_max_acc || h_max_vel) {
         rc = pm_read_back(c, m, d_bits, sizeof(m));
         if (rc) return rc;
+        unsigned long long aged, passes;
+        memcpy(&aged, &m[2], sizeof(aged));
+        memcpy(&passes, &m[3], sizeof(passes));
+        c->age64_count = (int64_t)aged, c->age64_passes = (int64_t)passes, c->age64_np = np;
     }
     if (h_max_acc) *h_max_acc = m[0];
     if (h_max_vel) *h_max_vel = m[1];
+    return PM_OK;
+}
+
+// The age of the particle stream as the last pm_real64_interp_kick (with read-back) found it: how many particles it
+// served one by one through L2 -- members of a tile with fewer than DENSE_MIN of the chunk's particles -- of how many,
+// and how many tile passes its *h_chunks workgroups made.  A Morton-sorted stream gives the few particles of near-empty
+// tiles and at most (tiles + chunks) passes (two per chunk at one particle per cell); a shuffled one nearly every
+// particle; the in-place steps let both grow (the kernels serve every particle whatever the order: this is a performance matter only), and the host
+// re-sorts past a threshold (pysco_amd.main.reorder_policy), as it does in the fp32 mode on the straggler fraction.
+// *h_np = -1 before any gather.
+extern "C" int pm_real64_stream_age(pm_ctx *c, int64_t *h_aged, int64_t *h_np, int64_t *h_passes, int64_t *h_chunks) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(h_aged && h_np && h_passes && h_chunks, "NULL argument");
+    *h_aged = c->age64_count, *h_np = c->age64_np, *h_passes = c->age64_passes;
+    *h_chunks = c->age64_np > 0 ? (c->age64_np + CHUNK - 1) / CHUNK : 0;
+    return PM_OK;
+}
+
+// utils.reorder_particles (utils.py:1019-1116) for float64 arrays: stable sort by Morton key (morton.py:42-137, 21 bits
+// per axis), velocity / acceleration (optional, in pairs) carried along, d_perm (optional): new[i] = old[perm[i]].
+// key_bits (1..21): only the top key_bits bits per axis decide the order; -1: only the tile of the context's mesh does
+// (all the kernels care about: 16 bits at 512^3, two radix passes); 0 = all 21 bits per axis, the reference's key.
+namespace {
+__device__ __forceinline__ unsigned long long interleave21(unsigned long long x) {
+    x &= 0x1FFFFFull;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+__global__ __launch_bounds__(BLK) void morton_keys64_kernel(const double *__restrict__ pos, int64_t np,
+                                                            unsigned long long *__restrict__ keys, unsigned *__restrict__ iota) {
+    for (int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x; p < np; p += (int64_t)gridDim.x * BLK) {
+        const unsigned long long xx = interleave21((unsigned long long)(long long)floor(pos[3 * p] * 2097152.0));
+        const unsigned long long yy = interleave21((unsigned long long)(long long)floor(pos[3 * p + 1] * 2097152.0));
+        const unsigned long long zz = interleave21((unsigned long long)(long long)floor(pos[3 * p + 2] * 2097152.0));
+        keys[p] = xx << 2 | yy << 1 | zz;
+        iota[p] = (unsigned)p;
+    }
+}
+__global__ __launch_bounds__(BLK) void gather3_64_kernel(const unsigned *__restrict__ perm, int64_t np,
+                                                         const double *__restrict__ a, const double *__restrict__ b,
+                                                         const double *__restrict__ cc, double *__restrict__ ao,
+                                                         double *__restrict__ bo, double *__restrict__ co,
+                                                         int64_t *__restrict__ perm_out) {
+    for (int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x; p < np; p += (int64_t)gridDim.x * BLK) {
+        const int64_t s = perm[p];
+        ao[3 * p] = a[3 * s], ao[3 * p + 1] = a[3 * s + 1], ao[3 * p + 2] = a[3 * s + 2];
+        if (b) bo[3 * p] = b[3 * s], bo[3 * p + 1] = b[3 * s + 1], bo[3 * p + 2] = b[3 * s + 2];
+        if (cc) co[3 * p] = cc[3 * s], co[3 * p + 1] = cc[3 * s + 1], co[3 * p + 2] = cc[3 * s + 2];
+        if (perm_out) perm_out[p] = s;
+    }
+}
+}  // namespace
+
+extern "C" int pm_real64_reorder_particles(pm_ctx *c, int64_t np, const double *d_pos, const double *d_vel,
+                                           const double *d_acc, double *d_pos_out, double *d_vel_out, double *d_acc_out,
+                                           int64_t *d_perm, int key_bits) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(np >= 0 && key_bits >= -1 && key_bits <= 21, "bad argument");
+    if (np == 0) return PM_OK;
+    PM_REQUIRE(d_pos && d_pos_out && d_pos != d_pos_out, "pos / pos_out must be distinct non-NULL buffers");
+    PM_REQUIRE((!d_vel) == (!d_vel_out) && (!d_acc) == (!d_acc_out), "in/out arrays must come in pairs");
+    PM_REQUIRE(np < 2147483647LL, "rocPRIM radix sort is limited to 2^31-1 keys per call");
+    // (-1: to the tiles of this context's mesh -- a tile is 2^11 consecutive cell codes, LI + LJ + LK bits)
+    const int tile_bits = 3 * c->log2n - (LI + LJ + LK);
+    const unsigned begin_bit = key_bits > 0 ? 3u * (unsigned)(21 - key_bits) : key_bits < 0 ? (unsigned)(63 - (tile_bits > 1 ? tile_bits : 1)) : 0u;
+    size_t tmp_bytes = 0;
+    unsigned long long *nullk = nullptr;
+    unsigned *nullv = nullptr;
+    PM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, nullk, nullk, nullv, nullv, (size_t)np, begin_bit, 63, c->stream));
+    const size_t karr = ((size_t)np * sizeof(unsigned long long) + 255) & ~(size_t)255;
+    const size_t varr = ((size_t)np * sizeof(unsigned) + 255) & ~(size_t)255;
+    const size_t need = 2 * karr + 2 * varr + tmp_bytes;
+    if (c->sort_tmp_bytes < need) {
+        if (c->sort_tmp) PM_HIP(hipFree(c->sort_tmp));
+        c->sort_tmp = nullptr, c->sort_tmp_bytes = 0;
+        PM_HIP(hipMalloc(&c->sort_tmp, need));
+        c->sort_tmp_bytes = need;
+    }
+    char *w = (char *)c->sort_tmp;
+    unsigned long long *keys_in = (unsigned long long *)w, *keys_out = (unsigned long long *)(w + karr);
+    unsigned *iota = (unsigned *)(w + 2 * karr), *perm = (unsigned *)(w + 2 * karr + varr);
+    void *rp_tmp = w + 2 * karr + 2 * varr;
+    hipLaunchKernelGGL(morton_keys64_kernel, dim3(blocks_for(np, BLK)), dim3(BLK), 0, c->stream, d_pos, np, keys_in, iota);
+    PM_LAUNCH_CHECK();
+    PM_HIP(rocprim::radix_sort_pairs(rp_tmp, tmp_bytes, keys_in, keys_out, iota, perm, (size_t)np, begin_bit, 63, c->stream));
+    hipLaunchKernelGGL(gather3_64_kernel, dim3(blocks_for(np, BLK)), dim3(BLK), 0, c->stream, perm, np, d_pos, d_vel, d_acc,
+                       d_pos_out, d_vel_out, d_acc_out, d_perm);
+    PM_LAUNCH_CHECK();
+    c->age64_np = -1;  // (what the last gather found no longer describes this stream)
     return PM_OK;
 }
 

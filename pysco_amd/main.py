@@ -15,7 +15,7 @@ from typing import Callable, List, Optional, Sequence
 import numpy as np
 
 from . import _lib as L
-from . import integration, solver, utils
+from . import integration, real64, solver, utils
 
 __version__ = "1.0.9"  # of the reference release whose main.run this mirrors
 
@@ -24,6 +24,8 @@ REBUCKET_FRACTION = 0.0    # default of param["rebucket_straggler_fraction"] in 
                            # that found a straggler re-buckets (measured at 1024^3: 47.7 ms per step sustained against
                            # 48.5 / 49.7 with 0.02 / 0.04, where in-place and re-bucketing steps alternate)
 REORDER_FRACTION = 0.10    # default of param["reorder_straggler_fraction"]
+REORDER_AGE_FRACTION = 0.25  # default of param["reorder_age_fraction"] (fp64 device mode: pm_real64_stream_age)
+REORDER_PASSES_PER_CHUNK = 3.5  # default of param["reorder_passes_per_chunk"] (idem: a sorted stream makes ~2)
 last_placement_probe_ms = None  # tune_placement's timings of its candidate arrays, ascending (diagnostics)
 
 
@@ -153,6 +155,16 @@ def reorder_policy(position, velocity, acceleration, param):
     fixed cadence.  NumPy arrays or no incremental re-sort: the reference's cadence, plus the aged test."""
     device = L.is_device_array(position)
     frac, complete = (None, True)
+    if device and real64.is_float64(position):
+        # the fp64 mode steps in place over chunks of the sorted stream; its gather reports the share of particles it
+        # served one by one because too few of their chunk shared their tile, and past param["reorder_age_fraction"]
+        # a sort to cell resolution pays
+        age = real64.stream_age(2 ** int(param["ncoarse"]))
+        if age is not None and (age[0] > float(param.get("reorder_age_fraction", REORDER_AGE_FRACTION))
+                                or age[1] > float(param.get("reorder_passes_per_chunk", REORDER_PASSES_PER_CHUNK))):
+            logging.info(f"Reordering particles (fp64 stream, {age=})")
+            return _reorder(position, velocity, acceleration, param, key_bits=-1)
+        return position, velocity, acceleration
     if device:
         frac, complete = utils.straggler_fraction(2 ** int(param["ncoarse"]))
     aged = (not complete) or (frac is not None and frac > float(param.get("reorder_straggler_fraction", REORDER_FRACTION)))
@@ -164,11 +176,16 @@ def reorder_policy(position, velocity, acceleration, param):
     return position, velocity, acceleration
 
 
-def _reorder(position, velocity, acceleration, param):
-    """utils.reorder_particles, with the optional tags of param["particle_id"] following the permutation."""
+def _reorder(position, velocity, acceleration, param, key_bits=0):
+    """utils.reorder_particles, with the optional tags of param["particle_id"] following the permutation.
+    key_bits (fp64 arrays): sort to that many bits per axis only (real64.reorder_particles)."""
     ids = param.get("particle_id") if L.is_device_array(position) else None
     order = [] if ids is not None else None
-    position, velocity, acceleration = utils.reorder_particles(position, velocity, acceleration, _order_out=order)
+    if key_bits and real64.is_float64(position):
+        position, velocity, acceleration = real64.reorder_particles(position, velocity, acceleration, _order_out=order,
+                                                                    _key_bits=key_bits, _ncells=2 ** int(param["ncoarse"]))
+    else:
+        position, velocity, acceleration = utils.reorder_particles(position, velocity, acceleration, _order_out=order)
     if ids is not None:
         param["particle_id"] = ids[order[0]]
     return position, velocity, acceleration
@@ -184,14 +201,16 @@ def run_nbody(position, velocity, param, tables: List, z_out: Sequence[float],
         param["nsteps"] = 0
     if L.is_device_array(position):
         param.setdefault("rebucket_straggler_fraction", REBUCKET_FRACTION)
-        if param["rebucket_straggler_fraction"] is not None:
+        if param["rebucket_straggler_fraction"] is not None and not real64.is_float64(position):
             reserve_step_buffers(position)
     acceleration, potential, additional_field = solver.pm(position, param, tables=tables)
-    if L.is_device_array(position):  # an unsorted input stream (initial conditions in lattice order) is sorted once
+    if L.is_device_array(position) and real64.is_float64(position):  # (idem, on the fp64 gather's own measure)
+        position, velocity, acceleration = reorder_policy(position, velocity, acceleration, param)
+    elif L.is_device_array(position):  # an unsorted input stream (initial conditions in lattice order) is sorted once
         frac, complete = utils.straggler_fraction(2 ** int(param["ncoarse"]))
         if not complete or (frac is not None and frac > float(param.get("reorder_straggler_fraction", REORDER_FRACTION))):
             position, velocity, acceleration = _reorder(position, velocity, acceleration, param)
-        if param.get("rebucket_straggler_fraction") is not None and position.shape[0] >= 2**24:
+        if param.get("rebucket_straggler_fraction") is not None and position.shape[0] >= 2**24 and not real64.is_float64(position):
             # (worth its 0.1 s only for large runs: see tune_placement)
             position, velocity, acceleration = tune_placement(position, velocity, acceleration)
     aexp_out = 1.0 / (np.array(z_out, dtype=np.float64) + 1)

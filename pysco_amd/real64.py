@@ -22,6 +22,9 @@ from . import _lib as L
 from . import iostream, utils
 
 
+RESORT_PASSES_PER_CHUNK = 2.6  # default of param["resort_passes_per_chunk"]: a sorted stream makes ~2 (integrate)
+
+
 def is_float64(x) -> bool:
     if L.is_device_array(x):
         return str(x.dtype) == "torch.float64"
@@ -158,6 +161,27 @@ def integrate(position, velocity, acceleration, potential, additional_field, tab
     n = 2 ** int(param["ncoarse"])
     L.context(n, 8).call("pm_real64_kick_drift_wrap", L.ptr(pos_d), L.ptr(vel_d), L.ptr(acc_d), float(half_dt), float(dt),
                          pos_d.shape[0])
+    if not host and param.get("rebucket_straggler_fraction") is not None:
+        # The product loop's order policy (main.run_nbody sets the key: the caller takes new arrays back).  The last
+        # gather made more tile passes per chunk than a sorted stream needs: sort the drifted particles to tile
+        # resolution HERE, before the deposit and the gather of this step read them (both then see a perfectly sorted
+        # stream; after the step the order would already be one drift old when it is first used), and move only
+        # position and velocity (the old acceleration is dead after the kick).
+        # (the measure that counts is the one taken on a stream one drift old: a step that sorted says ~2 whatever the
+        # next drift will do; every ninth step in a row goes unsorted to take it again)
+        age = stream_age(n)
+        if age is not None and not param.get("_f64_sorted_last", False):
+            param["_f64_aged_passes"] = age[1]
+        aged, streak = param.get("_f64_aged_passes"), int(param.get("_f64_sort_streak", 0))
+        resort = aged is not None and aged > float(param.get("resort_passes_per_chunk", RESORT_PASSES_PER_CHUNK)) and streak < 8
+        param["_f64_sorted_last"], param["_f64_sort_streak"] = resort, (streak + 1 if resort else 0)
+        if resort:
+            ids = param.get("particle_id")
+            order = [] if ids is not None and L.is_device_array(ids) else None
+            pos_d, vel_d = reorder_particles(pos_d, vel_d, _order_out=order, _key_bits=-1, _ncells=n, _pool=True)
+            if order:
+                param["particle_id"] = ids[order[0]]
+            param["_resorted_f64"] = int(param.get("_resorted_f64", 0)) + 1
     param["t"] += dt
     param["aexp_old"] = param["aexp"]
     param["aexp"] = float(np.exp(utils.table_eval(tables[0], param["t"])))
@@ -167,3 +191,54 @@ def integrate(position, velocity, acceleration, potential, additional_field, tab
         param.pop("_max_f64", None)
         return pos_d.cpu().numpy(), vel_d.cpu().numpy(), acc_d.cpu().numpy(), potential.cpu().numpy(), additional_field.cpu().numpy()
     return pos_d, vel_d, acc_d, potential, additional_field
+
+
+def reorder_particles(position, velocity=None, acceleration=None, _order_out=None, _key_bits=0, _ncells=4, _pool=False):
+    """utils.reorder_particles (utils.py:1019-1116) for float64 arrays: stable Morton sort, in double all the way
+    (utils.reorder_particles dispatches here; nothing is rounded to float32).  `_key_bits` (private): order to that many
+    bits per axis only; -1: to the mesh's tiles (all the kernels care about: a quarter of the sort's passes).  The mesh
+    is the context's: `_ncells`."""
+    host = not L.is_device_array(position)
+    pos = _dev(position)
+    vel = _dev(velocity) if velocity is not None else None
+    acc = _dev(acceleration) if acceleration is not None else None
+    torch = L.require_gpu()
+    from . import mesh
+
+    # (_pool, private: outputs from / inputs back to the step loop's pool of spare particle arrays -- no device
+    # allocation inside the loop; the caller no longer reads the input arrays)
+    new = mesh._pool_take if _pool else torch.empty_like
+    po = new(pos)
+    vo = new(vel) if vel is not None else None
+    ao = new(acc) if acc is not None else None
+    order = None
+    if _order_out is not None:
+        order = torch.empty((pos.shape[0],), dtype=torch.int64, device=pos.device)
+        _order_out.append(order)
+    L.context(_ncells, 8).call("pm_real64_reorder_particles", pos.shape[0], L.ptr(pos), L.ptr(vel), L.ptr(acc), L.ptr(po), L.ptr(vo),
+                         L.ptr(ao), L.ptr(order), int(_key_bits))
+
+    if _pool and not host:
+        mesh.pool_give(pos, vel, acc)
+
+    def back(t, like):
+        return t.cpu().numpy() if host else L.like_input(t, like)
+
+    if acceleration is not None:
+        return back(po, position), back(vo, velocity), back(ao, acceleration)
+    if velocity is not None:
+        return back(po, position), back(vo, velocity)
+    return back(po, position)
+
+
+def stream_age(ncells_1d: int):
+    """(direct, passes) as the last gather found the stream (pm_real64_stream_age): the share of particles it served one
+    by one through L2 (too few of their chunk in their tile) and its tile passes per 2048-particle chunk.  A sorted
+    stream: the few particles of near-empty tiles, about two passes per chunk; both grow as the in-place steps let the
+    order age; a shuffled stream: ~1 and 0.  None before any gather.  The fp64 mode's counterpart of
+    utils.straggler_fraction, for main.reorder_policy."""
+    aged, npart, passes, chunks = C.c_int64(0), C.c_int64(-1), C.c_int64(0), C.c_int64(0)
+    L.context(ncells_1d, 8).call("pm_real64_stream_age", C.byref(aged), C.byref(npart), C.byref(passes), C.byref(chunks))
+    if npart.value <= 0:
+        return None
+    return aged.value / npart.value, passes.value / max(chunks.value, 1)

@@ -171,6 +171,10 @@ def reorder_particles(position, velocity=None, acceleration=None, _order_out=Non
     """Sort particles by Morton key (utils.py:1019).  Unlike the reference's per-thread partial
     argsort (utils.py:1080-1116) this is always a full, stable sort.  `_order_out` (private): a list that
     receives the permutation (int64 device tensor: new[i] = old[order[i]])."""
+    from . import real64
+
+    if real64.is_float64(position):  # the fp64 device mode: sorted in double, nothing rounded to float32
+        return real64.reorder_particles(position, velocity, acceleration, _order_out=_order_out)
     torch = L.require_gpu()
     pos = L.to_device(position, torch.float32)
     vel = L.to_device(velocity, torch.float32) if velocity is not None else None

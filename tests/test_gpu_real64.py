@@ -161,3 +161,85 @@ def test_real64_steps_vs_fp64_cpu(n, npart_1d, scheme, solver, order, resident, 
     norm = (par_g["boxlen"] / n**2) ** 3
     assert np.abs(pk - pk_c * norm).max() <= 1e-10 * np.abs(pk_c * norm).max()
     assert (np.abs(pk / (pk_c * norm) - 1) <= 1e-10).all()       # ... and per bin
+
+
+def _morton21(pos):
+    """morton.py:42-137 on float64 positions: 21 bits per axis, x the most significant of each triple."""
+    q = np.floor(pos * 2097152.0).astype(np.int64)
+    key = np.zeros(len(pos), dtype=np.int64)
+    for b in range(21):
+        for a in range(3):
+            key |= ((q[:, a] >> b) & 1) << (3 * b + (2 - a))
+    return key
+
+
+def test_real64_reorder_is_a_stable_morton_sort_in_double():
+    """utils.reorder_particles on float64 device arrays: sorted in double (nothing rounded to float32: two particles
+    that differ only below float32 resolution keep their values and fall on the right side of each other), stable,
+    velocity / acceleration carried along; with _key_bits only the top bits decide and ties keep the input order; and
+    the stream age the gather reports goes to None after the sort (main.reorder_policy's measure)."""
+    import torch
+
+    from pysco_amd import real64, utils
+
+    rng = np.random.default_rng(11)
+    npart = 50_000
+    pos = rng.random((npart, 3))
+    pos[1] = pos[0] + np.array([2.0**-40, 0.0, 0.0])  # same float32, different float64 (and, at 21 bits, the same key)
+    pos[7] = pos[3]
+    vel, acc = rng.standard_normal((npart, 3)), rng.standard_normal((npart, 3))
+    order = []
+    p, v, a = utils.reorder_particles(torch.from_numpy(pos).cuda(), torch.from_numpy(vel).cuda(), torch.from_numpy(acc).cuda(),
+                                      _order_out=order)
+    assert p.dtype == torch.float64
+    want = np.argsort(_morton21(pos), kind="stable")
+    np.testing.assert_array_equal(order[0].cpu().numpy(), want)
+    np.testing.assert_array_equal(p.cpu().numpy(), pos[want])
+    np.testing.assert_array_equal(v.cpu().numpy(), vel[want])
+    np.testing.assert_array_equal(a.cpu().numpy(), acc[want])
+    for bits in (4, 9):
+        order = []
+        p2 = real64.reorder_particles(torch.from_numpy(pos).cuda(), _order_out=order, _key_bits=bits)
+        want = np.argsort(_morton21(pos) >> (3 * (21 - bits)), kind="stable")
+        np.testing.assert_array_equal(order[0].cpu().numpy(), want)
+        np.testing.assert_array_equal(p2.cpu().numpy(), pos[want])
+    # NumPy in, NumPy out
+    ph, vh = utils.reorder_particles(pos, vel)
+    assert isinstance(ph, np.ndarray) and ph.dtype == np.float64
+    np.testing.assert_array_equal(ph, pos[np.argsort(_morton21(pos), kind="stable")])
+
+
+def test_real64_stream_age_and_policy():
+    """The gather's age measure (particles served one by one: too few of their chunk in their tile) is small on a sorted
+    stream (with about two tile passes per chunk), large on a shuffled one, and main.reorder_policy re-sorts the
+    shuffled one to tile resolution: same particles, sorted order, age reset."""
+    import torch
+
+    from pysco_amd import main as pm_main
+    from pysco_amd import real64, solver
+
+    n = 64
+    pos, vel = _particles(64, seed=5, rms=0.7)
+    param, tables = _param(n, len(pos))
+    ps, vs = real64.reorder_particles(torch.from_numpy(pos).cuda(), torch.from_numpy(vel).cuda())
+    acc, _, _ = solver.pm(ps, dict(param), tables=tables)
+    # (pm without the fused kick does not read the maxima back: step once for the measure)
+    from pysco_amd import integration
+
+    p1 = dict(param)
+    out = integration.integrate(ps.clone(), vs.clone(), acc.clone(), None, None, tables, p1, 1e30)
+    age_sorted = real64.stream_age(n)
+    assert age_sorted is not None and age_sorted[0] < 0.1 and age_sorted[1] <= 3.0, age_sorted
+    same = pm_main.reorder_policy(out[0], out[1], out[2], dict(p1))  # the sorted stream is left alone
+    assert same[0].data_ptr() == out[0].data_ptr()
+    perm = torch.from_numpy(np.random.default_rng(2).permutation(len(pos))).cuda()
+    pu, vu, au = ps[perm].contiguous(), vs[perm].contiguous(), acc[perm].contiguous()
+    p2 = dict(param)
+    pu, vu, au, _, _ = integration.integrate(pu, vu, au, None, None, tables, p2, 1e30)
+    age_shuffled = real64.stream_age(n)
+    assert age_shuffled[0] > 0.5, age_shuffled
+    pr, vr, ar = pm_main.reorder_policy(pu, vu, au, p2)
+    assert real64.stream_age(n) is None and pr.data_ptr() != pu.data_ptr()
+    key = _morton21(pr.cpu().numpy()) >> (63 - (3 * 6 - 11))  # (the policy sorts to the 8 x 16 x 16-cell tiles)
+    assert (np.diff(key) >= 0).all()
+    np.testing.assert_array_equal(np.sort(pr.cpu().numpy(), axis=0), np.sort(pu.cpu().numpy(), axis=0))
