@@ -353,6 +353,10 @@ int pm_set_fr_rows_sweep(pm_ctx *ctx, int on);
  * 1/2 + sqrt(1/4 + g0 / |grad|) with the hardware's 1-ulp reciprocal square root and square root (1.5e-7 relative, the
  * size of the exact chain's own roundings); off: IEEE sqrt, divide, sqrt as the reference writes it (comparison). */
 int pm_set_mond_fast_nu(pm_ctx *ctx, int on);
+/* on (default): pm_fr_vcycle takes the restricted operator / residual, solution and density term of a level of 512^3 and
+ * more in ONE marching pass (the operator's values never reach memory; same expression, same order of the eight-cell
+ * sums: the same bits); off: operator kernel + three pm_restriction launches (comparison). */
+int pm_set_fr_fused_restrict(pm_ctx *ctx, int on);
 int pm_set_vcycle_graphs(pm_ctx *ctx, int mode);
 int pm_vcycle_graph_stats(pm_ctx *ctx, unsigned *replayed, unsigned *captured);
 /* laplacian.gauss_seidel :844: one red + one black sweep with over-relaxation f_relax, in place */

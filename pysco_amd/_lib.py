@@ -108,6 +108,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_set_fused_coarse": (_vp, _i),
     "pm_set_fr_rows_sweep": (_vp, _i),
     "pm_set_mond_fast_nu": (_vp, _i),
+    "pm_set_fr_fused_restrict": (_vp, _i),
     "pm_vcycle_graph_stats": (_vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)),
     "pm_lap_smoothing": (_vp, _vp, _vp, _i, _i),
     "pm_fr_vcycle": (_vp, _i, _vp, _vp, _f, _i, _i, _i),

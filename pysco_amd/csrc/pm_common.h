@@ -205,6 +205,7 @@ struct pm_ctx {
     int rb_cur;
     int mg_fused_sweep;  // 1 (default): single-pass red + black sweep for n >= 256 (pm_set_fused_sweep; tests compare)
     int fr_rows_sweep;    // the f(R) smoothers' row kernels for n >= 16 (pm_set_fr_rows_sweep; tests compare)
+    int fr_fused_restrict;  // pm_fr_vcycle: operator + the three restrictions in one marching pass (pm_set_fr_fused_restrict)
     int mond_fast_nu;     // pm_mond_rhs, simple function: hardware rsq / sqrt (pm_set_mond_fast_nu; tests compare)
     int mg_fused_coarse;  // pm_lap_vcycle runs the levels from 16^3 down in one workgroup (pm_set_fused_coarse)
     void *mg_buf;        // scratch grids of pm_lap_vcycle (grown on demand)

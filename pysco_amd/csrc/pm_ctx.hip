@@ -71,7 +71,7 @@ extern "C" int pm_ctx_create(pm_ctx **out, int n, void *stream) {
     c->acc_scale_pred = 1.0f;
     c->real_bytes = 4;
     c->age64_np = -1;
-    c->vc_graph_mode = 1, c->mg_fused_coarse = 1, c->fr_rows_sweep = 1, c->fr_march_gradient = 1, c->mond_fast_nu = 1;
+    c->vc_graph_mode = 1, c->mg_fused_coarse = 1, c->fr_rows_sweep = 1, c->fr_march_gradient = 1, c->mond_fast_nu = 1, c->fr_fused_restrict = 1;
     if (hipHostMalloc(&c->h_pinned, PM_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) c->h_pinned = nullptr, (void)hipGetLastError();
     c->n = n;
     c->log2n = __builtin_ctz((unsigned)n);

@@ -1444,6 +1444,100 @@ __global__ __launch_bounds__(BLK) void cubic_operator_march_kernel(const float *
     if (MODE == 2) block_sum_to(acc, result);
 }
 
+// The FAS V-cycle's way down in one pass over the fine grids (n >= 512, cube): the marching operator above, whose values
+// never reach memory -- the restriction (mesh.py:14-110: scale * the eight fine cells summed in the order (i, j), (i, j + 1),
+// (i + 1, j), (i + 1, j + 1), k then k + 1 within each) is taken on the fly, of the operator / residual (scale -1/8
+// without a right-hand side, +1/8 with one), of x and of b alike.  A thread holds eight k-cells of one row of one
+// plane: the k pairs are its own, the row j + 1 belongs to the lane 16 further on (one shuffle per value), the plane
+// i + 1 is the next trip of its own march.  Same operator expression, same order of the sums: the bits of
+// fr_operator + three pm_restriction launches, which write the operator's n^3 floats and read x, b and them again
+// (0.73 -> ms at 512^3).
+template <bool WITH_RHS, int FRN>
+__global__ __launch_bounds__(BLK) void fr_restrict_march_kernel(const float *__restrict__ x, const float *__restrict__ b,
+                                                                float qh2, const float *__restrict__ rhs, int log2n, float h2,
+                                                                float invsix, float res_scale, float *__restrict__ res_c,
+                                                                float *__restrict__ x_c, float *__restrict__ b_c) {
+    __shared__ __attribute__((aligned(16))) float sh[2][RM_TJ + 2][RM_TK + 8];
+    static_assert(RM_LX % 2 == 0 && RM_TJ % 2 == 0, "plane and row pairs stay inside a workgroup's segment");
+    const int n = 1 << log2n, m = n - 1, tid = threadIdx.x, log2nc = log2n - 1;
+    const int ncol_k = n / RM_TK, ncol_j = n / RM_TJ;
+    const int col = blockIdx.x % (ncol_k * ncol_j), seg = blockIdx.x / (ncol_k * ncol_j);
+    const int kb = (col % ncol_k) * RM_TK, j0 = (col / ncol_k) * RM_TJ;
+    const int jj = tid >> 4, kq = tid & 15, j = j0 + jj, k0 = kb + 8 * kq;
+    const int ia = seg * RM_LX, ie = min(ia + RM_LX, n);
+    auto row = [&](const float *g, int a, int bb) -> const float * {
+        return g + ((((int64_t)(a & m) << log2n) + (bb & m)) << log2n);
+    };
+    auto ld8 = [&](const float *p, float *d) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(p), q1 = *reinterpret_cast<const float4 *>(p + 4);
+        d[0] = q0.x, d[1] = q0.y, d[2] = q0.z, d[3] = q0.w, d[4] = q1.x, d[5] = q1.y, d[6] = q1.z, d[7] = q1.w;
+    };
+    const bool edge_j = jj == 0 || jj == RM_TJ - 1, edge_k = kq == 0 || kq == 15;
+    const int jrow = jj == 0 ? j0 - 1 : j0 + RM_TJ, lrow = jj == 0 ? 0 : RM_TJ + 1;
+    const int kcell = kq == 0 ? kb - 1 : kb + RM_TK, lcell = kq == 0 ? 3 : 4 + RM_TK;
+    float prev[8], cur[8], next[8], erow[8], bb8[8], rr8[8], ecell = 0.f;
+    float sr[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};  // the coarse cells under way
+    if (ia < ie) {
+        ld8(row(x, ia - 1, j) + k0, prev);
+        ld8(row(x, ia, j) + k0, cur);
+    }
+    for (int i = ia; i < ie; ++i) {
+        float *pl = &sh[i & 1][0][0];
+        constexpr int RS = RM_TK + 8;
+        ld8(row(x, i + 1, j) + k0, next);
+        ld8(row(b, i, j) + k0, bb8);
+        if (WITH_RHS) ld8(rhs + cidx(i, j, k0, log2n), rr8);
+        if (edge_j) ld8(row(x, i, jrow) + k0, erow);
+        if (edge_k) ecell = row(x, i, j)[kcell & m];
+        *reinterpret_cast<float4 *>(pl + (jj + 1) * RS + 4 + 8 * kq) = make_float4(cur[0], cur[1], cur[2], cur[3]);
+        *reinterpret_cast<float4 *>(pl + (jj + 1) * RS + 8 + 8 * kq) = make_float4(cur[4], cur[5], cur[6], cur[7]);
+        if (edge_j) {
+            *reinterpret_cast<float4 *>(pl + lrow * RS + 4 + 8 * kq) = make_float4(erow[0], erow[1], erow[2], erow[3]);
+            *reinterpret_cast<float4 *>(pl + lrow * RS + 8 + 8 * kq) = make_float4(erow[4], erow[5], erow[6], erow[7]);
+        }
+        if (edge_k) pl[(jj + 1) * RS + lcell] = ecell;
+        __syncthreads();
+        const float *me = pl + (jj + 1) * RS + 4 + 8 * kq, *ym = me - RS, *yp = me + RS;
+        const float4 a0 = *reinterpret_cast<const float4 *>(ym), a1 = *reinterpret_cast<const float4 *>(ym + 4);
+        const float4 c0 = *reinterpret_cast<const float4 *>(yp), c1 = *reinterpret_cast<const float4 *>(yp + 4);
+        const float aym[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float ayp[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        float v[10], res[8];
+        v[0] = me[-1], v[9] = me[8];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) v[c2 + 1] = cur[c2];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+            const float xt = v[c2 + 1];
+            const float p = h2 * bb8[c2] - invsix * (fr_pw<FRN>(prev[c2]) + fr_pw<FRN>(aym[c2]) + fr_pw<FRN>(v[c2]) +
+                                                     fr_pw<FRN>(v[c2 + 2]) + fr_pw<FRN>(ayp[c2]) + fr_pw<FRN>(next[c2]));
+            if (!WITH_RHS) res[c2] = fr_lead<FRN>(xt) + p * xt + qh2;
+            else res[c2] = -(fr_lead<FRN>(xt)) - p * xt - qh2 + rr8[c2];
+        }
+        // the eight sums in the restriction's order: (i even: own row, then row j + 1), (i odd: the same, and out they go)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float r0 = res[2 * q], r1 = res[2 * q + 1], x0 = cur[2 * q], x1 = cur[2 * q + 1], b0 = bb8[2 * q], b1 = bb8[2 * q + 1];
+            const float pr0 = __shfl_xor(r0, 16, 64), pr1 = __shfl_xor(r1, 16, 64);
+            const float px0 = __shfl_xor(x0, 16, 64), px1 = __shfl_xor(x1, 16, 64);
+            const float pb0 = __shfl_xor(b0, 16, 64), pb1 = __shfl_xor(b1, 16, 64);
+            if (!(i & 1)) {
+                sr[q] = r0 + r1 + pr0 + pr1, sx[q] = x0 + x1 + px0 + px1, sb[q] = b0 + b1 + pb0 + pb1;
+            } else {
+                sr[q] = sr[q] + r0 + r1 + pr0 + pr1, sx[q] = sx[q] + x0 + x1 + px0 + px1, sb[q] = sb[q] + b0 + b1 + pb0 + pb1;
+            }
+        }
+        if ((i & 1) && !(jj & 1)) {
+            const int64_t at = cidx(i >> 1, j >> 1, k0 >> 1, log2nc);
+            *reinterpret_cast<float4 *>(res_c + at) = make_float4(res_scale * sr[0], res_scale * sr[1], res_scale * sr[2], res_scale * sr[3]);
+            *reinterpret_cast<float4 *>(x_c + at) = make_float4(0.125f * sx[0], 0.125f * sx[1], 0.125f * sx[2], 0.125f * sx[3]);
+            *reinterpret_cast<float4 *>(b_c + at) = make_float4(0.125f * sb[0], 0.125f * sb[1], 0.125f * sb[2], 0.125f * sb[3]);
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) prev[c2] = cur[c2], cur[c2] = next[c2];
+    }
+}
+
 static bool fr_march_applies(const pm_ctx *c, int n, const float *x, const float *b, const float *o1, const float *o2) {
     return n >= 512 && c->fr_rows_sweep && pm_aligned16(x) && pm_aligned16(b) && pm_aligned16(o1) && pm_aligned16(o2);
 }
@@ -1813,6 +1907,14 @@ extern "C" int pm_fr_smoothing(pm_ctx *c, int fr_n, float *d_x, const float *d_b
     return PM_OK;
 }
 
+// 1 (default): pm_fr_vcycle restricts operator, solution and density term in one marching pass from 512^3 up; 0: operator
+// kernel + three restrictions (comparison)
+extern "C" int pm_set_fr_fused_restrict(pm_ctx *c, int on) {
+    PM_REQUIRE(c, "NULL argument");
+    c->fr_fused_restrict = on ? 1 : 0;
+    return PM_OK;
+}
+
 // 1 (default): the f(R) smoothers use the row kernels for n >= 16; 0: one cell per thread (comparison)
 extern "C" int pm_set_fr_rows_sweep(pm_ctx *c, int on) {
     PM_REQUIRE(c, "NULL argument");
@@ -1860,11 +1962,23 @@ static int fr_vcycle_level(pm_ctx *c, float *x, const float *b, float q, const f
     if ((rc = fr_smooth_pp<FRN>(c, x, fine, b, q, rhs, n, npre, f_relax, &cur))) return rc;
     float *op = cur == x ? fine : x;
     // multigrid.restrict_residual (:282): no rhs -> minus_restriction(operator); rhs -> restriction(rhs - operator)
-    if ((rc = fr_operator<FRN>(c, cur, b, q, rhs, n, op, xr_cube(n)))) return rc;
-    if ((rc = pm_restriction(c, op, n, rhs ? 0.125f : -0.125f, res_c))) return rc;
-    if ((rc = pm_restriction(c, cur, n, 0.125f, x_c))) return rc;
+    if (c->fr_fused_restrict && fr_march_applies(c, n, cur, b, rhs, res_c) && pm_aligned16(x_c) && pm_aligned16(b_c)) {
+        const float h2 = (float)(1.0 / ((double)n * n)), invsix = (float)(1.0 / 6);
+        const unsigned blocks = fr_march_blocks(n, xr_cube(n));
+        if (rhs)
+            hipLaunchKernelGGL((fr_restrict_march_kernel<true, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, cur, b, q * h2, rhs,
+                               ilog2(n), h2, invsix, 0.125f, res_c, x_c, b_c);
+        else
+            hipLaunchKernelGGL((fr_restrict_march_kernel<false, FRN>), dim3(blocks), dim3(BLK), 0, c->stream, cur, b, q * h2, rhs,
+                               ilog2(n), h2, invsix, -0.125f, res_c, x_c, b_c);
+        PM_LAUNCH_CHECK();
+    } else {
+        if ((rc = fr_operator<FRN>(c, cur, b, q, rhs, n, op, xr_cube(n)))) return rc;
+        if ((rc = pm_restriction(c, op, n, rhs ? 0.125f : -0.125f, res_c))) return rc;
+        if ((rc = pm_restriction(c, cur, n, 0.125f, x_c))) return rc;
+        if ((rc = pm_restriction(c, b, n, 0.125f, b_c))) return rc;
+    }
     PM_HIP(hipMemcpyAsync(x_corr_c, x_c, (size_t)ccells * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    if ((rc = pm_restriction(c, b, n, 0.125f, b_c))) return rc;
     if ((rc = fr_operator<FRN>(c, x_c, b_c, q, nullptr, nc, L_c, xr_cube(nc)))) return rc;
     // res_c = 4 res_c + L_c  (utils.linear_operator_vectors_inplace with multigrid.normalisation_residual = 4)
     if ((rc = pm_linear_operator_vectors(c, res_c, 4.0f, L_c, 1.0f, ccells))) return rc;
@@ -1892,7 +2006,7 @@ extern "C" int pm_fr_vcycle(pm_ctx *c, int fr_n, float *d_x, const float *d_b, f
     float *scratch = nullptr;
     int rc = mg_arena(c, ((size_t)n * n * n * 13 / 7 + 4096) * sizeof(float), &scratch);
     if (rc) return rc;
-    return vcycle_graphed(c, 4 * fr_n + (c->mg_fused_sweep ? 1 : 0) + (c->fr_rows_sweep ? 2 : 0), d_x, d_b, q, n, npre, npost, [&]() {
+    return vcycle_graphed(c, 16 * fr_n + (c->mg_fused_sweep ? 1 : 0) + (c->fr_rows_sweep ? 2 : 0) + (c->fr_fused_restrict ? 4 : 0), d_x, d_b, q, n, npre, npost, [&]() {
         return fr_n == 1 ? fr_vcycle_level<1>(c, d_x, d_b, q, nullptr, n, npre, npost, scratch)
                          : fr_vcycle_level<2>(c, d_x, d_b, q, nullptr, n, npre, npost, scratch);
     });

@@ -492,6 +492,36 @@ def test_fr_single_pass_sweep_is_the_two_half_sweeps(amd, n, fr_n, with_rhs, swe
         assert bool((vc[1] == vc[0]).all()), float((vc[1] - vc[0]).abs().max())
 
 
+@pytest.mark.parametrize("fr_n", [1, 2])
+def test_fr_fused_restriction_is_operator_plus_restrictions(amd, fr_n):
+    """pm_fr_vcycle at 512^3 with the restricted operator / residual, solution and density term taken in one marching
+    pass (fr_restrict_march_kernel) against the operator kernel + three pm_restriction launches: the same bits after two
+    cycles (NaNs of the quartic's random data in the same places)."""
+    from pysco_amd import _lib as L
+
+    t = amd.torch
+    n = 512
+    g = t.Generator(device="cuda")
+    g.manual_seed(40 + fr_n)
+    b = t.rand((n, n, n), generator=g, device="cuda") * 0.5 + 0.2
+    x0 = t.rand((n, n, n), generator=g, device="cuda") * 0.2 + 0.9
+    ctx = L.context(4)
+    out = {}
+    try:
+        for fused in (1, 0):
+            ctx.call("pm_set_fr_fused_restrict", fused)
+            x = x0.clone()
+            for _ in range(2):
+                ctx.call("pm_fr_vcycle", fr_n, L.ptr(x), L.ptr(b), -0.1, n, 2, 1)
+            out[fused] = x
+    finally:
+        ctx.call("pm_set_fr_fused_restrict", 1)
+    same = (out[1] == out[0]) | (t.isnan(out[1]) & t.isnan(out[0]))
+    assert bool(same.all()), int((~same).sum())
+    if fr_n == 1:
+        assert bool(t.isfinite(out[1]).all()) and float((out[1] - x0).abs().max()) > 0
+
+
 def test_mond_and_fR_at_benchmark_size(amd):
     """BASELINE configs 4 and 5 at their full 512^3, where the oracle cannot follow: size-independent properties.
     QUMOND: the multigrid and the fft_7pt solver solve the same two discrete Poisson problems (Newtonian potential,
