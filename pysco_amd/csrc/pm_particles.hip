@@ -3140,7 +3140,7 @@ static int kr_bufs(pm_ctx *c, unsigned ntiles, int64_t np, KrBufs *b) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t maxblocks = (size_t)ntiles + (size_t)(np / PM_RANGE_CHUNK) + 2;
     const size_t t32 = up(((size_t)ntiles + 1) * sizeof(unsigned)), w32 = up(maxblocks * sizeof(unsigned));
-    const size_t nent = (size_t)256 * ntiles + (size_t)(np / 4) + ntiles;  // sum of the list capacities (kr_segcap_kernel)
+    const size_t nent = (size_t)256 * ntiles + (size_t)(np / 4) + (size_t)(np / 2) + ntiles;  // sum of the list capacities (kr_segcap_kernel)
     size_t tmp = 0;
     unsigned *nullp = nullptr;
     PM_HIP(rocprim::exclusive_scan(nullptr, tmp, nullp, nullp, 0u, (size_t)ntiles + 1, rocprim::plus<unsigned>(), c->stream));
@@ -3167,13 +3167,32 @@ static int kr_bufs(pm_ctx *c, unsigned ntiles, int64_t np, KrBufs *b) {
     return PM_OK;
 }
 
-// capacity of a tile's incoming list: a quarter of what the tile holds now, and 256 (movers are a few per cent of a
-// tile's particles per step; a list that overflows all the same raises Codes::overflow and the step is taken in place)
-__global__ __launch_bounds__(BLK) void kr_segcap_kernel(const int64_t *__restrict__ start, unsigned ntiles,
+// capacity of a tile's incoming list: 256, a quarter of what the tile holds now, and what its six face neighbours can
+// send it in one drift of at most a cell if they are evenly filled -- an eighth of a neighbour across an x face (the
+// tile is 8 cells thick there), a sixteenth across a y or z face.  (Round 3's first version knew nothing of the
+// neighbours: forty steps into the 1024^3 run a near-empty tile beside a cluster overflowed, every step from then on,
+// and the stream aged: profiles/r03_long_run_s200w5.json, first version.)  A list that overflows all the same -- a
+// cluster sitting on a face -- raises Codes::overflow, the next kick is taken in place and the caller re-buckets with
+// its gather for a while (integration.leapfrog).
+__global__ __launch_bounds__(BLK) void kr_segcap_kernel(const int64_t *__restrict__ start, unsigned ntiles, int n,
                                                         unsigned *__restrict__ cap) {
     const unsigned t = blockIdx.x * BLK + threadIdx.x;
     if (t > ntiles) return;
-    cap[t] = t < ntiles ? 256u + (unsigned)((start[t + 1] - start[t]) >> 2) : 0u;
+    if (t == ntiles) {
+        cap[t] = 0u;
+        return;
+    }
+    const TileId id = tile_of_key(t);
+    const int Ti = n >> PM_LI, Tj = n >> PM_LJ, Tk = n >> PM_LK;
+    auto len = [&](int ti, int tj, int tk) -> unsigned {
+        const unsigned u = tile_key((ti + Ti) % Ti, (tj + Tj) % Tj, (tk + Tk) % Tk);
+        return (unsigned)(start[u + 1] - start[u]);
+    };
+    const unsigned own = (unsigned)(start[t + 1] - start[t]);
+    const unsigned fx = len(id.ti - 1, id.tj, id.tk) + len(id.ti + 1, id.tj, id.tk);
+    const unsigned fyz = len(id.ti, id.tj - 1, id.tk) + len(id.ti, id.tj + 1, id.tk) + len(id.ti, id.tj, id.tk - 1) +
+                         len(id.ti, id.tj, id.tk + 1);
+    cap[t] = 256u + (own >> 2) + (fx >> 3) + (fyz >> 4);
 }
 
 // a tile's population in the new stream: its stayers + its incoming list
@@ -3231,7 +3250,7 @@ extern "C" int pm_gradient_interp_kick_codes(pm_ctx *c, int order, int scheme, c
     rc = tile_work_for(c, d_pos, np, &work, &lists, &nblk);
     if (rc) return rc;
     const unsigned tb = (ntiles + 1 + BLK - 1) / BLK;
-    hipLaunchKernelGGL(kr_segcap_kernel, dim3(tb), dim3(BLK), 0, c->stream, work.start, ntiles, b.segcap);
+    hipLaunchKernelGGL(kr_segcap_kernel, dim3(tb), dim3(BLK), 0, c->stream, work.start, ntiles, c->n, b.segcap);
     PM_LAUNCH_CHECK();
     size_t tmp = b.scan_tmp_bytes;
     PM_HIP(rocprim::exclusive_scan(b.scan_tmp, tmp, b.segcap, b.segstart, 0u, (size_t)ntiles + 1, rocprim::plus<unsigned>(), c->stream));

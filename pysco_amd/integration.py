@@ -122,6 +122,8 @@ _PREDICT = True       # incremental re-sort: file particles under the tile they 
 _KICK_REBUCKETS = True  # ... decided by the gather (in place), carried out by the next fused kick + deposit, which
                         # rewrites position and velocity anyway (pmstep.h: pm_gradient_interp_kick_codes); False: the
                         # gather itself writes the three arrays out of place (pm_gradient_interp_kick_rebucket)
+_KR_HOLD_STEPS = 16     # after a gather whose mover lists overflowed (pm_rebucket_kick_ready says no): that many steps
+                        # are re-bucketed by the gather itself (which has no lists to overflow) before the lists are tried again
 _FUSE_DEPOSIT = True  # tests flip this to compare with the separate kick-drift-wrap and deposit
 _USE_KHALO = True     # ... and this for the plain flush (every tile cell through global atomics)
 _khalo_buffers = {}
@@ -174,8 +176,16 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
             use_khalo = bool(_USE_KHALO and (khalo_consumer or _USE_KHALO == "always"))
             from . import mesh as _mesh
 
-            if (param.get("rebucket_straggler_fraction") is not None and _KICK_REBUCKETS
-                    and _mesh.kick_rebucket_ready(position, ncells_1d)):
+            kr_ready = (param.get("rebucket_straggler_fraction") is not None and _KICK_REBUCKETS
+                        and _mesh.kick_rebucket_ready(position, ncells_1d))
+            if (not kr_ready and _KICK_REBUCKETS and param.get("_kr_decided") and param.get("rebucket_straggler_fraction") is not None):
+                # the last gather decided, and its decisions cannot be used (a mover list overflowed: a cluster on a tile
+                # face): this kick runs in place, and this step's gather and the next few re-bucket the old way
+                logging.warning("the re-bucketing kick's mover lists overflowed: re-bucketing inside the gather for "
+                                f"{_KR_HOLD_STEPS} steps")
+                param["_kr_hold"] = _KR_HOLD_STEPS
+            param["_kr_decided"] = False
+            if kr_ready:
                 # "the kick re-buckets": the last gather decided where every particle goes; this pass, which rewrites
                 # position and velocity anyway, writes them out of place in that order.  The arrays read become the
                 # next step's output arrays.
@@ -220,6 +230,8 @@ def leapfrog(position, velocity, acceleration, potential, additional_field, dt, 
         if rebucket is not None and rebucket.get("mode") == "codes" and rebucket.get("done"):
             # the gather stayed in place (a new acceleration array from the pool, the old one goes back): nothing permuted
             from . import mesh
+
+            param["_kr_decided"] = True  # (the next kick checks that the decisions could be used)
 
             if acceleration_in.data_ptr() != acceleration.data_ptr():
                 mesh.pool_give(acceleration_in)
@@ -275,7 +287,10 @@ def _rebucket_request(density, param, position, kick_rebucketed=False):
     # to be punished that way every other step)
     if float(thr) > 0.0 and frac <= float(thr):
         return None
-    if _KICK_REBUCKETS and _PREDICT and float(thr) <= 0.0 and (param.get("_dt_pred") or 0.0) > 0.0:
+    hold = int(param.get("_kr_hold", 0) or 0)
+    if hold > 0 and not kick_rebucketed:
+        param["_kr_hold"] = hold - 1
+    elif _KICK_REBUCKETS and _PREDICT and float(thr) <= 0.0 and (param.get("_dt_pred") or 0.0) > 0.0:
         return {"mode": "codes"}  # the gather decides, the next fused kick carries it out (every step: f <= 0 only)
     if kick_rebucketed:  # (this step's fused kick already re-sorted, and left no counts for a re-bucketing gather)
         return None
