@@ -404,3 +404,33 @@ def test_bench_size_rebucket_matches_inplace():
     assert float((v1 - v0[idx]).abs().max()) < 2e-4 * float(v0.abs().max())
     assert float((a1 - a0[idx]).abs().max()) < 2e-4 * float(a0.abs().max())
     assert f1[-1] < 1e-3 and f1[-1] < 0.2 * f0[-1], (f0, f1)  # filed where they are: the in-place stream ages instead
+
+
+def test_kick_rebucket_overflow_falls_back_to_the_gather():
+    """A cluster sitting on a tile face and moving across it: more movers into one tile than its incoming list holds
+    (256 + a quarter of its own + an eighth of its x-face neighbours).  The gather raises the overflow flag, the next
+    fused kick runs in place, integration.leapfrog re-buckets with the gather itself for _KR_HOLD_STEPS steps -- and the
+    particles are the in-place run's (by tag), nobody lost, the stream tile-sorted again at the end."""
+    n = 64
+    pos_h, vel_h = zeldovich_particles(32, seed=12, rms_cells=0.3, vel_factor=0.05)
+    rng = np.random.default_rng(5)
+    m = 60000
+    blob = np.empty((m, 3), np.float32)
+    blob[:, 0] = (24.0 - rng.random(m) * 0.15) / n        # just below the x face between tiles 2 and 3
+    blob[:, 1] = (20.0 + rng.random(m) * 8.0) / n
+    blob[:, 2] = (36.0 + rng.random(m) * 8.0) / n
+    vb = np.zeros((m, 3), np.float32)
+    vb[:, 0] = 40.0 * np.abs(vel_h).max()                   # the fastest particles of the run: they set dt and move ~C cells
+    pos_h = np.concatenate([pos_h, blob]).astype(np.float32)
+    vel_h = np.concatenate([vel_h, vb]).astype(np.float32)
+    ref = _run(n, pos_h, vel_h, 5, None, predict=True)
+    new = _run(n, pos_h, vel_h, 5, 0.0, predict=True)
+    assert "_kr_hold" in new[5], "the lists were expected to overflow"
+    for k in range(3):
+        a, b = ref[k][ref[3]], new[k][new[3]]
+        if k == 0:
+            d = np.abs(a - b)
+            assert np.minimum(d, 1 - d).max() <= 3e-6
+        else:
+            assert np.abs(a - b).max() <= 2e-4 * np.abs(a).max()
+    assert new[4][-1] < 0.05, new[4]
