@@ -105,11 +105,13 @@ def pm(position, param, potential=None, additional_field=None, tables=(), _kick=
     if param["save_pk"]:  # (of the density itself: the same spectrum solver.fft derives from the scaled source)
         k, pk, nmodes = power_spectrum(density.clone(), param)
         iostream.write_power_spectrum_to_ascii_file(k, pk, nmodes, param)
+    # solver.rhs_poisson (solver.py:381-449): f1 rho - f1.  The constant only feeds the k = 0 mode, which the Green's
+    # function zeroes (fourier.py:491, 544, 595), and the factor commutes with the transform: both ride on the Green's
+    # prefactor instead of a pass over the grid (1e-16 relative; as the fp32 step does)
     f1 = 1.5 * param["aexp"] * param["Om_m"]
-    ctx.call("pm_real64_scale_add", L.ptr(density), float(f1), float(-f1), n**3)  # solver.rhs_poisson: f1 rho - f1
     kind, k2, s, c0 = green_tables(n, solver)
     phi = torch.empty_like(density)
-    ctx.call("pm_real64_poisson_fft", kind, int(param["MAS_index"]), L.ptr(density), L.ptr(phi), L.hptr(k2), L.hptr(s), float(c0))
+    ctx.call("pm_real64_poisson_fft", kind, int(param["MAS_index"]), L.ptr(density), L.ptr(phi), L.hptr(k2), L.hptr(s), float(c0 * f1))
     del density
     force = torch.empty((n, n, n, 3), dtype=torch.float64, device=pos_d.device)
     ctx.call("pm_real64_gradient", int(param["gradient_stencil_order"]), L.ptr(phi), L.ptr(force))
