@@ -463,7 +463,10 @@ int pm_fr_solve(pm_ctx *ctx, int fr_n, float *d_x, const float *d_b, float q, in
  * obeying those decisions: position and velocity of the new step are written OUT OF PLACE into d_pos_out / d_vel_out, tile
  * after tile (d_pos / d_vel / d_acc are only read; optional uint32 tags follow), and the new stream's tile offsets, ranges
  * and straggler lists are left prepared.  pm_rebucket_kick_ready: *h_ready = 1 if the decisions on file are for exactly
- * d_pos / np and no list overflowed (otherwise take the in-place step). */
+ * d_pos / np and no list overflowed (otherwise take the in-place step and re-bucket with
+ * pm_gradient_interp_kick_rebucket, which has no lists).  A tile's incoming list holds 256 entries + a quarter of the
+ * tile's own population + an eighth (x faces) / a sixteenth (y, z faces) of its face neighbours': what evenly filled
+ * neighbours can send in one drift of at most a cell; 0.94 entries per particle in all. */
 int pm_gradient_interp_kick_codes(pm_ctx *ctx, int order, int scheme, const float *d_phi, const float *d_pos, float *d_vel,
                                   int64_t np, float half_dt, float *d_acc);
 int pm_rebucket_kick_ready(pm_ctx *ctx, const float *d_pos, int64_t np, int *h_ready);
