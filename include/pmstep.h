@@ -321,7 +321,7 @@ int pm_diff_norm(pm_ctx *ctx, const float *d_a, const float *d_b, float f, int64
  * same bits as the per-operator entry points called in that order.  n >= 8. */
 int pm_fr_vcycle(pm_ctx *ctx, int fr_n, float *d_x, const float *d_b, float q, int n, int npre, int npost);
 /* cubic.smoothing / smoothing_with_rhs (cubic.py:1065, 1100; quartic.py:1066, 1101): n_smoothing red-black sweeps of
- * the scalaron with omega = 1.25, result in x; d_rhs may be NULL.  For n >= 256 (fr_n = 1) each sweep is one pass over the grid,
+ * the scalaron with omega = 1.25, result in x; d_rhs may be NULL.  For n >= 256 each sweep is one pass over the grid,
  * as pm_lap_smoothing (the same marching kernel with the cubic / quartic cell update), out of place into a scratch grid
  * of the context; same bits as pm_cubic / pm_quartic_gauss_seidel called n_smoothing times.  pm_fr_vcycle's sweeps are
  * these.  pm_set_fused_sweep(ctx, 0) makes every sweep the two half-sweep launches again. */

@@ -1222,8 +1222,9 @@ extern "C" int pm_lap_gauss_seidel_slab(pm_ctx *c, float *d_x, const float *d_b,
 // f(R) n = 1 (cubic.py) and n = 2 (quartic.py): same stencil with u^2 / u^3 neighbour powers and the
 // depressed cubic / quartic root; kernels are templated on FRN = 1, 2.
 
-// quartic.py:157-210 solution_quartic_equation: fp64, same branch structure
-__device__ __forceinline__ double quartic_root(float pf, float qf) {
+// quartic.py:157-210 solution_quartic_equation: fp64, same branch structure.  Out of line: quartic_root below calls it
+// for the cells its fast path declines.
+__device__ __attribute__((noinline)) double quartic_root_closed_form(float pf, float qf) {
     const double pp = (double)pf, qq = (double)qf;
     if (pp == 0.0) return pow(-qq, 0.25);
     const double d0 = 12.0 * qq, d1 = 27.0 * (pp * pp);
@@ -1238,6 +1239,40 @@ __device__ __forceinline__ double quartic_root(float pf, float qf) {
         return S + 0.5 * sqrt(-4.0 * (S * S) - pp / S);
     }
     return pow(-qq, 0.25);
+}
+
+// The same root for ~80 instructions (cubic_root's recipe, further down): the reference's formula in its regular
+// branch (p != 0, the square-root term >= 0, Q + d0 / Q > 0) evaluated in fp32 with the hardware's 1-ulp sqrt / rcp /
+// log / exp, one fp32 Newton step of u^4 + p u + q (the formula's last line subtracts terms of like size), one more
+// whose residual is fp64 and whose slope and quotient are fp32; the last step is the check (more than 3e-5 of u, a NaN
+// anywhere: the closed form in fp64, as every other branch).  numpy emulation over 10^7 (p, q): the fp64 formula's float
+// but for rounding-boundary cases, no NaN of the reference turned into a number.
+__device__ __forceinline__ float quartic_root(float pf, float qf) {
+    if (pf != 0.0f) {
+        const float d0 = 12.0f * qf, d1 = 27.0f * (pf * pf);
+        const float r = d0 * __builtin_amdgcn_rcpf(d1);
+        const float st = 1.0f - 4.0f * d0 * (r * r);
+        if (st >= 0.0f) {
+            const float h = 0.5f * d1 * (1.0f + __builtin_amdgcn_sqrtf(st));
+            const float Q = __builtin_amdgcn_exp2f(0.33333334f * __builtin_amdgcn_logf(h));
+            const float QQ = Q + d0 * __builtin_amdgcn_rcpf(Q);
+            if (QQ > 0.0f) {
+                const float S = 0.5f * __builtin_amdgcn_sqrtf(QQ * 0.33333334f);
+                const float pS = pf * __builtin_amdgcn_rcpf(S);
+                const float x0 = pf > 0.0f ? -S + 0.5f * __builtin_amdgcn_sqrtf(-4.0f * (S * S) + pS)
+                                           : S + 0.5f * __builtin_amdgcn_sqrtf(-4.0f * (S * S) - pS);
+                const float x02 = x0 * x0;
+                const float f0 = __builtin_fmaf(x02, x02, __builtin_fmaf(pf, x0, qf));
+                const float x1 = x0 - f0 * __builtin_amdgcn_rcpf(__builtin_fmaf(4.0f * x02, x0, pf));
+                const double x = (double)x1, x2 = x * x;
+                const double f = fma(x2, x2, fma((double)pf, x, (double)qf));
+                const float x12 = x1 * x1;
+                const float delta = (float)f * __builtin_amdgcn_rcpf(__builtin_fmaf(4.0f * x12, x1, pf));
+                if (fabsf(delta) <= 3.0e-5f * fabsf(x1)) return x1 - delta;
+            }
+        }
+    }
+    return (float)quartic_root_closed_form(pf, qf);
 }
 
 template <int FRN>
@@ -1857,8 +1892,7 @@ static int fr_smooth_pp(pm_ctx *c, float *cur, float *other, const float *b, flo
                         float f_relax, float **where) {
     int rc;
     *where = cur;
-    // (the quartic's root is the fp64 closed form: the single-pass kernel is bound by it and slower than the half-sweeps)
-    if (FRN != 1 || !lap_fused_applies(c, n, cur, b, other) || (rhs && !pm_aligned16(rhs))) {
+    if (!lap_fused_applies(c, n, cur, b, other) || (rhs && !pm_aligned16(rhs))) {
         for (int s = 0; s < n_sweeps; ++s)
             if ((rc = fr_gauss_seidel<FRN>(c, cur, b, q, rhs, n, f_relax, xr_cube(n), 0, 3))) return rc;
         return PM_OK;
@@ -1872,14 +1906,12 @@ static int fr_smooth_pp(pm_ctx *c, float *cur, float *other, const float *b, flo
 #define FR_FUSED(LX, WITH)                                                                                                   \
     hipLaunchKernelGGL((gs_fused_kernel<LX, FrCell<WITH, FRN>>), dim3(blocks), dim3(BLK), 0, c->stream, src, b, rhs, dst, ilog2(n), \
                        FrCell<WITH, FRN>{h2, invsix, f_relax, c_q})
-        if constexpr (FRN == 1) {
-            if (lx == 64) {
-                if (rhs) FR_FUSED(64, true);
-                else FR_FUSED(64, false);
-            } else {
-                if (rhs) FR_FUSED(32, true);
-                else FR_FUSED(32, false);
-            }
+        if (lx == 64) {
+            if (rhs) FR_FUSED(64, true);
+            else FR_FUSED(64, false);
+        } else {
+            if (rhs) FR_FUSED(32, true);
+            else FR_FUSED(32, false);
         }
 #undef FR_FUSED
         PM_LAUNCH_CHECK();
@@ -1957,7 +1989,7 @@ static int fr_vcycle_level(pm_ctx *c, float *x, const float *b, float q, const f
     // coarse ones
     float *fine = scratch, *res_c = fine + cells, *x_c = res_c + ccells, *x_corr_c = x_c + ccells, *b_c = x_corr_c + ccells,
           *L_c = b_c + ccells, *next = L_c + ccells;
-    const bool pingpong = FRN == 1 && lap_fused_applies(c, n, x, b, fine) && (!rhs || pm_aligned16(rhs));
+    const bool pingpong = lap_fused_applies(c, n, x, b, fine) && (!rhs || pm_aligned16(rhs));
     float *cur = x;  // the array that holds the level's solution at the moment; the other of (x, fine) is free
     if ((rc = fr_smooth_pp<FRN>(c, x, fine, b, q, rhs, n, npre, f_relax, &cur))) return rc;
     float *op = cur == x ? fine : x;
