@@ -136,6 +136,7 @@ def alg_bytes(n, npart):
         # the fp64 device mode (8-byte elements; its gradient is a pass of its own: read phi, write F(3))
         "pm_real64_kick_drift_wrap": 120.0 * npart,
         "pm_real64_deposit": 24.0 * npart + 8.0 * cells,
+        "pm_real64_kick_drift_wrap_deposit": 120.0 * npart + 8.0 * cells,
         "pm_real64_scale_add": 16.0 * cells,
         "pm_real64_poisson_fft": 96.0 * cells,
         "pm_real64_gradient": 32.0 * cells,

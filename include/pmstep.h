@@ -491,6 +491,10 @@ int pm_real64_scale_add(pm_ctx *ctx, double *d_x, double a, double b, int64_t n)
 int pm_real64_max_abs(pm_ctx *ctx, const double *d_x, int64_t n, double *h_out);
 /* mesh.NGP :2240 / CIC :2284 / TSC :2468; d_rho [n,n,n] is overwritten */
 int pm_real64_deposit(pm_ctx *ctx, int scheme, const double *d_pos, int64_t np, double *d_rho);
+/* the two above in one pass over the particles (integration.py:250-258 followed by the deposit of solver.py:75-90): same
+ * expressions per particle, position and velocity updated in place */
+int pm_real64_kick_drift_wrap_deposit(pm_ctx *ctx, int scheme, double *d_pos, double *d_vel, const double *d_acc, double half_dt,
+                                      double dt, int64_t np, double *d_rho);
 /* solver.fft :453-522: r2c, Green's function (pm_greens' kinds and tables, in double), c2r with 1/n^3.
  * d_rhs may be overwritten. */
 int pm_real64_poisson_fft(pm_ctx *ctx, int kind, int p, const double *d_rhs, double *d_phi, const double *h_k2,

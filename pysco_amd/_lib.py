@@ -158,6 +158,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_real64_scale_add": (_vp, _vp, _d, _d, _i64),
     "pm_real64_max_abs": (_vp, _vp, _i64, C.POINTER(_d)),
     "pm_real64_deposit": (_vp, _i, _vp, _i64, _vp),
+    "pm_real64_kick_drift_wrap_deposit": (_vp, _i, _vp, _vp, _vp, _d, _d, _i64, _vp),
     "pm_real64_poisson_fft": (_vp, _i, _i, _vp, _vp, _vp, _vp, _d),
     "pm_real64_gradient": (_vp, _i, _vp, _vp),
     "pm_real64_interp_kick": (_vp, _i, _vp, _vp, _i64, _vp, _vp, _d, C.POINTER(_d), C.POINTER(_d)),

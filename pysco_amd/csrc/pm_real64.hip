@@ -244,9 +244,13 @@ __device__ __forceinline__ bool next_tile(unsigned todo, const int (&key)[NP], i
     return true;
 }
 
-template <int SCHEME>
-__global__ __launch_bounds__(BLK) void deposit64_kernel(const double *__restrict__ pos, int64_t np, int n, int log2n,
-                                                        double *__restrict__ rho) {
+// KDW: the first kick, the drift and the wrap of the leapfrog (kdw64_kernel's expressions) applied where the particle is
+// first read -- position and velocity updated in place -- so that the deposit does not read the positions a pass of
+// their own has just written (pm_real64_kick_drift_wrap_deposit)
+template <int SCHEME, bool KDW = false>
+__global__ __launch_bounds__(BLK) void deposit64_kernel(double *pos, int64_t np, int n, int log2n, double *__restrict__ rho,
+                                                        double *vel = nullptr, const double *acc = nullptr, double mhalf_dt = 0.0,
+                                                        double dt = 0.0) {
     __shared__ double tile[TILE];  // 25.9 KB
     __shared__ int s_pick[3];
     const int tid = threadIdx.x;
@@ -261,7 +265,18 @@ __global__ __launch_bounds__(BLK) void deposit64_kernel(const double *__restrict
         const int64_t p = base + r * BLK + tid;
         key[r] = -1;
         if (p < np) {
-            const double xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
+            double x[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                x[m] = pos[3 * p + m];
+                if (KDW) {
+                    const double v = vel[3 * p + m] + mhalf_dt * acc[3 * p + m];  // (utils.py:297: product and sum rounded separately)
+                    vel[3 * p + m] = v;
+                    x[m] = wrap01(x[m] + dt * v);
+                    pos[3 * p + m] = x[m];  // (read again below by this very thread)
+                }
+            }
+            const double xp = x[0] * nf, yp = x[1] * nf, zp = x[2] * nf;
             key[r] = tile_key_of(cell_of(xp, n), cell_of(yp, n), cell_of(zp, n));
             todo |= 1u << r;
         }
@@ -679,21 +694,36 @@ extern "C" int pm_real64_max_abs(pm_ctx *c, const double *d_x, int64_t n, double
     return pm_read_back(c, h_out, d_bits, sizeof(double));
 }
 
-extern "C" int pm_real64_deposit(pm_ctx *c, int scheme, const double *d_pos, int64_t np, double *d_rho) {
-    PM_REQUIRE_F64(c);
-    PM_REQUIRE(d_pos && d_rho && np >= 0, "bad argument");
+template <bool KDW>
+static int deposit64_launch(pm_ctx *c, int scheme, double *d_pos, int64_t np, double *d_rho, double *d_vel, const double *d_acc,
+                            double mhalf_dt, double dt) {
     const int n = c->n;
     PM_HIP(hipMemsetAsync(d_rho, 0, (size_t)n * n * n * sizeof(double), c->stream));
     if (np == 0) return PM_OK;
     const dim3 grid((unsigned)((np + CHUNK - 1) / CHUNK));
     switch (scheme) {
-        case PM_NGP: hipLaunchKernelGGL((deposit64_kernel<PM_NGP>), grid, dim3(BLK), 0, c->stream, d_pos, np, n, c->log2n, d_rho); break;
-        case PM_CIC: hipLaunchKernelGGL((deposit64_kernel<PM_CIC>), grid, dim3(BLK), 0, c->stream, d_pos, np, n, c->log2n, d_rho); break;
-        case PM_TSC: hipLaunchKernelGGL((deposit64_kernel<PM_TSC>), grid, dim3(BLK), 0, c->stream, d_pos, np, n, c->log2n, d_rho); break;
+        case PM_NGP: hipLaunchKernelGGL((deposit64_kernel<PM_NGP, KDW>), grid, dim3(BLK), 0, c->stream, d_pos, np, n, c->log2n, d_rho, d_vel, d_acc, mhalf_dt, dt); break;
+        case PM_CIC: hipLaunchKernelGGL((deposit64_kernel<PM_CIC, KDW>), grid, dim3(BLK), 0, c->stream, d_pos, np, n, c->log2n, d_rho, d_vel, d_acc, mhalf_dt, dt); break;
+        case PM_TSC: hipLaunchKernelGGL((deposit64_kernel<PM_TSC, KDW>), grid, dim3(BLK), 0, c->stream, d_pos, np, n, c->log2n, d_rho, d_vel, d_acc, mhalf_dt, dt); break;
         default: pm_set_error("mass scheme %d, should be NGP(1), CIC(2) or TSC(3)", scheme); return PM_EINVAL;
     }
     PM_LAUNCH_CHECK();
     return PM_OK;
+}
+
+extern "C" int pm_real64_deposit(pm_ctx *c, int scheme, const double *d_pos, int64_t np, double *d_rho) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(d_pos && d_rho && np >= 0, "bad argument");
+    return deposit64_launch<false>(c, scheme, const_cast<double *>(d_pos), np, d_rho, nullptr, nullptr, 0.0, 0.0);
+}
+
+// pm_real64_kick_drift_wrap followed by pm_real64_deposit of the new positions, in one pass over the particles (the
+// same expressions, particle by particle: the same position, velocity and -- up to the order of the double sums -- density)
+extern "C" int pm_real64_kick_drift_wrap_deposit(pm_ctx *c, int scheme, double *d_pos, double *d_vel, const double *d_acc,
+                                                 double half_dt, double dt, int64_t np, double *d_rho) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(d_pos && d_vel && d_acc && d_rho && np >= 0, "bad argument");
+    return deposit64_launch<true>(c, scheme, d_pos, np, d_rho, d_vel, d_acc, -half_dt, dt);
 }
 
 extern "C" int pm_real64_poisson_fft(pm_ctx *c, int kind, int p, const double *d_rhs, double *d_phi, const double *h_k2,

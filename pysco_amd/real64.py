@@ -81,7 +81,7 @@ def power_spectrum(density, param):
     return k * (2 * np.pi / param["boxlen"]), pk * (param["boxlen"] / n**2) ** 3, nmodes
 
 
-def pm(position, param, potential=None, additional_field=None, tables=(), _kick=None):
+def pm(position, param, potential=None, additional_field=None, tables=(), _kick=None, _density=None):
     """solver.pm (solver.py:30-215) in float64.  Returns (acceleration, potential, additional_field): the kinds of the
     input (NumPy in, NumPy out); `_kick = (velocity, half_dt)` (private) applies the second kick of the leapfrog in
     the gather's pass and leaves max|a|, max|v| in param["_max_f64"]."""
@@ -94,8 +94,11 @@ def pm(position, param, potential=None, additional_field=None, tables=(), _kick=
     pos_d = _dev(position)
     npart = pos_d.shape[0]
     ctx = L.context(n, 8)
-    density = torch.empty((n, n, n), dtype=torch.float64, device=pos_d.device)
-    ctx.call("pm_real64_deposit", scheme, L.ptr(pos_d), npart, L.ptr(density))
+    if _density is not None:  # (private: deposited by integrate()'s fused kick + drift + deposit)
+        density = _density
+    else:
+        density = torch.empty((n, n, n), dtype=torch.float64, device=pos_d.device)
+        ctx.call("pm_real64_deposit", scheme, L.ptr(pos_d), npart, L.ptr(density))
     if n**3 != param["npart"]:
         ctx.call("pm_real64_scale_add", L.ptr(density), float(n**3 / param["npart"]), 0.0, n**3)
     save = param["save_power_spectrum"].casefold()
@@ -161,34 +164,40 @@ def integrate(position, velocity, acceleration, potential, additional_field, tab
     logging.info(f"Conditions: velocity {dt1=}, acceleration {dt2=}, scale factor {dt3=}")
     half_dt = 0.5 * dt
     n = 2 ** int(param["ncoarse"])
-    L.context(n, 8).call("pm_real64_kick_drift_wrap", L.ptr(pos_d), L.ptr(vel_d), L.ptr(acc_d), float(half_dt), float(dt),
-                         pos_d.shape[0])
+    # The product loop's order policy (main.run_nbody sets the key: the caller takes new arrays back).  When the last
+    # gather on a stream one drift old made more tile passes per chunk than pays (a sorted stream makes ~2; a step that
+    # sorted says ~2 whatever the next drift will do, so every ninth step in a row goes unsorted to take the measure
+    # again), the drifted particles are sorted to tile resolution HERE, before the deposit and the gather of this step
+    # read them -- after the step the order would already be one drift old when it is first used -- and only position
+    # and velocity move (the old acceleration is dead after the kick).
+    resort = False
     if not host and param.get("rebucket_straggler_fraction") is not None:
-        # The product loop's order policy (main.run_nbody sets the key: the caller takes new arrays back).  The last
-        # gather made more tile passes per chunk than a sorted stream needs: sort the drifted particles to tile
-        # resolution HERE, before the deposit and the gather of this step read them (both then see a perfectly sorted
-        # stream; after the step the order would already be one drift old when it is first used), and move only
-        # position and velocity (the old acceleration is dead after the kick).
-        # (the measure that counts is the one taken on a stream one drift old: a step that sorted says ~2 whatever the
-        # next drift will do; every ninth step in a row goes unsorted to take it again)
         age = stream_age(n)
         if age is not None and not param.get("_f64_sorted_last", False):
             param["_f64_aged_passes"] = age[1]
         aged, streak = param.get("_f64_aged_passes"), int(param.get("_f64_sort_streak", 0))
         resort = aged is not None and aged > float(param.get("resort_passes_per_chunk", RESORT_PASSES_PER_CHUNK)) and streak < 8
         param["_f64_sorted_last"], param["_f64_sort_streak"] = resort, (streak + 1 if resort else 0)
-        if resort:
-            ids = param.get("particle_id")
-            order = [] if ids is not None and L.is_device_array(ids) else None
-            pos_d, vel_d = reorder_particles(pos_d, vel_d, _order_out=order, _key_bits=-1, _ncells=n, _pool=True)
-            if order:
-                param["particle_id"] = ids[order[0]]
-            param["_resorted_f64"] = int(param.get("_resorted_f64", 0)) + 1
+    density = None
+    if resort or host or n < 16:  # kick + drift + wrap (then the sort), the deposit in pm()
+        L.context(n, 8).call("pm_real64_kick_drift_wrap", L.ptr(pos_d), L.ptr(vel_d), L.ptr(acc_d), float(half_dt), float(dt),
+                             pos_d.shape[0])
+    else:  # ... or all of it in one pass over the particles
+        density = L.require_gpu().empty((n, n, n), dtype=pos_d.dtype, device=pos_d.device)
+        L.context(n, 8).call("pm_real64_kick_drift_wrap_deposit", _scheme(param), L.ptr(pos_d), L.ptr(vel_d), L.ptr(acc_d),
+                             float(half_dt), float(dt), pos_d.shape[0], L.ptr(density))
+    if resort:
+        ids = param.get("particle_id")
+        order = [] if ids is not None and L.is_device_array(ids) else None
+        pos_d, vel_d = reorder_particles(pos_d, vel_d, _order_out=order, _key_bits=-1, _ncells=n, _pool=True)
+        if order:
+            param["particle_id"] = ids[order[0]]
+        param["_resorted_f64"] = int(param.get("_resorted_f64", 0)) + 1
     param["t"] += dt
     param["aexp_old"] = param["aexp"]
     param["aexp"] = float(np.exp(utils.table_eval(tables[0], param["t"])))
     utils.set_units(param)
-    acc_d, potential, additional_field = pm(pos_d, param, tables=tables, _kick=(vel_d, half_dt))
+    acc_d, potential, additional_field = pm(pos_d, param, tables=tables, _kick=(vel_d, half_dt), _density=density)
     if host:
         param.pop("_max_f64", None)
         return pos_d.cpu().numpy(), vel_d.cpu().numpy(), acc_d.cpu().numpy(), potential.cpu().numpy(), additional_field.cpu().numpy()
