@@ -504,12 +504,25 @@ __global__ __launch_bounds__(IB) void interp64_kernel(const double *__restrict__
     unsigned long long ma = 0, mv = 0;
     unsigned direct = 0, npass = 0;  // particles served through L2, tile passes: what pm_real64_stream_age reports
     // serves particle slot r: dense -> from the LDS tile of t, else through L2
-    auto serve = [&](int r, bool dense, const Tile &t) {
+    // a particle's record on its way to the service loop: loaded one particle ahead (the first of a pass before the
+    // tile fill), so that its two memory latencies lie behind the fill / the previous particle's 27 cells
+    struct Slot {
+        double x[3], v[3];
+    };
+    auto load = [&](int r) {
+        Slot q;
+        const int64_t p = min(base + (int64_t)max(r, 0) * IB + tid, np - 1);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            q.x[m] = pos[3 * p + m];
+            q.v[m] = KICK ? __builtin_nontemporal_load(vel + 3 * p + m) : 0.0;
+        }
+        return q;
+    };
+    auto serve = [&](int r, const Slot &q, bool dense, const Tile &t) {
         const int64_t p = base + r * IB + tid;
-        double v[3] = {0.0, 0.0, 0.0};
-        const double xp = pos[3 * p] * nf, yp = pos[3 * p + 1] * nf, zp = pos[3 * p + 2] * nf;
-        if (KICK) v[0] = __builtin_nontemporal_load(vel + 3 * p), v[1] = __builtin_nontemporal_load(vel + 3 * p + 1),
-                  v[2] = __builtin_nontemporal_load(vel + 3 * p + 2);
+        const double xp = q.x[0] * nf, yp = q.x[1] * nf, zp = q.x[2] * nf;
+        const double *v = q.v;
         const int i = cell_of(xp, n), j = cell_of(yp, n), k = cell_of(zp, n);
         double a[3];
         if (dense) {
@@ -531,6 +544,19 @@ __global__ __launch_bounds__(IB) void interp64_kernel(const double *__restrict__
             }
         }
     };
+    // the particles of `mask`, lowest slot first, `first` being the record of the first one
+    auto sweep = [&](unsigned mask, const Slot &first, bool dense, const Tile &t) {
+        Slot nxt = first;
+        int r = mask ? __ffs((int)mask) - 1 : -1;
+        while (mask) {
+            mask &= mask - 1u;
+            const int rn = mask ? __ffs((int)mask) - 1 : -1;
+            const Slot cur = nxt;
+            if (rn >= 0) nxt = load(rn);
+            serve(r, cur, dense, t);
+            r = rn;
+        }
+    };
     const bool tiled = n >= 16;
     unsigned left = todo;  // served through L2 at the end: the sparse ones (everything when n < 16)
     if (tiled) {
@@ -544,6 +570,7 @@ __global__ __launch_bounds__(IB) void interp64_kernel(const double *__restrict__
         const Tile t = tile_of_key(akey);
         ++npass;
         const bool dense = true;
+        const Slot first = load(mine ? __ffs((int)mine) - 1 : 0);  // (in flight during the fill)
         {
             // the force tile: consecutive lanes, consecutive doubles of a row of 18 x 3; FILL_U loads in flight per thread
             // before the first is stored (one load per trip was 38 memory latencies in a row per pass: most of the kernel)
@@ -565,15 +592,11 @@ __global__ __launch_bounds__(IB) void interp64_kernel(const double *__restrict__
             }
             __syncthreads();
         }
-#pragma unroll 1
-        for (int r = 0; r < IPT; ++r)
-            if (mine >> r & 1u) serve(r, dense, t);
+        sweep(mine, first, dense, t);
         todo &= ~mine;
     }
     left |= todo;
-#pragma unroll 1
-    for (int r = 0; r < IPT; ++r)  // the sparse ones
-        if (left >> r & 1u) serve(r, false, Tile{0, 0, 0});
+    if (__ballot(left != 0u)) sweep(left, load(left ? __ffs((int)left) - 1 : 0), false, Tile{0, 0, 0});  // the sparse ones
     for (int off = 32; off > 0; off >>= 1) {
         ma = max(ma, (unsigned long long)__shfl_down((long long)ma, off, 64));
         mv = max(mv, (unsigned long long)__shfl_down((long long)mv, off, 64));
