@@ -243,3 +243,64 @@ def test_real64_stream_age_and_policy():
     key = _morton21(pr.cpu().numpy()) >> (63 - (3 * 6 - 11))  # (the policy sorts to the 8 x 16 x 16-cell tiles)
     assert (np.diff(key) >= 0).all()
     np.testing.assert_array_equal(np.sort(pr.cpu().numpy(), axis=0), np.sort(pu.cpu().numpy(), axis=0))
+
+
+def test_real64_fused_kick_deposit_is_the_two_passes():
+    """pm_real64_kick_drift_wrap_deposit against pm_real64_kick_drift_wrap followed by pm_real64_deposit: the same
+    position and velocity bit for bit, the same density up to the order of the double sums."""
+    import torch
+
+    from pysco_amd import _lib as L
+
+    n = 64
+    pos, vel = _particles(48, seed=8, rms=0.8)
+    rng = np.random.default_rng(8)
+    acc = rng.standard_normal(pos.shape) * 0.05
+    ctx = L.context(n, 8)
+    out = {}
+    for fused in (False, True):
+        p, v, a = (torch.from_numpy(x.copy()).cuda() for x in (pos, vel, acc))
+        rho = torch.empty((n, n, n), dtype=torch.float64, device="cuda")
+        if fused:
+            ctx.call("pm_real64_kick_drift_wrap_deposit", L.TSC, L.ptr(p), L.ptr(v), L.ptr(a), 0.01, 0.02, p.shape[0], L.ptr(rho))
+        else:
+            ctx.call("pm_real64_kick_drift_wrap", L.ptr(p), L.ptr(v), L.ptr(a), 0.01, 0.02, p.shape[0])
+            ctx.call("pm_real64_deposit", L.TSC, L.ptr(p), p.shape[0], L.ptr(rho))
+        out[fused] = (p.cpu().numpy(), v.cpu().numpy(), rho.cpu().numpy())
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    np.testing.assert_array_equal(out[True][1], out[False][1])
+    assert np.abs(out[True][2] - out[False][2]).max() <= 1e-12
+    assert abs(out[True][2].sum() - len(pos)) < 1e-8 and np.abs(out[True][0] - pos).max() > 0
+
+
+def test_real64_steps_with_the_resort_policy_match_in_place_steps():
+    """Eight fp64 leapfrog steps with the order policy forced on every step (a tile re-sort of position and velocity
+    right after the drift, fused kick + deposit on the others) against the same steps in place: the same particles by
+    tag to 1e-12 (only the order of the deposit's double sums differs), and the policy did re-sort."""
+    import torch
+
+    from pysco_amd import integration, solver
+
+    n = 64
+    pos, vel = _particles(64, seed=21, rms=0.6)
+    out = {}
+    for policy in (False, True):
+        param, tables = _param(n, len(pos))
+        if policy:
+            param["rebucket_straggler_fraction"] = 0.0
+            param["resort_passes_per_chunk"] = 0.0  # (every step the gather has measured)
+            param["particle_id"] = torch.arange(len(pos), dtype=torch.int32, device="cuda")
+        p, v = torch.from_numpy(pos.copy()).cuda(), torch.from_numpy(vel.copy()).cuda()
+        a, phi, extra = solver.pm(p, param, tables=tables)
+        for _ in range(8):
+            p, v, a, phi, extra = integration.integrate(p, v, a, phi, extra, tables, param, 1e30)
+        if policy:
+            assert param.get("_resorted_f64", 0) >= 5
+            inv = np.argsort(param["particle_id"].cpu().numpy())
+            out[policy] = (p.cpu().numpy()[inv], v.cpu().numpy()[inv], a.cpu().numpy()[inv])
+        else:
+            out[policy] = (p.cpu().numpy(), v.cpu().numpy(), a.cpu().numpy())
+    d = np.abs(out[True][0] - out[False][0])
+    assert np.minimum(d, 1 - d).max() <= 1e-12
+    assert np.abs(out[True][1] - out[False][1]).max() <= 1e-11 * np.abs(out[False][1]).max()
+    assert np.abs(out[True][2] - out[False][2]).max() <= 1e-9 * np.abs(out[False][2]).max()
