@@ -339,7 +339,14 @@ __global__ __launch_bounds__(BLK) void greens64_kernel(double2 *__restrict__ x, 
             g = c0 / ((s[i] + s[j]) + s[k]);
         } else {
             const double invk2 = c0 / ((k2[i] + k2[j]) + k2[k]);
-            g = KIND == PM_GREEN_COMPENSATED ? pow((s[i] * s[j]) * s[k], (double)(-2 * p)) * invk2 : invk2;
+            if (KIND == PM_GREEN_COMPENSATED) {  // w^(-2p) for the small integer p of the mass scheme: products, one division
+                const double w = (s[i] * s[j]) * s[k], w2 = w * w;
+                double wp = w2;
+                for (int e = 1; e < p; ++e) wp *= w2;
+                g = invk2 / wp;  // (pow(w, -2p) to an ulp or two: 1e-16, against the 1e-10 this mode is held to)
+            } else {
+                g = invk2;
+            }
         }
         double2 v = x[t];
         if (t == 0) v = make_double2(0.0, 0.0);  // x[0,0,0] = 0 (fourier.py:491, 544, 595)
@@ -753,6 +760,7 @@ extern "C" int pm_real64_poisson_fft(pm_ctx *c, int kind, int p, const double *d
                                      const double *h_s, double c0) {
     PM_REQUIRE_F64(c);
     PM_REQUIRE(d_rhs && d_phi && h_k2 && h_s, "NULL argument");
+    PM_REQUIRE(kind != PM_GREEN_COMPENSATED || (p >= 1 && p <= 16), "the compensated Green's function needs the mass-scheme index p >= 1");
     int rc = build_plans64(c);
     if (rc) return rc;
     const int n = c->n;
