@@ -165,6 +165,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pm_real64_pk": (_vp, _i, _vp, _vp, _vp, _vp, _vp),
     "pm_real64_reorder_particles": (_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i),
     "pm_real64_stream_age": (_vp, _vp, _vp, _vp, _vp),
+    "pm_real64_reserve_sort": (_vp, _i64),
 }
 _RESTYPES = {"pm_last_error": C.c_char_p, "pm_khalo_floats": C.c_int64, "pm_khalo_floats_slab": C.c_int64}
 

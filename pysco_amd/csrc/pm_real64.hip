@@ -435,6 +435,63 @@ __global__ __launch_bounds__(BLK) void gradient64_rows_kernel(const double *__re
     }
 }
 
+// The same marching along x (n >= 128; the fp32 mode's gradient_march_kernel in double): a workgroup owns a patch of 8
+// rows x 32 double2 (64 k-cells) and walks 32 planes; a thread keeps its two cells of planes i - R .. i + R in registers
+// (every plane of phi is loaded once along x), its y neighbours are the loads of the threads beside it (L1), its z
+// window two more double2.  Same expression per cell (stencil64).
+template <int ORDER>
+__global__ __launch_bounds__(BLK) void gradient64_march_kernel(const double *__restrict__ phi, int n, int log2n, int seg,
+                                                               double *__restrict__ force) {
+    constexpr int R = (ORDER == 2 || ORDER == 3) ? 1 : (ORDER == 5 ? 2 : 3), W = (R + 1) & ~1;
+    const double scale = ORDER == 2 ? (double)n : (ORDER == 3 ? 0.5 * n : (ORDER == 5 ? n / 12.0 : n / 60.0));
+    const int nq = n >> 1, pk = nq >> 5, pj = n >> 3;
+    const int patch = (int)(blockIdx.x % (pk * pj));
+    const int i0 = (int)(blockIdx.x / (pk * pj)) * seg;
+    const int k = ((patch % pk) * 32 + (threadIdx.x & 31)) << 1, j = (patch / pk) * 8 + (threadIdx.x >> 5);
+    auto ld = [&](int ii, int jj, int kk) { return *reinterpret_cast<const double2 *>(phi + cell_index(n, log2n, ii, jj, kk)); };
+    double2 w[2 * R + 1];
+#pragma unroll
+    for (int o = 0; o < 2 * R; ++o) w[o + 1] = ld(i0 - R + o, j, k);
+#pragma unroll 1
+    for (int i = i0; i < i0 + seg; ++i) {
+#pragma unroll
+        for (int o = 0; o < 2 * R; ++o) w[o] = w[o + 1];
+        w[2 * R] = ld(i + R, j, k);
+        double ax[2][7], ay[2][7], az[2][7], zw[2 * W + 2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int o = 0; o < 7; ++o) ax[c][o] = ay[c][o] = az[c][o] = 0.0;
+#pragma unroll
+        for (int o = -R; o <= R; ++o) {
+            ax[0][o + 3] = w[o + R].x, ax[1][o + 3] = w[o + R].y;
+            if (o == 0) continue;
+            const double2 vy = ld(i, j + o, k);
+            ay[0][o + 3] = vy.x, ay[1][o + 3] = vy.y;
+        }
+        ay[0][3] = w[R].x, ay[1][3] = w[R].y;
+#pragma unroll
+        for (int q = 0; q <= W; ++q) {
+            const double2 v = (2 * q == W) ? w[R] : ld(i, j, k - W + 2 * q);
+            zw[2 * q] = v.x, zw[2 * q + 1] = v.y;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int o = -R; o <= R; ++o) az[c][o + 3] = zw[W + c + o];
+        double g[6];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            g[3 * c] = stencil64<ORDER>(ax[c], scale);
+            g[3 * c + 1] = stencil64<ORDER>(ay[c], scale);
+            g[3 * c + 2] = stencil64<ORDER>(az[c], scale);
+        }
+        double *o = force + 3 * cell_index(n, log2n, i, j, k);  // (read once, by the gather's tile fills: nontemporal)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) __builtin_nontemporal_store(g[m], o + m);
+    }
+}
+
 // ---- gather + second kick + CFL maxima ----------------------------------------------------------------------------
 // 27 (8, 1) cells read through `at(a, b, c, m)`, summed in the reference's left-to-right order (mesh.py:3058-3086)
 template <int SCHEME, class F>
@@ -785,6 +842,19 @@ extern "C" int pm_real64_gradient(pm_ctx *c, int order, const double *d_phi, dou
     PM_REQUIRE_F64(c);
     PM_REQUIRE(d_phi && d_force, "NULL argument");
     const int n = c->n;
+    if (n >= 128 && pm_aligned16(d_phi) && pm_aligned16(d_force)) {
+        const int seg = 32;
+        const dim3 gm((unsigned)(((n >> 1) >> 5) * (n >> 3) * (n / seg)));
+        switch (order) {
+            case 2: hipLaunchKernelGGL((gradient64_march_kernel<2>), gm, dim3(BLK), 0, c->stream, d_phi, n, c->log2n, seg, d_force); break;
+            case 3: hipLaunchKernelGGL((gradient64_march_kernel<3>), gm, dim3(BLK), 0, c->stream, d_phi, n, c->log2n, seg, d_force); break;
+            case 5: hipLaunchKernelGGL((gradient64_march_kernel<5>), gm, dim3(BLK), 0, c->stream, d_phi, n, c->log2n, seg, d_force); break;
+            case 7: hipLaunchKernelGGL((gradient64_march_kernel<7>), gm, dim3(BLK), 0, c->stream, d_phi, n, c->log2n, seg, d_force); break;
+            default: pm_set_error("gradient_order=%d, should be 2, 3, 5 or 7", order); return PM_EINVAL;
+        }
+        PM_LAUNCH_CHECK();
+        return PM_OK;
+    }
     if (n >= 8 && pm_aligned16(d_phi) && pm_aligned16(d_force)) {
         const dim3 grid2(blocks_for((int64_t)n * n * n / 2, BLK));
         switch (order) {
@@ -914,6 +984,32 @@ __global__ __launch_bounds__(BLK) void gather3_64_kernel(const unsigned *__restr
 }
 }  // namespace
 
+// keys in / out, values in / out and rocPRIM's scratch of the sort, in the context's sort workspace (grown on demand: a
+// device allocation of a few GB, ~0.15 s -- pm_real64_reserve_sort takes it out of the step loop)
+static int sort64_workspace(pm_ctx *c, int64_t np, size_t *tmp_bytes, size_t *karr, size_t *varr) {
+    unsigned long long *nullk = nullptr;
+    unsigned *nullv = nullptr;
+    *tmp_bytes = 0;
+    PM_HIP(rocprim::radix_sort_pairs(nullptr, *tmp_bytes, nullk, nullk, nullv, nullv, (size_t)np, 0, 63, c->stream));
+    *karr = ((size_t)np * sizeof(unsigned long long) + 255) & ~(size_t)255;
+    *varr = ((size_t)np * sizeof(unsigned) + 255) & ~(size_t)255;
+    const size_t need = 2 * *karr + 2 * *varr + *tmp_bytes;
+    if (c->sort_tmp_bytes < need) {
+        if (c->sort_tmp) PM_HIP(hipFree(c->sort_tmp));
+        c->sort_tmp = nullptr, c->sort_tmp_bytes = 0;
+        PM_HIP(hipMalloc(&c->sort_tmp, need));
+        c->sort_tmp_bytes = need;
+    }
+    return PM_OK;
+}
+
+extern "C" int pm_real64_reserve_sort(pm_ctx *c, int64_t np) {
+    PM_REQUIRE_F64(c);
+    PM_REQUIRE(np > 0 && np < 2147483647LL, "bad argument");
+    size_t a, b, d;
+    return sort64_workspace(c, np, &a, &b, &d);
+}
+
 extern "C" int pm_real64_reorder_particles(pm_ctx *c, int64_t np, const double *d_pos, const double *d_vel,
                                            const double *d_acc, double *d_pos_out, double *d_vel_out, double *d_acc_out,
                                            int64_t *d_perm, int key_bits) {
@@ -926,19 +1022,9 @@ extern "C" int pm_real64_reorder_particles(pm_ctx *c, int64_t np, const double *
     // (-1: to the tiles of this context's mesh -- a tile is 2^11 consecutive cell codes, LI + LJ + LK bits)
     const int tile_bits = 3 * c->log2n - (LI + LJ + LK);
     const unsigned begin_bit = key_bits > 0 ? 3u * (unsigned)(21 - key_bits) : key_bits < 0 ? (unsigned)(63 - (tile_bits > 1 ? tile_bits : 1)) : 0u;
-    size_t tmp_bytes = 0;
-    unsigned long long *nullk = nullptr;
-    unsigned *nullv = nullptr;
-    PM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, nullk, nullk, nullv, nullv, (size_t)np, begin_bit, 63, c->stream));
-    const size_t karr = ((size_t)np * sizeof(unsigned long long) + 255) & ~(size_t)255;
-    const size_t varr = ((size_t)np * sizeof(unsigned) + 255) & ~(size_t)255;
-    const size_t need = 2 * karr + 2 * varr + tmp_bytes;
-    if (c->sort_tmp_bytes < need) {
-        if (c->sort_tmp) PM_HIP(hipFree(c->sort_tmp));
-        c->sort_tmp = nullptr, c->sort_tmp_bytes = 0;
-        PM_HIP(hipMalloc(&c->sort_tmp, need));
-        c->sort_tmp_bytes = need;
-    }
+    size_t tmp_bytes = 0, karr = 0, varr = 0;
+    int rc = sort64_workspace(c, np, &tmp_bytes, &karr, &varr);
+    if (rc) return rc;
     char *w = (char *)c->sort_tmp;
     unsigned long long *keys_in = (unsigned long long *)w, *keys_out = (unsigned long long *)(w + karr);
     unsigned *iota = (unsigned *)(w + 2 * karr), *perm = (unsigned *)(w + 2 * karr + varr);

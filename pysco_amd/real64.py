@@ -172,6 +172,15 @@ def integrate(position, velocity, acceleration, potential, additional_field, tab
     # and velocity move (the old acceleration is dead after the kick).
     resort = False
     if not host and param.get("rebucket_straggler_fraction") is not None:
+        if param.get("_f64_reserved") != pos_d.shape[0]:
+            # what a re-sort needs, taken once and outside the steps that sort: the sort workspace and two spare particle
+            # arrays in the loop's pool (device allocations of several GB cost ~0.15 s)
+            from . import mesh
+
+            L.context(n, 8).call("pm_real64_reserve_sort", pos_d.shape[0])
+            torch = L.require_gpu()
+            mesh.pool_give(torch.empty_like(pos_d), torch.empty_like(vel_d))
+            param["_f64_reserved"] = pos_d.shape[0]
         age = stream_age(n)
         if age is not None and not param.get("_f64_sorted_last", False):
             param["_f64_aged_passes"] = age[1]

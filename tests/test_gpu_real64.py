@@ -304,3 +304,20 @@ def test_real64_steps_with_the_resort_policy_match_in_place_steps():
     assert np.minimum(d, 1 - d).max() <= 1e-12
     assert np.abs(out[True][1] - out[False][1]).max() <= 1e-11 * np.abs(out[False][1]).max()
     assert np.abs(out[True][2] - out[False][2]).max() <= 1e-9 * np.abs(out[False][2]).max()
+
+
+@pytest.mark.parametrize("order", [2, 3, 5, 7])
+def test_real64_marching_gradient_is_the_cpu_stencil(order):
+    """pm_real64_gradient at 128^3 (the marching kernel: planes along x kept in registers) against the fp64 CPU
+    stencils: bit-identical, every order."""
+    import torch
+
+    from pysco_amd import _lib as L
+
+    n = 128
+    rng = np.random.default_rng(order)
+    phi = rng.standard_normal((n, n, n))
+    pd = torch.from_numpy(phi).cuda()
+    force = torch.empty((n, n, n, 3), dtype=torch.float64, device="cuda")
+    L.context(n, 8).call("pm_real64_gradient", order, L.ptr(pd), L.ptr(force))
+    np.testing.assert_array_equal(force.cpu().numpy(), o64.derivative(phi, order))
