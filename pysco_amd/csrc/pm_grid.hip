@@ -389,10 +389,11 @@ __global__ __launch_bounds__(BLK) void gradient_march_kernel(const float *__rest
             for (int o = 0; o < 7; ++o) sa[o] = az[4 + c + o - 3], sb[o] = (FRN > 0) ? bz[4 + c + o - 3] : 0.f;
             res[3 * c + 2] = Stencil<ORDER, FRN>::eval(sa, sb, f, scale);
         }
-        float4 *o4 = reinterpret_cast<float4 *>(out + 3 * (((((int64_t)i << log2n) + j) << log2n) + k0));
-        o4[0] = make_float4(res[0], res[1], res[2], res[3]);
-        o4[1] = make_float4(res[4], res[5], res[6], res[7]);
-        o4[2] = make_float4(res[8], res[9], res[10], res[11]);
+        // (the force grid is read once, by the gather's tile fills: nontemporal)
+        probe_v4f *o4 = reinterpret_cast<probe_v4f *>(out + 3 * (((((int64_t)i << log2n) + j) << log2n) + k0));
+        __builtin_nontemporal_store(probe_v4f{res[0], res[1], res[2], res[3]}, o4);
+        __builtin_nontemporal_store(probe_v4f{res[4], res[5], res[6], res[7]}, o4 + 1);
+        __builtin_nontemporal_store(probe_v4f{res[8], res[9], res[10], res[11]}, o4 + 2);
     }
 }
 
